@@ -1,0 +1,227 @@
+"""Generic D2Q9 BGK lattice on one MI355X (or one row slab of a multi-GPU run).
+
+``Simulation`` owns a ``liblbhip`` handle and mirrors the method surface of the reference's
+``LB_D2Q9.dimensionless.opencl_dim.Pipe_Flow`` (opencl_dim.py:295-438): ``move``, ``move_bcs``,
+``update_hydro``, ``update_feq``, ``collide_particles``, ``run(n)``, ``get_fields()``, plus
+``step()`` == ``run(1)``.  It takes lattice parameters directly (nx, ny, omega, boundary family);
+the physical-units constructors live in ``LB_D2Q9.dimensionless.hip_dim``.
+
+Host arrays use the reference's conventions: F-ordered float32 ``(nx, ny)`` / ``(nx, ny, 9)``
+(opencl_dim.py:165, 279, 390-415); for a row slab ``ny`` is the slab height.
+"""
+import ctypes as ct
+
+import numpy as np
+
+from . import _native
+from ._native import LbError, check
+
+NUM_JUMPERS = 9
+
+
+def _f_order(a, shape, dtype=np.float32):
+    a = np.asarray(a)
+    if a.shape != shape:
+        raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+    return np.asfortranarray(a.astype(dtype, copy=False))
+
+
+def _address(buf):
+    if isinstance(buf, np.ndarray):
+        assert buf.dtype == np.float32 and buf.flags.c_contiguous
+        return buf.ctypes.data
+    return int(buf)
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the caller broadcasts it)."""
+    uid = (ct.c_char * 128)()
+    check(_native.lib().lb_comm_unique_id(uid))
+    return bytes(uid.raw)
+
+
+class Simulation(object):
+    def __init__(self, nx, ny, omega, bc="pipe", inlet_rho=1., outlet_rho=1., lid_u=0., rho0=1.,
+                 obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False):
+        """
+        :param nx, ny: global grid size (cells, boundary nodes included).
+        :param omega: BGK relaxation rate, 0 < omega < 2.
+        :param bc: 'pipe' (the reference's pressure inlet/outlet + no-slip walls, D2Q9.cl:173-261),
+                   'periodic' or 'cavity' (lid-driven; build-defined, see oracle/d2q9_oracle.c).
+        :param obstacle_mask: optional (nx, ny) array, non-zero = solid (bounce-back, D2Q9.cl:398-433).
+        :param y0, local_ny: the row slab this object owns (multi-GPU); default = whole grid.
+        :param halo: fill the ghost rows through the halo interface even for a whole-grid handle.
+        """
+        if isinstance(bc, str):
+            if bc not in _native.BC_NAMES:
+                raise ValueError("bc must be one of %s" % sorted(_native.BC_NAMES))
+            bc = _native.BC_NAMES[bc]
+        self.nx, self.ny = int(nx), int(ny)
+        self.y0 = int(y0)
+        self.local_ny = self.ny if local_ny is None else int(local_ny)
+        self.omega = omega
+        self.bc_mode = bc
+        self.inlet_rho, self.outlet_rho = inlet_rho, outlet_rho
+        self.lid_u, self.rho0 = lid_u, rho0
+        self.device = int(device)
+        self._lib = _native.lib()            # raises if liblbhip.so is missing: no CPU fallback
+        p = _native.LbParams()
+        p.nx, p.ny, p.y0, p.local_ny = self.nx, self.ny, self.y0, self.local_ny
+        p.bc_mode, p.device = bc, self.device
+        p.flags = _native.LB_FLAG_HALO if halo else 0
+        p.omega = np.float32(omega)
+        p.inlet_rho, p.outlet_rho = np.float32(inlet_rho), np.float32(outlet_rho)
+        p.lid_u, p.rho0 = np.float32(lid_u), np.float32(rho0)
+        self._h = ct.c_void_p()
+        check(self._lib.lb_create(ct.byref(p), ct.byref(self._h)))
+        self._shape2 = (self.nx, self.local_ny)
+        self._shape3 = (self.nx, self.local_ny, NUM_JUMPERS)
+        if obstacle_mask is not None:
+            self.set_obstacle_mask(obstacle_mask)
+
+    # -- lifetime ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lb_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._lib.lb_sync(self._h))
+
+    # -- state -------------------------------------------------------------
+    def set_obstacle_mask(self, mask):
+        """(nx, local_ny) array; cells equal to 1/True are solid.  None removes the obstacle."""
+        if mask is None:
+            check(self._lib.lb_set_mask(self._h, None))
+            return
+        m = _f_order(np.asarray(mask) != 0, self._shape2, np.int32)
+        check(self._lib.lb_set_mask(self._h, m.ctypes.data))
+
+    def set_fields(self, rho, u, v):
+        """Upload the macroscopic fields (what init_hydro does, opencl_dim.py:291-293)."""
+        r, uu, vv = (_f_order(a, self._shape2) for a in (rho, u, v))
+        check(self._lib.lb_set_macro(self._h, r.ctypes.data, uu.ctypes.data, vv.ctypes.data))
+
+    def set_f(self, f):
+        """Upload the populations, (nx, local_ny, 9); also fills the streaming buffer."""
+        ff = _f_order(f, self._shape3)
+        check(self._lib.lb_set_f(self._h, ff.ctypes.data))
+
+    def init_pop(self, perturb=None):
+        """f = f_streamed = feq * perturb (opencl_dim.py:308-327); perturb None = exactly feq."""
+        if perturb is None:
+            check(self._lib.lb_init_pop(self._h))
+            self.sync()
+        else:
+            f = self.get_fields(("feq",))["feq"]
+            f *= np.asarray(perturb)
+            self.set_f(f)
+
+    def init_equilibrium(self, rho, u, v, perturb=None):
+        """rho,u,v -> feq -> f = feq * perturb (the construction sequence of opencl_dim.py:163-178)."""
+        self.set_fields(rho, u, v)
+        self.update_feq()
+        self.init_pop(perturb)
+
+    # -- the reference's phases, one kernel each (slow path, API parity) -----
+    def move(self):
+        check(self._lib.lb_move(self._h))
+        self.sync()
+
+    def move_bcs(self):
+        check(self._lib.lb_move_bcs(self._h))
+        self.sync()
+
+    def update_hydro(self):
+        check(self._lib.lb_update_hydro(self._h))
+        self.sync()
+
+    def update_feq(self):
+        check(self._lib.lb_update_feq(self._h))
+        self.sync()
+
+    def collide_particles(self):
+        check(self._lib.lb_collide_particles(self._h))
+        self.sync()
+
+    def zero_velocity_in_obstacle(self):
+        check(self._lib.lb_zero_velocity_in_obstacle(self._h))
+        self.sync()
+
+    # -- the hot path --------------------------------------------------------
+    def run(self, num_iterations, wait=True):
+        """num_iterations fused time steps (one HIP launch each).  The reference returns with the
+        work complete (it waits after every kernel); pass wait=False to only enqueue."""
+        check(self._lib.lb_run(self._h, int(num_iterations)))
+        if wait:
+            self.sync()
+
+    def step(self):
+        self.run(1)
+
+    def timed_run(self, num_iterations):
+        """run() bracketed by HIP events on the engine's stream; returns milliseconds."""
+        ms = ct.c_float()
+        check(self._lib.lb_timer_start(self._h))
+        check(self._lib.lb_run(self._h, int(num_iterations)))
+        check(self._lib.lb_timer_stop(self._h, ct.byref(ms)))
+        return ms.value
+
+    # -- read-back -------------------------------------------------------------
+    def get_fields(self, which=("f", "feq", "u", "v", "rho")):
+        """Dictionary of host copies, same keys/shapes/orders as opencl_dim.py:390-415."""
+        out = {}
+        if "f" in which:
+            out["f"] = np.zeros(self._shape3, np.float32, order="F")
+            check(self._lib.lb_get_f(self._h, out["f"].ctypes.data))
+        if "feq" in which:
+            out["feq"] = np.zeros(self._shape3, np.float32, order="F")
+            check(self._lib.lb_get_feq(self._h, out["feq"].ctypes.data))
+        macro = [k for k in ("rho", "u", "v") if k in which]
+        if macro:
+            for k in macro:
+                out[k] = np.zeros(self._shape2, np.float32, order="F")
+            ptr = lambda k: out[k].ctypes.data if k in out else None
+            check(self._lib.lb_get_macro(self._h, ptr("rho"), ptr("u"), ptr("v")))
+        return out
+
+    # -- row-slab stepping (driven by LB_D2Q9.slabs) -------------------------------
+    def step_boundary(self, write_macro=False):
+        check(self._lib.lb_step_boundary(self._h, int(bool(write_macro))))
+
+    def step_interior(self, write_macro=False):
+        check(self._lib.lb_step_interior(self._h, int(bool(write_macro))))
+
+    def step_finish(self):
+        check(self._lib.lb_step_finish(self._h))
+
+    def halo_export(self, side, buf):
+        """Copy the 3 populations leaving through edge `side` (0 south, 1 north) into buf[3*nx]
+        (numpy float32 array or a raw host/device address)."""
+        check(self._lib.lb_halo_export(self._h, int(side), _address(buf)))
+
+    def halo_import(self, side, buf):
+        check(self._lib.lb_halo_import(self._h, int(side), _address(buf)))
+
+    def use_stream(self, hip_stream):
+        """Run on an external hipStream_t (integer handle, e.g. torch's current stream); None = own."""
+        check(self._lib.lb_set_stream(self._h, hip_stream))
+
+    def comm_init(self, unique_id, rank, nranks):
+        """Attach an RCCL communicator: run() then exchanges halos itself (lb_comm_init)."""
+        check(self._lib.lb_comm_init(self._h, unique_id, int(rank), int(nranks)))
+
+    # -- tuning / introspection ------------------------------------------------
+    def set_variant(self, variant):
+        check(self._lib.lb_set_variant(self._h, int(variant)))
+
+    def layout(self):
+        a, b, c = ct.c_int64(), ct.c_int64(), ct.c_int64()
+        check(self._lib.lb_layout(self._h, ct.byref(a), ct.byref(b), ct.byref(c)))
+        return {"pitch": a.value, "plane_stride": b.value, "bytes": c.value}

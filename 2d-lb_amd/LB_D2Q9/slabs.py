@@ -1,0 +1,256 @@
+"""Row-slab decomposition of the lattice across GPUs (new work: the reference is single-device).
+
+The grid is cut along y (the slow axis of the device layout) into contiguous row slabs, one per
+GPU / process.  Streaming reaches one cell, so per step each slab needs from its neighbours only
+the three populations that cross the shared edge: k=2,5,6 travel north, k=4,7,8 travel south
+(3*nx floats per direction per step).  There is no collective on the data path.
+
+* ``partition_rows`` / ``neighbours``  - the arithmetic.
+* ``LocalSlabRing``     - G slabs on ONE device, halos copied with lb_halo_export/import.  Used to
+                          prove that a partitioned run equals the single-slab run bit for bit.
+* ``DistributedSlab``   - one process per GPU under ``torch.distributed``.  transport='rccl': the
+                          engine exchanges halos itself inside ``lb_run`` (RCCL send/recv on a side
+                          HIP stream, overlapped with the interior rows).  transport='torch': the
+                          exchange is driven from here with ``torch.distributed`` point-to-point ops
+                          (any backend; also the path the CPU/gloo tests exercise with a stand-in
+                          engine injected through ``engine_factory``).
+"""
+import numpy as np
+
+from . import _native
+
+SOUTH, NORTH = 0, 1
+
+
+def partition_rows(ny, nparts):
+    """Balanced contiguous split of ny rows: list of (y0, height); the first ny % nparts slabs get
+    one extra row."""
+    if nparts < 1 or nparts > ny:
+        raise ValueError("cannot cut %d rows into %d slabs" % (ny, nparts))
+    base, extra = divmod(ny, nparts)
+    out, y0 = [], 0
+    for r in range(nparts):
+        h = base + (1 if r < extra else 0)
+        out.append((y0, h))
+        y0 += h
+    return out
+
+
+def neighbours(rank, nranks, periodic):
+    """(south, north) ranks of slab `rank`; -1 where the slab touches a wall."""
+    south = rank - 1 if rank > 0 else (nranks - 1 if periodic else -1)
+    north = rank + 1 if rank < nranks - 1 else (0 if periodic else -1)
+    return south, north
+
+
+def _is_periodic(bc):
+    return bc in ("periodic", _native.LB_BC_PERIODIC) and not isinstance(bc, bool)
+
+
+def _default_engine(**kw):
+    from .simulation import Simulation
+    return Simulation(**kw)
+
+
+class _SlabSet(object):
+    """Shared scatter/gather helpers: global F-ordered (nx, ny[, 9]) arrays <-> per-slab pieces."""
+
+    def _cut(self, a, y0, h):
+        return np.asfortranarray(np.asarray(a)[:, y0:y0 + h])
+
+
+class LocalSlabRing(_SlabSet):
+    """G virtual slabs on one device.  Not a performance path: it exists so that
+    'partitioned == unpartitioned, bit for bit' can be tested on a single GPU."""
+
+    def __init__(self, nx, ny, omega, nslabs, bc="pipe", obstacle_mask=None, device=0, **kw):
+        self.nx, self.ny, self.bc = nx, ny, bc
+        self.parts = partition_rows(ny, nslabs)
+        self.periodic = _is_periodic(bc)
+        self.slabs = []
+        for (y0, h) in self.parts:
+            m = None if obstacle_mask is None else self._cut(obstacle_mask, y0, h)
+            self.slabs.append(_default_engine(nx=nx, ny=ny, omega=omega, bc=bc, obstacle_mask=m,
+                                              device=device, y0=y0, local_ny=h, halo=True, **kw))
+        self._buf = np.zeros((len(self.slabs), 2, 3 * nx), np.float32)
+        self._ghosts_valid = False
+
+    def set_f(self, f):
+        for s, (y0, h) in zip(self.slabs, self.parts):
+            s.set_f(self._cut(f, y0, h))
+        self._ghosts_valid = False
+
+    def _exchange(self):
+        n = len(self.slabs)
+        for r, s in enumerate(self.slabs):
+            s.halo_export(SOUTH, self._buf[r, SOUTH])
+            s.halo_export(NORTH, self._buf[r, NORTH])
+        for s in self.slabs:
+            s.sync()
+        for r, s in enumerate(self.slabs):
+            south, north = neighbours(r, n, self.periodic)
+            if south >= 0:
+                s.halo_import(SOUTH, self._buf[south, NORTH])   # what the southern slab sent north
+            if north >= 0:
+                s.halo_import(NORTH, self._buf[north, SOUTH])
+        for s in self.slabs:
+            s.sync()
+
+    def run(self, n):
+        if not self._ghosts_valid:
+            self._exchange()
+        for it in range(n):
+            macro = (it == n - 1)
+            for s in self.slabs:
+                s.step_boundary(macro)
+                s.step_interior(macro)
+            self._exchange()            # halos of the lattice just written
+            for s in self.slabs:
+                s.step_finish()
+        self._ghosts_valid = True
+
+    def get_fields(self, which=("f", "feq", "u", "v", "rho")):
+        pieces = [s.get_fields(which) for s in self.slabs]
+        return {k: np.asfortranarray(np.concatenate([p[k] for p in pieces], axis=1)) for k in which}
+
+
+class DistributedSlab(_SlabSet):
+    """This process's slab of a multi-GPU lattice.  Requires an initialised
+    ``torch.distributed`` process group (backend 'nccl' == RCCL on ROCm, or 'gloo')."""
+
+    def __init__(self, nx, ny, omega, bc="pipe", obstacle_mask=None, transport="rccl", device=None,
+                 engine_factory=None, group=None, **kw):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.nranks = dist.get_world_size(group)
+        self.nx, self.ny, self.bc = nx, ny, bc
+        self.periodic = _is_periodic(bc)
+        self.parts = partition_rows(ny, self.nranks)
+        self.y0, self.h = self.parts[self.rank]
+        self.south, self.north = neighbours(self.rank, self.nranks, self.periodic)
+        self.transport = transport
+        make = engine_factory or _default_engine
+        m = None if obstacle_mask is None else self._cut(obstacle_mask, self.y0, self.h)
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", "0")) if engine_factory is None else 0
+        self.engine = make(nx=nx, ny=ny, omega=omega, bc=bc, obstacle_mask=m, device=device,
+                           y0=self.y0, local_ny=self.h, halo=True, **kw)
+        self._ghosts_valid = False
+        self._bufs = None
+        if transport == "rccl":
+            self._attach_rccl()
+        elif transport != "torch":
+            raise ValueError("transport must be 'rccl' or 'torch'")
+
+    # -- RCCL inside the engine ------------------------------------------------------------------
+    def _attach_rccl(self):
+        import torch
+        from .simulation import comm_unique_id
+        dist = self._dist
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", self.engine.device) if on_gpu else torch.device("cpu")
+        if on_gpu:
+            torch.cuda.set_device(dev)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            uid = torch.tensor(list(comm_unique_id()), dtype=torch.uint8, device=dev)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(uid, src=src, group=self.group)
+        self.engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.nranks)
+
+    # -- torch.distributed driven exchange ----------------------------------------------------------
+    def _torch_buffers(self):
+        if self._bufs is None:
+            import torch
+            on_gpu = self._dist.get_backend(self.group) == "nccl"
+            dev = torch.device("cuda", self.engine.device) if on_gpu else torch.device("cpu")
+            if on_gpu:
+                torch.cuda.set_device(dev)
+                # one stream for kernels, halo copies and torch's collectives' stream dependencies
+                self.engine.use_stream(torch.cuda.current_stream().cuda_stream)
+            mk = lambda: torch.zeros(3 * self.nx, dtype=torch.float32, device=dev)
+            self._bufs = {"send_s": mk(), "send_n": mk(), "recv_s": mk(), "recv_n": mk(), "gpu": on_gpu}
+        return self._bufs
+
+    @staticmethod
+    def _ptr(t):
+        return t.data_ptr()
+
+    def _exchange_torch(self):
+        """Edge rows of the lattice the next step reads -> neighbours' ghost rows."""
+        import torch
+        dist, b = self._dist, self._torch_buffers()
+        eng = self.engine
+        eng.halo_export(SOUTH, self._ptr(b["send_s"]))
+        eng.halo_export(NORTH, self._ptr(b["send_n"]))
+        if not b["gpu"]:
+            eng.sync()
+        grank = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
+        if self.nranks == 1:
+            if self.periodic:
+                b["recv_s"].copy_(b["send_n"])
+                b["recv_n"].copy_(b["send_s"])
+        else:
+            # posting order: sends north then south, receives south then north, so that with two
+            # ranks (both neighbours are the same peer) the n-th send meets the n-th receive
+            ops = []
+            if self.north >= 0:
+                ops.append(dist.P2POp(dist.isend, b["send_n"], grank(self.north), self.group))
+            if self.south >= 0:
+                ops.append(dist.P2POp(dist.isend, b["send_s"], grank(self.south), self.group))
+            if self.south >= 0:
+                ops.append(dist.P2POp(dist.irecv, b["recv_s"], grank(self.south), self.group))
+            if self.north >= 0:
+                ops.append(dist.P2POp(dist.irecv, b["recv_n"], grank(self.north), self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.south >= 0:
+            eng.halo_import(SOUTH, self._ptr(b["recv_s"]))
+        if self.north >= 0:
+            eng.halo_import(NORTH, self._ptr(b["recv_n"]))
+        if not b["gpu"]:
+            eng.sync()
+
+    # -- public API -------------------------------------------------------------------------------------
+    def set_f(self, f_global):
+        """Every rank passes the same global (nx, ny, 9) array and keeps its rows."""
+        self.engine.set_f(self._cut(f_global, self.y0, self.h))
+        self._ghosts_valid = False
+
+    def set_f_local(self, f_slab):
+        self.engine.set_f(f_slab)
+        self._ghosts_valid = False
+
+    def run(self, n, wait=True):
+        if self.transport == "rccl":
+            self.engine.run(n, wait=wait)
+            return
+        if n and not self._ghosts_valid:
+            self._exchange_torch()
+        for it in range(n):
+            macro = (it == n - 1)
+            self.engine.step_boundary(macro)
+            self.engine.step_interior(macro)
+            self._exchange_torch()
+            self.engine.step_finish()
+        self._ghosts_valid = True
+        if wait:
+            self.engine.sync()
+
+    def timed_run(self, n):
+        """HIP-event time of run(n) on this rank's stream, ms (transport 'rccl' only)."""
+        return self.engine.timed_run(n)
+
+    def get_local_fields(self, which=("f", "feq", "u", "v", "rho")):
+        return self.engine.get_fields(which)
+
+    def get_fields(self, which=("f", "u", "v", "rho")):
+        """Gather the slabs of every rank (all ranks receive the global arrays).  For tests and
+        small grids; large runs should read ``get_local_fields``."""
+        local = self.get_local_fields(which)
+        gathered = [None] * self.nranks
+        self._dist.all_gather_object(gathered, local, group=self.group)
+        return {k: np.asfortranarray(np.concatenate([g[k] for g in gathered], axis=1)) for k in which}

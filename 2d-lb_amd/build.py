@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Build liblbhip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python 2d-lb_amd/build.py            # -> 2d-lb_amd/LB_D2Q9/liblbhip.so
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "lb_hip.cpp")
+HDR = os.path.join(os.path.dirname(HERE), "include", "lb_hip.h")
+OUT = os.path.join(HERE, "LB_D2Q9", "liblbhip.so")
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in (SRC, HDR, __file__))
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", SRC, "-o", OUT, "-ldl"]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,1095 @@
+// lb_hip.cpp -- MI355X (gfx950 / CDNA4) D2Q9 BGK lattice-Boltzmann engine behind the C ABI
+// of include/lb_hip.h.  Written for gfx950 only: wave64, 16-byte-per-lane global accesses,
+// one fused pull kernel per time step (72 algorithmic bytes per lattice update), no MFMA
+// (the path is a memory-bound stencil).
+//
+// What it replaces (reference = latticeboltzmann/2d-lb):
+//   LB_D2Q9/D2Q9.cl               update_feq :2-64, update_hydro :67-100, collide_particles :102-121,
+//                                 copy_buffer :123-137, move :139-171, move_bcs :173-261,
+//                                 set_zero_velocity_in_obstacle :377-396, bounceback_in_obstacle :398-433
+//   LB_D2Q9/dimensionless/opencl_dim.py   the pyopencl buffer/queue plumbing (:203-255, 291-293,
+//                                 323-327, 395-407) and the per-step launch sequence of run() (:372-387)
+//
+// Device layout: structure of arrays, nine planes per lattice, two lattices
+// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -1 and H
+// are ghost rows (slab halo / don't-care at walls), so element (k, x, y) of a slab of H rows lives at
+//   lattice + GUARD + k*plane + (y+1)*pitch + x .
+// All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
+// 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <initializer_list>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/lb_hip.h"
+
+namespace {
+
+constexpr int GUARD = 64;  // floats in front of / behind each lattice allocation
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(LB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+//  device code
+// ------------------------------------------------------------------------------------------
+
+typedef float f4a __attribute__((ext_vector_type(4)));              // 16-byte aligned
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword aligned
+typedef unsigned char uc4 __attribute__((ext_vector_type(4)));
+
+struct StepArgs {
+    const float *src;      // plane 0, row 0, x 0 of the lattice being read
+    float *dst;            // same element of the lattice being written
+    const uint8_t *mask;   // [H][pitch] or nullptr
+    float *rho, *u, *v;    // [H][pitch]
+    long long plane;       // plane stride, floats
+    int pitch;             // row pitch, floats
+    int nx, ny;            // global grid
+    int y0, h;             // slab origin / height
+    int row_begin, row_step, row_count;  // local rows visited: row_begin + i*row_step, i < row_count
+    int wrap_y;            // periodic in y inside one slab: wrap the source rows locally
+    float omega, rho_in, rho_out, lid_u, rho0;
+};
+
+// One cell's nine populations as named scalars (never an indexable array: the boundary rules
+// below assign different members on different branches, and an array would be demoted to scratch).
+struct Cell {
+    float f0, f1, f2, f3, f4, f5, f6, f7, f8;
+};
+
+// D2Q9.cl:173-261 (move_bcs) for one cell, float arithmetic (the reference's double literals
+// are not mimicked: SURVEY.md Appendix D.1 measured that difference at <= 1e-6 over 5000 steps).
+__device__ __forceinline__ void bc_pipe_cell(Cell &c, int x, int y, int nx, int ny, float rin, float rout)
+{
+    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
+    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    if (w && !s && !n) {                                   // inlet :198-203
+        const float uu = -((f0 + f2 + 2.f * f3 + f4 + 2.f * f6 + 2.f * f7 - rin) / rin);
+        const float a = (1.f / 6.f) * uu * rin;
+        c.f1 = f3 + (2.f / 3.f) * rin * uu;
+        c.f5 = -.5f * f2 + .5f * f4 + f7 + a;
+        c.f8 = .5f * f2 - .5f * f4 + f6 + a;
+    }
+    if (e && !s && !n) {                                   // outlet :205-210
+        const float uu = -1.f + (f0 + 2.f * f1 + f2 + f4 + 2.f * f5 + 2.f * f8) / rout;
+        const float a = (1.f / 6.f) * uu * rout;
+        c.f3 = f1 - (2.f / 3.f) * rout * uu;
+        c.f6 = -.5f * f2 + .5f * f4 + f8 - a;
+        c.f7 = .5f * f2 - .5f * f4 + f5 - a;
+    }
+    if (n && !w && !e) {                                   // north wall :213-217
+        c.f4 = f2;
+        c.f8 = .5f * (-f1 + f3 + 2.f * f6);
+        c.f7 = .5f * (f1 - f3 + 2.f * f5);
+    }
+    if (s && !w && !e) {                                   // south wall :219-223
+        c.f2 = f4;
+        c.f6 = .5f * (f1 - f3 + 2.f * f8);
+        c.f5 = .5f * (-f1 + f3 + 2.f * f7);
+    }
+    if (w && s) {                                          // corners :228-259
+        const float t = .5f * (-f0 - 2.f * f3 - 2.f * f4 - 2.f * f7 + rin);
+        c.f1 = f3; c.f2 = f4; c.f5 = f7; c.f6 = t; c.f8 = t;
+    }
+    if (w && n) {
+        const float t = .5f * (-f0 - 2.f * f2 - 2.f * f3 - 2.f * f6 + rin);
+        c.f1 = f3; c.f4 = f2; c.f8 = f6; c.f5 = t; c.f7 = t;
+    }
+    if (e && s) {
+        const float t = .5f * (-f0 - 2.f * f1 - 2.f * f4 - 2.f * f8 + rout);
+        c.f3 = f1; c.f2 = f4; c.f6 = f8; c.f5 = t; c.f7 = t;
+    }
+    if (e && n) {
+        const float t = .5f * (-f0 - 2.f * f1 - 2.f * f2 - 2.f * f5 + rout);
+        c.f3 = f1; c.f4 = f2; c.f7 = f5; c.f6 = t; c.f8 = t;
+    }
+}
+
+// Build-defined lid-driven cavity closure, oracle/d2q9_oracle.c o2_bc_cavity.
+__device__ __forceinline__ void bc_cavity_cell(Cell &c, int x, int y, int nx, int ny, float lid, float rho0)
+{
+    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
+    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    if (n && !w && !e) {
+        const float rw = f0 + f1 + f3 + 2.f * (f2 + f5 + f6);
+        c.f4 = f2;
+        c.f7 = 0.5f * (f1 - f3 + 2.f * f5) - 0.5f * rw * lid;
+        c.f8 = 0.5f * (-f1 + f3 + 2.f * f6) + 0.5f * rw * lid;
+    }
+    if (s && !w && !e) {
+        c.f2 = f4;
+        c.f6 = 0.5f * (f1 - f3 + 2.f * f8);
+        c.f5 = 0.5f * (-f1 + f3 + 2.f * f7);
+    }
+    if (w && !s && !n) {
+        c.f1 = f3;
+        c.f5 = 0.5f * (-f2 + f4 + 2.f * f7);
+        c.f8 = 0.5f * (f2 - f4 + 2.f * f6);
+    }
+    if (e && !s && !n) {
+        c.f3 = f1;
+        c.f6 = 0.5f * (-f2 + f4 + 2.f * f8);
+        c.f7 = 0.5f * (f2 - f4 + 2.f * f5);
+    }
+    if (w && s) {
+        const float t = 0.5f * (-f0 - 2.f * f3 - 2.f * f4 - 2.f * f7 + rho0);
+        c.f1 = f3; c.f2 = f4; c.f5 = f7; c.f6 = t; c.f8 = t;
+    }
+    if (w && n) {
+        const float t = 0.5f * (-f0 - 2.f * f2 - 2.f * f3 - 2.f * f6 + rho0);
+        c.f1 = f3; c.f4 = f2; c.f8 = f6; c.f5 = t; c.f7 = t;
+    }
+    if (e && s) {
+        const float t = 0.5f * (-f0 - 2.f * f1 - 2.f * f4 - 2.f * f8 + rho0);
+        c.f3 = f1; c.f2 = f4; c.f6 = f8; c.f5 = t; c.f7 = t;
+    }
+    if (e && n) {
+        const float t = 0.5f * (-f0 - 2.f * f1 - 2.f * f2 - 2.f * f5 + rho0);
+        c.f3 = f1; c.f4 = f2; c.f7 = f5; c.f6 = t; c.f8 = t;
+    }
+}
+
+// D2Q9.cl:398-433 (bounceback_in_obstacle): exchange opposite links on a solid cell.
+__device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
+{
+    const float f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    c.f1 = solid ? f3 : f1; c.f3 = solid ? f1 : f3;
+    c.f2 = solid ? f4 : f2; c.f4 = solid ? f2 : f4;
+    c.f5 = solid ? f7 : f5; c.f7 = solid ? f5 : f7;
+    c.f6 = solid ? f8 : f6; c.f8 = solid ? f6 : f8;
+}
+
+// Moments (D2Q9.cl:92-97), equilibrium (:55-60) and BGK relaxation (:119) of one cell.
+__device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
+{
+    rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
+    const float inv = 1.0f / rho;
+    ux = (c.f1 - c.f3 + c.f5 - c.f6 - c.f7 + c.f8) * inv;
+    uy = (c.f5 + c.f2 + c.f6 - c.f7 - c.f4 - c.f8) * inv;
+    const float usq = ux * ux + uy * uy;
+    const float base = 1.f - 1.5f * usq;
+    const float keep = 1.f - omega;
+    const float r0 = omega * (4.f / 9.f) * rho, r1 = omega * (1.f / 9.f) * rho, r2 = omega * (1.f / 36.f) * rho;
+    // feq_k = w_k rho (1 + 3 cu + 4.5 cu^2 - 1.5 usq)
+    c.f0 = c.f0 * keep + r0 * base;
+    c.f1 = c.f1 * keep + r1 * (base + 3.f * ux + 4.5f * ux * ux);
+    c.f3 = c.f3 * keep + r1 * (base - 3.f * ux + 4.5f * ux * ux);
+    c.f2 = c.f2 * keep + r1 * (base + 3.f * uy + 4.5f * uy * uy);
+    c.f4 = c.f4 * keep + r1 * (base - 3.f * uy + 4.5f * uy * uy);
+    const float p = ux + uy, m = ux - uy;
+    c.f5 = c.f5 * keep + r2 * (base + 3.f * p + 4.5f * p * p);
+    c.f7 = c.f7 * keep + r2 * (base - 3.f * p + 4.5f * p * p);
+    c.f8 = c.f8 * keep + r2 * (base + 3.f * m + 4.5f * m * m);
+    c.f6 = c.f6 * keep + r2 * (base - 3.f * m + 4.5f * m * m);
+}
+
+template <bool NT>
+__device__ __forceinline__ f4a load4(const float *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4a *>(p));
+    return *reinterpret_cast<const f4a *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ f4a load4u(const float *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
+    return *reinterpret_cast<const f4u *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void store4(float *p, f4a v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4a *>(p));
+    else *reinterpret_cast<f4a *>(p) = v;
+}
+
+// The hot kernel: one full time step for 4 consecutive cells of one row per lane.
+//   pull-stream (move+copy_buffer) -> boundary rule (move_bcs) -> obstacle swap
+//   (bounceback_in_obstacle) -> moments (update_hydro) -> equilibrium (update_feq) ->
+//   relaxation (collide_particles), then 9 aligned 16-byte stores.
+// Launch: blockDim = (64, RW): a wave covers 256 cells of one row, RW rows per block.
+template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_step(const StepArgs a)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int ri = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x4 >= a.pitch || ri >= a.row_count) return;
+    const int yl = a.row_begin + ri * a.row_step;
+    const int yg = a.y0 + yl;
+    int ym = yl - 1, yp = yl + 1;          // source rows of the cy=+1 / cy=-1 links
+    if (a.wrap_y) {
+        if (ym < 0) ym = a.h - 1;
+        if (yp >= a.h) yp = 0;
+    }
+    const long long P = a.pitch, S = a.plane;
+    const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
+    const float *s = a.src;
+
+    f4a q[9];
+    q[0] = load4<NTL>(s + o0);
+    q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
+    q[2] = load4<NTL>(s + 2 * S + om);
+    q[3] = load4u<NTL>(s + 3 * S + o0 + 1);
+    q[4] = load4<NTL>(s + 4 * S + op);
+    q[5] = load4u<NTL>(s + 5 * S + om - 1);
+    q[6] = load4u<NTL>(s + 6 * S + om + 1);
+    q[7] = load4u<NTL>(s + 7 * S + op + 1);
+    q[8] = load4u<NTL>(s + 8 * S + op - 1);
+
+    uc4 mk = {0, 0, 0, 0};
+    if (MASK) mk = *reinterpret_cast<const uc4 *>(a.mask + o0);
+
+    if (BC == LB_BC_PERIODIC) {
+        // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
+        // row padding (wave-divergent, one lane per row).
+        if (x4 == 0) {
+            q[1].x = s[1 * S + (long long)yl * P + a.nx - 1];
+            q[5].x = s[5 * S + (long long)ym * P + a.nx - 1];
+            q[8].x = s[8 * S + (long long)yp * P + a.nx - 1];
+        }
+        const int c = a.nx - 1 - x4;
+        if (c >= 0 && c < 4) {
+            const float w3 = s[3 * S + (long long)yl * P], w6 = s[6 * S + (long long)ym * P],
+                        w7 = s[7 * S + (long long)yp * P];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == c) { q[3][j] = w3; q[6][j] = w6; q[7][j] = w7; }
+        }
+    }
+
+    const bool edge = (BC != LB_BC_PERIODIC) &&
+                      (yg == 0 || yg == a.ny - 1 || x4 == 0 || (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4));
+
+    f4a r4, u4, v4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+        if (edge) {
+            if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
+        }
+        if (MASK) bounce_cell(c, mk[j] != 0);
+        float rho, ux, uy;
+        relax_cell(c, a.omega, rho, ux, uy);
+        r4[j] = rho; u4[j] = ux; v4[j] = uy;
+        q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
+        q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+    }
+
+    float *d = a.dst + o0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, q[k]);
+    if (MACRO) {
+        store4<false>(a.rho + o0, r4);
+        store4<false>(a.u + o0, u4);
+        store4<false>(a.v + o0, v4);
+    }
+}
+
+// ---- un-fused kernels: the reference's phases one by one (API / test parity) ----------------
+struct PhaseArgs {
+    float *f, *fs, *feq;   // plane 0, row 0, x 0
+    float *rho, *u, *v;
+    const uint8_t *mask;
+    long long plane;
+    int pitch, nx, ny, bc;
+    float omega, rho_in, rho_out, lid_u, rho0;
+};
+
+__device__ __constant__ int d_cx[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
+__device__ __constant__ int d_cy[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+__device__ __constant__ float d_w[9] = {4.f / 9.f,  1.f / 9.f,  1.f / 9.f,  1.f / 9.f, 1.f / 9.f,
+                                        1.f / 36.f, 1.f / 36.f, 1.f / 36.f, 1.f / 36.f};
+
+// D2Q9.cl:139-171 in pull form: a cell whose upstream neighbour is outside the box keeps the
+// stale content of f_streamed, exactly like the reference's dropped push.
+__global__ void k_move(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= a.nx) return;
+    int sx = x - d_cx[k], sy = y - d_cy[k];
+    if (a.bc == LB_BC_PERIODIC) {
+        sx = (sx + a.nx) % a.nx;
+        sy = (sy + a.ny) % a.ny;
+    }
+    if (sx < 0 || sx >= a.nx || sy < 0 || sy >= a.ny) return;
+    a.fs[k * a.plane + (long long)y * a.pitch + x] = a.f[k * a.plane + (long long)sy * a.pitch + sx];
+}
+
+__global__ void k_bcs(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    float *f = a.f + o;
+    Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
+    if (x == 0 || x == a.nx - 1 || y == 0 || y == a.ny - 1) {
+        if (a.bc == LB_BC_PIPE) bc_pipe_cell(c, x, y, a.nx, a.ny, a.rho_in, a.rho_out);
+        if (a.bc == LB_BC_CAVITY) bc_cavity_cell(c, x, y, a.nx, a.ny, a.lid_u, a.rho0);
+    }
+    bounce_cell(c, a.mask && a.mask[o]);
+    f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
+    f[5 * S] = c.f5; f[6 * S] = c.f6; f[7 * S] = c.f7; f[8 * S] = c.f8;
+}
+
+__global__ void k_hydro(const PhaseArgs a)   // D2Q9.cl:67-100
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = a.f[k * a.plane + o];
+    const float rho = f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + f[8];
+    const float inv = 1.0f / rho;
+    a.rho[o] = rho;
+    a.u[o] = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) * inv;
+    a.v[o] = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
+}
+
+__global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x;
+    const float rho = a.rho[o], ux = a.u[o], uy = a.v[o];
+    const float usq = ux * ux + uy * uy;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float cu = d_cx[k] * ux + d_cy[k] * uy;
+        a.feq[k * a.plane + o] = d_w[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
+    }
+}
+
+__global__ void k_collide(const PhaseArgs a) // D2Q9.cl:102-121
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= a.nx) return;
+    const long long o = k * a.plane + (long long)y * a.pitch + x;
+    a.f[o] = a.f[o] * (1.f - a.omega) + a.omega * a.feq[o];
+}
+
+__global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x;
+    if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
+}
+
+// ------------------------------------------------------------------------------------------
+//  RCCL, loaded lazily so that single-GPU use never touches librccl
+// ------------------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return LB_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(LB_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+#define SYM(field, name)                                                                     \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                              \
+    if (!g_rccl.field) return fail(LB_ERR_COMM, "librccl.so lacks %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.lib = h;
+    return LB_OK;
+}
+
+#define NCCL_TRY(expr)                                                                        \
+    do {                                                                                      \
+        ncclResult_t r_ = (expr);                                                             \
+        if (r_ != ncclSuccess)                                                                \
+            return fail(LB_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));      \
+    } while (0)
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+//  host side
+// ------------------------------------------------------------------------------------------
+struct lb_sim {
+    lb_params p;
+    int H = 0;                  // rows owned
+    long long pitch = 0, plane = 0, lat_floats = 0;
+    float *lat[2] = {nullptr, nullptr};   // raw allocations (with guards)
+    int cur = 0;                // lattice holding f
+    int stepping = 0;           // 1 between lb_step_boundary and lb_step_finish
+    float *feq = nullptr;       // raw allocation, lazily created
+    float *rho = nullptr, *u = nullptr, *v = nullptr;
+    uint8_t *mask = nullptr;
+    bool has_mask = false;
+    bool feq_valid = false;     // feq buffer consistent with rho,u,v
+    hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
+    int variant = 0;
+    int64_t bytes = 0;
+
+    float *origin(int which) const { return lat[which] + GUARD + pitch; }   // plane 0, row 0, x 0
+    float *feq_origin() const { return feq + GUARD + pitch; }
+    bool multi_slab() const { return H != p.ny || (p.flags & LB_FLAG_HALO); }
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
+{
+    StepArgs a;
+    a.src = s->origin(s->cur);
+    a.dst = s->origin(s->cur ^ 1);
+    a.mask = s->has_mask ? s->mask : nullptr;
+    a.rho = s->rho; a.u = s->u; a.v = s->v;
+    a.plane = s->plane; a.pitch = (int)s->pitch;
+    a.nx = s->p.nx; a.ny = s->p.ny; a.y0 = s->p.y0; a.h = s->H;
+    a.row_begin = row_begin; a.row_step = row_step; a.row_count = row_count;
+    a.wrap_y = (s->p.bc_mode == LB_BC_PERIODIC && !s->multi_slab()) ? 1 : 0;
+    a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
+    a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
+    return a;
+}
+
+template <int BC, bool MASK, bool MACRO>
+void launch_step_nt(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block)
+{
+    switch (s->variant & 3) {
+    case 0: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, false, false>), grid, block, 0, s->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, false, true>), grid, block, 0, s->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, true, false>), grid, block, 0, s->stream, a); break;
+    default: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, true, true>), grid, block, 0, s->stream, a); break;
+    }
+}
+
+template <int BC>
+void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, bool macro)
+{
+    if (s->has_mask) {
+        if (macro) launch_step_nt<BC, true, true>(s, a, grid, block);
+        else launch_step_nt<BC, true, false>(s, a, grid, block);
+    } else {
+        if (macro) launch_step_nt<BC, false, true>(s, a, grid, block);
+        else launch_step_nt<BC, false, false>(s, a, grid, block);
+    }
+}
+
+// Launch the fused step over local rows row_begin + i*row_step, i < row_count.
+int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macro)
+{
+    if (row_count <= 0) return LB_OK;
+    const StepArgs a = step_args(s, row_begin, row_step, row_count);
+    const int rows_per_block = ((s->variant >> 2) & 3) == 1 ? 1 : (((s->variant >> 2) & 3) == 2 ? 2 : 4);
+    const int waves_x = 4 / rows_per_block;          // waves side by side in x
+    dim3 block(64 * waves_x, rows_per_block);
+    const int lanes_x = (int)(s->pitch / 4);
+    dim3 grid((lanes_x + block.x - 1) / block.x, (row_count + rows_per_block - 1) / rows_per_block);
+    switch (s->p.bc_mode) {
+    case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro); break;
+    case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro); break;
+    default: launch_step_bc<LB_BC_CAVITY>(s, a, grid, block, macro); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+PhaseArgs phase_args(const lb_sim *s)
+{
+    PhaseArgs a;
+    a.f = s->origin(s->cur);
+    a.fs = s->origin(s->cur ^ 1);
+    a.feq = s->feq ? s->feq_origin() : nullptr;
+    a.rho = s->rho; a.u = s->u; a.v = s->v;
+    a.mask = s->has_mask ? s->mask : nullptr;
+    a.plane = s->plane; a.pitch = (int)s->pitch; a.nx = s->p.nx; a.ny = s->p.ny; a.bc = s->p.bc_mode;
+    a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
+    a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
+    return a;
+}
+
+int ensure_feq(lb_sim *s)
+{
+    if (s->feq) return LB_OK;
+    HIP_TRY(hipMalloc(&s->feq, sizeof(float) * s->lat_floats));
+    HIP_TRY(hipMemsetAsync(s->feq, 0, sizeof(float) * s->lat_floats, s->stream));
+    s->bytes += sizeof(float) * s->lat_floats;
+    return LB_OK;
+}
+
+int need_single_slab(const lb_sim *s, const char *what)
+{
+    if (s->multi_slab())
+        return fail(LB_ERR_STATE, "%s is only available on a handle that owns the whole grid", what);
+    return LB_OK;
+}
+
+// host [rows][nx] <-> device [rows][pitch]
+int copy_plane_h2d(lb_sim *s, float *dev, const float *host)
+{
+    HIP_TRY(hipMemcpy2DAsync(dev, s->pitch * sizeof(float), host, s->p.nx * sizeof(float),
+                             s->p.nx * sizeof(float), s->H, hipMemcpyHostToDevice, s->stream));
+    return LB_OK;
+}
+int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
+{
+    HIP_TRY(hipMemcpy2DAsync(host, s->p.nx * sizeof(float), dev, s->pitch * sizeof(float),
+                             s->p.nx * sizeof(float), s->H, hipMemcpyDeviceToHost, s->stream));
+    return LB_OK;
+}
+
+// Halo rows travel as three contiguous nx-float segments per edge.
+const int K_UP[3] = {2, 5, 6};     // cy = +1: leave through the north edge, enter through the south ghost row
+const int K_DOWN[3] = {4, 7, 8};   // cy = -1
+
+int exchange_rccl(lb_sim *s, int which)
+{
+    // neighbours: south = rank-1, north = rank+1; PERIODIC wraps, walls have none
+    const bool wrap = (s->p.bc_mode == LB_BC_PERIODIC);
+    const int south = (s->rank > 0) ? s->rank - 1 : (wrap ? s->nranks - 1 : -1);
+    const int north = (s->rank < s->nranks - 1) ? s->rank + 1 : (wrap ? 0 : -1);
+    float *o = s->origin(which);
+    const size_t n = (size_t)s->p.nx;
+    // Posting order matters when both neighbours are the same rank (2 ranks, or 1 rank talking
+    // to itself, in a periodic box): sends go north-then-south, receives south-then-north, so the
+    // n-th send to a peer always meets the n-th receive that peer posted for us.
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < 3; ++i) {
+        if (north >= 0)
+            NCCL_TRY(g_rccl.Send(o + K_UP[i] * s->plane + (long long)(s->H - 1) * s->pitch, n, ncclFloat, north,
+                                 s->comm, s->comm_stream));
+        if (south >= 0)
+            NCCL_TRY(g_rccl.Send(o + K_DOWN[i] * s->plane, n, ncclFloat, south, s->comm, s->comm_stream));
+        if (south >= 0)
+            NCCL_TRY(g_rccl.Recv(o + K_UP[i] * s->plane - s->pitch, n, ncclFloat, south, s->comm,
+                                 s->comm_stream));
+        if (north >= 0)
+            NCCL_TRY(g_rccl.Recv(o + K_DOWN[i] * s->plane + (long long)s->H * s->pitch, n, ncclFloat, north,
+                                 s->comm, s->comm_stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return LB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lb_abi_version(void) { return LB_ABI_VERSION; }
+
+const char *lb_last_error(void) { return g_err; }
+
+int lb_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(LB_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int lb_create(const lb_params *p, lb_sim **out)
+{
+    if (!p || !out) return fail(LB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (p->nx < 2 || p->ny < 2) return fail(LB_ERR_ARG, "grid must be at least 2x2 (got %dx%d)", p->nx, p->ny);
+    if (p->local_ny < 1 || p->y0 < 0 || p->y0 + p->local_ny > p->ny)
+        return fail(LB_ERR_ARG, "slab [%d,%d) outside 0..%d", p->y0, p->y0 + p->local_ny, p->ny);
+    if (p->bc_mode < LB_BC_PIPE || p->bc_mode > LB_BC_CAVITY) return fail(LB_ERR_ARG, "unknown bc_mode %d", p->bc_mode);
+    if (!(p->omega > 0.f && p->omega < 2.f)) return fail(LB_ERR_ARG, "omega must be in (0,2), got %g", p->omega);
+    for (int r : p->reserved)
+        if (r != 0) return fail(LB_ERR_ARG, "reserved fields must be zero");
+    if (p->flags & ~LB_FLAG_HALO) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(LB_ERR_HIP, "no HIP device visible");
+    if (p->device < 0 || p->device >= ndev) return fail(LB_ERR_ARG, "device %d not in 0..%d", p->device, ndev - 1);
+
+    DeviceGuard guard(p->device);
+    lb_sim *s = new lb_sim();
+    s->p = *p;
+    s->H = p->local_ny;
+    s->pitch = ((long long)p->nx + 63) / 64 * 64;
+    long long skew = 0;
+    if (const char *e = getenv("LB_PLANE_SKEW")) skew = atoll(e) * 64;
+    s->plane = (long long)(s->H + 2) * s->pitch + skew;
+    s->lat_floats = 9 * s->plane + 2 * GUARD;
+    if (const char *e = getenv("LB_VARIANT")) s->variant = atoi(e);
+
+#define CREATE_TRY(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            fail(LB_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                   \
+            lb_destroy(s);                                                                     \
+            return LB_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
+    CREATE_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreate(&s->ev_t0));
+    CREATE_TRY(hipEventCreate(&s->ev_t1));
+    const size_t lat_bytes = sizeof(float) * s->lat_floats;
+    const size_t fld_bytes = sizeof(float) * s->pitch * s->H;
+    for (int i = 0; i < 2; ++i) {
+        CREATE_TRY(hipMalloc(&s->lat[i], lat_bytes));
+        CREATE_TRY(hipMemsetAsync(s->lat[i], 0, lat_bytes, s->stream));
+    }
+    CREATE_TRY(hipMalloc(&s->rho, fld_bytes));
+    CREATE_TRY(hipMalloc(&s->u, fld_bytes));
+    CREATE_TRY(hipMalloc(&s->v, fld_bytes));
+    CREATE_TRY(hipMalloc(&s->mask, (size_t)s->pitch * s->H));
+    CREATE_TRY(hipMemsetAsync(s->rho, 0, fld_bytes, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->u, 0, fld_bytes, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->v, 0, fld_bytes, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->mask, 0, (size_t)s->pitch * s->H, s->stream));
+    CREATE_TRY(hipStreamSynchronize(s->stream));
+#undef CREATE_TRY
+    s->bytes = 2 * lat_bytes + 3 * fld_bytes + (size_t)s->pitch * s->H;
+    *out = s;
+    return LB_OK;
+}
+
+int lb_destroy(lb_sim *s)
+{
+    if (!s) return LB_OK;
+    DeviceGuard guard(s->p.device);
+    if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+    if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
+    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v})
+        if (p) (void)hipFree(p);
+    if (s->mask) (void)hipFree(s->mask);
+    for (hipEvent_t e : {s->ev_boundary, s->ev_halo, s->ev_t0, s->ev_t1})
+        if (e) (void)hipEventDestroy(e);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+    delete s;
+    return LB_OK;
+}
+
+int lb_sync(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->comm_stream));
+    return LB_OK;
+}
+
+int lb_set_stream(lb_sim *s, void *hip_stream)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+    return LB_OK;
+}
+
+int lb_set_variant(lb_sim *s, int variant)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    s->variant = variant;
+    return LB_OK;
+}
+
+int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (pitch) *pitch = s->pitch;
+    if (plane_stride) *plane_stride = s->plane;
+    if (bytes_allocated) *bytes_allocated = s->bytes;
+    return LB_OK;
+}
+
+// ---- state transfer ----------------------------------------------------------------------
+int lb_set_macro(lb_sim *s, const float *rho, const float *u, const float *v)
+{
+    if (!s || !rho || !u || !v) return fail(LB_ERR_ARG, "null argument");
+    DeviceGuard guard(s->p.device);
+    int rc;
+    if ((rc = copy_plane_h2d(s, s->rho, rho))) return rc;
+    if ((rc = copy_plane_h2d(s, s->u, u))) return rc;
+    if ((rc = copy_plane_h2d(s, s->v, v))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LB_OK;
+}
+
+int lb_get_macro(lb_sim *s, float *rho, float *u, float *v)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    int rc;
+    if (rho && (rc = copy_plane_d2h(s, rho, s->rho))) return rc;
+    if (u && (rc = copy_plane_d2h(s, u, s->u))) return rc;
+    if (v && (rc = copy_plane_d2h(s, v, s->v))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LB_OK;
+}
+
+int lb_set_f(lb_sim *s, const float *f)
+{
+    if (!s || !f) return fail(LB_ERR_ARG, "null argument");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_set_f between lb_step_boundary and lb_step_finish");
+    DeviceGuard guard(s->p.device);
+    const size_t host_plane = (size_t)s->p.nx * s->H;
+    for (int k = 0; k < 9; ++k) {
+        int rc = copy_plane_h2d(s, s->origin(s->cur) + k * s->plane, f + k * host_plane);
+        if (rc) return rc;
+    }
+    // f_streamed = f (opencl_dim.py:323-327)
+    HIP_TRY(hipMemcpyAsync(s->lat[s->cur ^ 1], s->lat[s->cur], sizeof(float) * s->lat_floats,
+                           hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->ghosts_valid = false;
+    return LB_OK;
+}
+
+int lb_get_f(lb_sim *s, float *f)
+{
+    if (!s || !f) return fail(LB_ERR_ARG, "null argument");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipStreamSynchronize(s->comm_stream));
+    const size_t host_plane = (size_t)s->p.nx * s->H;
+    for (int k = 0; k < 9; ++k) {
+        int rc = copy_plane_d2h(s, f + k * host_plane, s->origin(s->cur) + k * s->plane);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LB_OK;
+}
+
+int lb_update_feq(lb_sim *s);
+
+int lb_get_feq(lb_sim *s, float *feq)
+{
+    if (!s || !feq) return fail(LB_ERR_ARG, "null argument");
+    DeviceGuard guard(s->p.device);
+    int rc;
+    if (!s->feq_valid && (rc = lb_update_feq(s))) return rc;
+    const size_t host_plane = (size_t)s->p.nx * s->H;
+    for (int k = 0; k < 9; ++k)
+        if ((rc = copy_plane_d2h(s, feq + k * host_plane, s->feq_origin() + k * s->plane))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LB_OK;
+}
+
+int lb_set_mask(lb_sim *s, const int32_t *mask)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    if (!mask) {
+        s->has_mask = false;
+        return LB_OK;
+    }
+    const size_t n = (size_t)s->pitch * s->H;
+    uint8_t *tmp = (uint8_t *)calloc(n, 1);
+    if (!tmp) return fail(LB_ERR_ARG, "out of host memory");
+    bool any = false;
+    for (int y = 0; y < s->H; ++y)
+        for (int x = 0; x < s->p.nx; ++x) {
+            const uint8_t m = mask[(size_t)y * s->p.nx + x] == 1;   // D2Q9.cl:410 tests == 1
+            tmp[(size_t)y * s->pitch + x] = m;
+            any |= m;
+        }
+    hipError_t e = hipMemcpy(s->mask, tmp, n, hipMemcpyHostToDevice);
+    free(tmp);
+    if (e != hipSuccess) return fail(LB_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    // An all-zero mask on one slab must still take the MASK kernel if the caller asked for a
+    // mask: keep the flag (kernel choice is per handle, results are identical either way).
+    (void)any;
+    s->has_mask = true;
+    return LB_OK;
+}
+
+// ---- un-fused phases ---------------------------------------------------------------------
+static dim3 cells_grid(const lb_sim *s, int nz) { return dim3((s->p.nx + 255) / 256, s->p.ny, nz); }
+
+int lb_move(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    int rc = need_single_slab(s, "lb_move");
+    if (rc) return rc;
+    DeviceGuard guard(s->p.device);
+    hipLaunchKernelGGL(k_move, cells_grid(s, 9), dim3(256), 0, s->stream, phase_args(s));
+    HIP_TRY(hipGetLastError());
+    // copy_buffer: f = f_streamed (kept as a copy, not a pointer swap, so that the stale
+    // never-written entries of f_streamed behave exactly like the reference's)
+    HIP_TRY(hipMemcpyAsync(s->lat[s->cur], s->lat[s->cur ^ 1], sizeof(float) * s->lat_floats,
+                           hipMemcpyDeviceToDevice, s->stream));
+    return LB_OK;
+}
+
+int lb_move_bcs(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    int rc = need_single_slab(s, "lb_move_bcs");
+    if (rc) return rc;
+    DeviceGuard guard(s->p.device);
+    hipLaunchKernelGGL(k_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+int lb_update_hydro(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    int rc = need_single_slab(s, "lb_update_hydro");
+    if (rc) return rc;
+    DeviceGuard guard(s->p.device);
+    hipLaunchKernelGGL(k_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    HIP_TRY(hipGetLastError());
+    return LB_OK;   // feq keeps its previous content, as the reference's feq buffer does
+}
+
+int lb_update_feq(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    int rc = ensure_feq(s);
+    if (rc) return rc;
+    PhaseArgs a = phase_args(s);
+    a.ny = s->H;   // rho,u,v are local: valid for slabs too
+    hipLaunchKernelGGL(k_feq, dim3((s->p.nx + 255) / 256, s->H, 1), dim3(256), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    s->feq_valid = true;
+    return LB_OK;
+}
+
+int lb_collide_particles(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    int rc = need_single_slab(s, "lb_collide_particles");
+    if (rc) return rc;
+    if (!s->feq) return fail(LB_ERR_STATE, "lb_collide_particles before any lb_update_feq");
+    DeviceGuard guard(s->p.device);
+    hipLaunchKernelGGL(k_collide, cells_grid(s, 9), dim3(256), 0, s->stream, phase_args(s));
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+int lb_zero_velocity_in_obstacle(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (!s->has_mask) return LB_OK;
+    DeviceGuard guard(s->p.device);
+    PhaseArgs a = phase_args(s);
+    hipLaunchKernelGGL(k_zero_vel, dim3((s->p.nx + 255) / 256, s->H, 1), dim3(256), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+int lb_init_pop(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    int rc;
+    if (!s->feq_valid && (rc = lb_update_feq(s))) return rc;
+    for (int i = 0; i < 2; ++i)
+        HIP_TRY(hipMemcpyAsync(s->lat[i], s->feq, sizeof(float) * s->lat_floats, hipMemcpyDeviceToDevice,
+                               s->stream));
+    s->ghosts_valid = false;
+    return LB_OK;
+}
+
+// ---- fused stepping ----------------------------------------------------------------------
+int lb_step_boundary(lb_sim *s, int write_macro)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_step_boundary called twice");
+    DeviceGuard guard(s->p.device);
+    // local rows 0 and H-1 (one row when H == 1)
+    int rc = launch_step(s, 0, s->H > 1 ? s->H - 1 : 1, s->H > 1 ? 2 : 1, write_macro != 0);
+    if (rc) return rc;
+    s->stepping = 1;
+    return LB_OK;
+}
+
+int lb_step_interior(lb_sim *s, int write_macro)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (!s->stepping) return fail(LB_ERR_STATE, "lb_step_interior before lb_step_boundary");
+    DeviceGuard guard(s->p.device);
+    return launch_step(s, 1, 1, s->H - 2, write_macro != 0);
+}
+
+int lb_step_finish(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (!s->stepping) return fail(LB_ERR_STATE, "lb_step_finish before lb_step_boundary");
+    s->cur ^= 1;
+    s->stepping = 0;
+    s->feq_valid = false;
+    s->ghosts_valid = false;   // the caller imports the new ghosts (lb_run manages its own)
+    return LB_OK;
+}
+
+int lb_halo_export(lb_sim *s, int side, void *buf)
+{
+    if (!s || !buf || side < 0 || side > 1) return fail(LB_ERR_ARG, "bad argument");
+    DeviceGuard guard(s->p.device);
+    const int which = s->stepping ? (s->cur ^ 1) : s->cur;
+    const int *ks = side ? K_UP : K_DOWN;
+    const long long row = side ? (long long)(s->H - 1) * s->pitch : 0;
+    for (int i = 0; i < 3; ++i)
+        HIP_TRY(hipMemcpyAsync((float *)buf + (size_t)i * s->p.nx, s->origin(which) + ks[i] * s->plane + row,
+                               sizeof(float) * s->p.nx, hipMemcpyDefault, s->stream));
+    return LB_OK;
+}
+
+int lb_halo_import(lb_sim *s, int side, const void *buf)
+{
+    if (!s || !buf || side < 0 || side > 1) return fail(LB_ERR_ARG, "bad argument");
+    DeviceGuard guard(s->p.device);
+    const int which = s->stepping ? (s->cur ^ 1) : s->cur;
+    const int *ks = side ? K_DOWN : K_UP;
+    const long long row = side ? (long long)s->H * s->pitch : -s->pitch;
+    for (int i = 0; i < 3; ++i)
+        HIP_TRY(hipMemcpyAsync(s->origin(which) + ks[i] * s->plane + row, (const float *)buf + (size_t)i * s->p.nx,
+                               sizeof(float) * s->p.nx, hipMemcpyDefault, s->stream));
+    return LB_OK;
+}
+
+int lb_run(lb_sim *s, int n_steps)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (n_steps < 0) return fail(LB_ERR_ARG, "negative step count");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_run between lb_step_boundary and lb_step_finish");
+    DeviceGuard guard(s->p.device);
+    int rc;
+    if (!s->multi_slab()) {
+        for (int it = 0; it < n_steps; ++it) {
+            if ((rc = launch_step(s, 0, 1, s->H, it == n_steps - 1))) return rc;
+            s->cur ^= 1;
+        }
+        if (n_steps) s->feq_valid = false;
+        return LB_OK;
+    }
+    if (!s->comm)
+        return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
+    if (n_steps == 0) return LB_OK;
+    if (!s->ghosts_valid) {
+        // ghost rows of the current lattice: exchange once before the first step
+        HIP_TRY(hipEventRecord(s->ev_boundary, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
+        if ((rc = exchange_rccl(s, s->cur))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+    }
+    for (int it = 0; it < n_steps; ++it) {
+        const bool macro = (it == n_steps - 1);
+        // 1. edge rows first, so their halo can travel while the interior is computed
+        if ((rc = launch_step(s, 0, s->H > 1 ? s->H - 1 : 1, s->H > 1 ? 2 : 1, macro))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_boundary, s->stream));
+        // 2. interior rows on the compute stream
+        if ((rc = launch_step(s, 1, 1, s->H - 2, macro))) return rc;
+        // 3. halo of the lattice just written, on the communication stream (RCCL over xGMI)
+        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
+        if ((rc = exchange_rccl(s, s->cur ^ 1))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
+        // 4. the next step reads the new lattice: wait for its ghost rows
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+        s->cur ^= 1;
+    }
+    s->ghosts_valid = true;
+    s->feq_valid = false;
+    return LB_OK;
+}
+
+// ---- RCCL --------------------------------------------------------------------------------
+int lb_comm_unique_id(void *unique_id_128)
+{
+    if (!unique_id_128) return fail(LB_ERR_ARG, "null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(unique_id_128, &id, sizeof(id));
+    return LB_OK;
+}
+
+int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
+{
+    if (!s || !unique_id_128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(LB_ERR_ARG, "bad argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    DeviceGuard guard(s->p.device);
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128, sizeof(id));
+    NCCL_TRY(g_rccl.CommInitRank(&s->comm, nranks, id, rank));
+    s->rank = rank;
+    s->nranks = nranks;
+    s->ghosts_valid = false;
+    return LB_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------
+int lb_timer_start(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipEventRecord(s->ev_t0, s->stream));
+    return LB_OK;
+}
+
+int lb_timer_stop(lb_sim *s, float *elapsed_ms)
+{
+    if (!s || !elapsed_ms) return fail(LB_ERR_ARG, "null argument");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipEventRecord(s->ev_t1, s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev_t1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, s->ev_t0, s->ev_t1));
+    return LB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MLUPS + achieved HBM GB/s of the fused D2Q9 step on an 8192x8192 fp32
+periodic shear layer (BASELINE.json: metric / configs[3]), 1..8 MI355X, row slabs + RCCL halo.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (stream + BC + moments + feq + BGK collide, one fused HIP
+launch per slab) over the whole grid.  The grid is fixed as N grows (strong scaling, as the
+north-star states its 8-GPU target).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     - the fused kernel against the HBM roofline: achieved = 72 B x cells per launch /
+                 average launch duration (HIP events on the engine's stream over the timed region).
+  cpu_baseline - oracle port of the reference's Cython CPU path (oracle/d2q9_oracle.c o1_run),
+                 1 core, on a bounded sample; reported, not a target.  Rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
+
+B_ALG = 72.0            # algorithmic bytes per lattice update: 9 fp32 read + 9 fp32 written
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def shear_layer(nx, ny, y0, h, U=0.04, seed=0):
+    """Double periodic shear layer (BASELINE config 4): rho=1, u = U tanh((y - ny/4)/d) below the
+    mid-line and U tanh((3ny/4 - y)/d) above, d = ny/80, v = 1e-3 U sin(2 pi 4 x / nx).
+    Returns the rows [y0, y0+h) as F-ordered (nx, h) float32 arrays."""
+    y = np.arange(y0, y0 + h, dtype=np.float64)
+    d = ny / 80.0
+    prof = np.where(y < ny / 2.0, np.tanh((y - ny / 4.0) / d), np.tanh((3.0 * ny / 4.0 - y) / d))
+    x = np.arange(nx, dtype=np.float64)
+    u = np.asfortranarray(np.broadcast_to((U * prof)[None, :], (nx, h)).astype(np.float32))
+    v = np.asfortranarray(np.broadcast_to((1e-3 * U * np.sin(2 * np.pi * 4 * x / nx))[:, None],
+                                          (nx, h)).astype(np.float32))
+    rho = np.ones((nx, h), np.float32, order="F")
+    return rho, u, v
+
+
+def cpu_baseline(budget_s=12.0, n=4096):
+    """Time the oracle's restatement of the reference Cython path (cython_dim.pyx:346-359, five
+    un-fused passes, single thread) on an n x n pipe flow for about budget_s seconds."""
+    from oracle import oracle as O
+    kw = dict(diameter=1., rho=1., viscosity=0.05, pressure_grad=-1., pipe_length=1., N=n - 1,
+              time_prefactor=(n - 1) / 10.)
+    t_build = time.perf_counter()
+    sim = O.O1Sim.pipe_flow(numpy2=False, **kw)
+    sim.run(1)                                   # touch every page once
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        sim.run(1)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 1000:
+            break
+    mlups = sim.nx * sim.ny * steps / el / 1e6
+    return {"value": round(mlups, 3), "unit": "MLUPS", "cores": 1, "kind": "port",
+            "sample": "oracle o1_run (C port of cython_dim.pyx Pipe_Flow.run), %dx%d grid, %d steps, %.1f s, "
+                      "1 thread of %d available" % (sim.nx, sim.ny, steps, el, len(os.sched_getaffinity(0)))}
+
+
+def load_pmc_traffic(n_side):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this workload
+    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); None when absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        ent = d.get(str(n_side))
+        return ent.get("hbm_bytes_per_launch") if ent else None
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=8192, help="grid side (BASELINE metric: 8192)")
+    ap.add_argument("--omega", type=float, default=1.7)
+    ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "torch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.slabs import DistributedSlab, partition_rows
+
+    n = args.size
+    if world == 1:
+        sim = Simulation(n, n, args.omega, bc="periodic", device=local_rank)
+        eng, y0, h = sim, 0, n
+    else:
+        slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=args.transport, device=local_rank)
+        sim, eng, y0, h = slab, slab.engine, slab.y0, slab.h
+    if args.variant is not None:
+        eng.set_variant(args.variant)
+    rho, u, v = shear_layer(n, n, y0, h)
+    eng.init_equilibrium(rho, u, v)            # feq and f = feq are built on the device
+    del rho, u, v
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    sim.run(args.warmup, wait=False) if world > 1 else sim.run(args.warmup, wait=False)
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms = sim.timed_run(args.steps)          # enqueue K steps between two HIP events, wait for them
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+
+    # sanity: the run must have produced finite numbers (guards against timing a broken kernel)
+    chk = eng.get_fields(("rho",))["rho"]
+    if not np.all(np.isfinite(chk)) or abs(float(chk.mean()) - 1.0) > 1e-3:
+        raise SystemExit("bench: non-physical density after the run (mean %r)" % float(chk.mean()))
+
+    if rank == 0:
+        cells = float(n) * n
+        mlups = cells * args.steps / wall / 1e6
+        # dominant kernel = the fused step over this rank's rows; rank 0's slab is representative
+        launch_s = ev_ms / 1e3 / args.steps
+        bytes_per_launch = B_ALG * n * h
+        achieved = bytes_per_launch / launch_s / 1e9
+        line = {
+            "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
+            "value": round(mlups, 1), "unit": "MLUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "achieved_hbm_GBps": round(mlups * 1e6 * B_ALG / 1e9, 1),
+            "config": {"workload": "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
+                                   "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
+                                                                    "" if world == 1 else ", halo via " + args.transport),
+                       "grid": [n, n], "bytes_per_lattice_update": B_ALG},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(n) if world == 1 else None,
+                         "kernel": "k_step<PERIODIC> (fused pull-stream+collide), %d x %d cells per launch" % (n, h),
+                         "launch_ms": round(launch_s * 1e3, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

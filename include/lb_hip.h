@@ -1,0 +1,153 @@
+/*
+ * lb_hip.h -- C ABI of liblbhip.so, the MI355X (gfx950) D2Q9 lattice-Boltzmann engine.
+ *
+ * This is the drop-in boundary for the collide-and-stream path of
+ * latticeboltzmann/2d-lb.  In the reference that path sits behind pyopencl:
+ * `cl.Program(...).build()` gives `self.kernels`, every step method is
+ * `self.kernels.<name>(queue, global, local, *buffers, scalars).wait()` and all
+ * state lives in `cl.Buffer`s (LB_D2Q9/dimensionless/opencl_dim.py:203-255,
+ * 295-370, 390-415, 495-518).  Each entry point below names the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *  - every function returns 0 on success or a negative lb_status; the message
+ *    of the last failure on the calling thread is lb_last_error().
+ *  - host arrays are borrowed for the duration of the call.  Field layout on
+ *    the host is the reference's device layout: plane-major, x fastest,
+ *    idx(k,x,y) = k*nx*H + y*nx + x (== the F-ordered (nx,ny[,9]) numpy arrays
+ *    of opencl_dim.py:165,279,390-415), H = rows of the slab this handle owns.
+ *  - work is enqueued asynchronously on the handle's HIP stream; lb_sync() and
+ *    every lb_get_* wait for it (the reference waits after every kernel).
+ *  - one host thread per handle.
+ */
+#ifndef LB_HIP_H
+#define LB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LB_ABI_VERSION 1
+
+typedef enum {
+    LB_OK = 0,
+    LB_ERR_ARG = -1,      /* bad argument / unsupported combination           */
+    LB_ERR_HIP = -2,      /* a HIP runtime call failed (no device, OOM, ...)  */
+    LB_ERR_STATE = -3,    /* call not valid in the handle's current state     */
+    LB_ERR_COMM = -4      /* RCCL failure                                     */
+} lb_status;
+
+/* Boundary-condition families.  PIPE is the reference's `move_bcs`
+ * (D2Q9.cl:173-261); PERIODIC and CAVITY are build-defined (BASELINE configs
+ * 2-4) and specified by oracle/d2q9_oracle.c. */
+typedef enum {
+    LB_BC_PIPE = 0,       /* pressure inlet x=0 / outlet x=nx-1, no-slip y=0,ny-1 */
+    LB_BC_PERIODIC = 1,   /* periodic in x and y                               */
+    LB_BC_CAVITY = 2      /* four no-slip walls, north wall moving with lid_u  */
+} lb_bc_mode;
+
+typedef struct {
+    int32_t nx, ny;           /* global grid (reference: self.nx, self.ny, opencl_dim.py:191-201) */
+    int32_t y0, local_ny;     /* row slab [y0, y0+local_ny) owned by this handle; 0, ny for one GPU */
+    int32_t bc_mode;          /* lb_bc_mode */
+    int32_t device;           /* HIP device ordinal */
+    float omega;              /* np.float32(self.omega), opencl_dim.py:369 */
+    float inlet_rho;          /* np.float32(self.inlet_rho), :336 */
+    float outlet_rho;
+    float lid_u;              /* CAVITY only */
+    float rho0;               /* CAVITY corner closure density */
+    int32_t flags;            /* LB_FLAG_* */
+    int32_t reserved[4];      /* must be zero */
+} lb_params;
+
+/* Treat the handle as a row slab with ghost rows even when it owns the whole grid: its halo
+ * is then filled by lb_halo_import / the RCCL exchange (a 1-rank periodic ring sends to
+ * itself).  Lets the multi-GPU code path run, and be tested, on a single GPU. */
+#define LB_FLAG_HALO 1
+
+typedef struct lb_sim lb_sim; /* opaque: device buffers, streams, events, RCCL communicator */
+
+/* ---- lifetime (replaces init_opencl + allocate_constants + the cl.Buffer
+ *      allocations of __init__, opencl_dim.py:165-176, 203-255) ------------- */
+int lb_abi_version(void);
+int lb_device_count(void);                     /* <0 on error */
+const char *lb_last_error(void);
+int lb_create(const lb_params *p, lb_sim **out);
+int lb_destroy(lb_sim *s);
+int lb_sync(lb_sim *s);
+/* Run everything on an externally owned hipStream_t (e.g. torch's current
+ * stream) instead of the handle's own; pass NULL to go back. */
+int lb_set_stream(lb_sim *s, void *hip_stream);
+
+/* ---- host <-> device state (replaces cl.Buffer(COPY_HOST_PTR, hostbuf=...)
+ *      and cl.enqueue_copy, opencl_dim.py:291-293, 323-327, 395-407, 502) ---- */
+int lb_set_macro(lb_sim *s, const float *rho, const float *u, const float *v);  /* each [H][nx]   */
+int lb_get_macro(lb_sim *s, float *rho, float *u, float *v);
+int lb_set_f(lb_sim *s, const float *f);       /* [9][H][nx]; also fills f_streamed (:323-327) */
+int lb_get_f(lb_sim *s, float *f);
+int lb_get_feq(lb_sim *s, float *feq);         /* [9][H][nx] */
+int lb_set_mask(lb_sim *s, const int32_t *mask); /* [H][nx], 1 = solid (opencl_dim.py:468, 502); NULL clears */
+
+/* ---- the reference's per-phase methods, one kernel each (slow, un-fused;
+ *      API and test parity).  Single-slab handles only. ------------------- */
+int lb_move(lb_sim *s);                 /* kernels.move + kernels.copy_buffer, opencl_dim.py:339-353 */
+int lb_move_bcs(lb_sim *s);             /* kernels.move_bcs (+ bounceback_in_obstacle), :329-337, 510-518 */
+int lb_update_hydro(lb_sim *s);         /* kernels.update_hydro, :355-362 */
+int lb_update_feq(lb_sim *s);           /* kernels.update_feq, :295-306 */
+int lb_collide_particles(lb_sim *s);    /* kernels.collide_particles, :364-370 */
+int lb_zero_velocity_in_obstacle(lb_sim *s); /* kernels.set_zero_velocity_in_obstacle, :506-508 */
+int lb_init_pop(lb_sim *s);             /* f = f_streamed = feq (device side of init_pop, :308-327) */
+
+/* ---- the hot path: n fused time steps (replaces the body of
+ *      Pipe_Flow.run, opencl_dim.py:372-387: move -> move_bcs(+obstacle) ->
+ *      update_hydro -> update_feq -> collide_particles, 6-8 launches and as
+ *      many host waits per step, by ONE launch per step and no host wait).
+ *      rho,u,v of the LAST step are stored (they are only observable through
+ *      get_fields); feq is rebuilt from them on demand.
+ *      Multi-slab handles exchange their halo rows inside lb_run when a
+ *      communicator is attached (lb_comm_init), otherwise the caller drives
+ *      lb_step_boundary / lb_halo_export / lb_halo_import / lb_step_interior. */
+int lb_run(lb_sim *s, int n_steps);
+
+/* ---- row-slab decomposition (new: the reference is single-device) -------- */
+/* One fused step split in two launches so the halo exchange can overlap the
+ * interior: boundary = local rows {0, H-1}, interior = rows 1..H-2.
+ * lb_step_finish swaps the lattices.  write_macro != 0 also stores rho,u,v. */
+int lb_step_boundary(lb_sim *s, int write_macro);
+int lb_step_interior(lb_sim *s, int write_macro);
+int lb_step_finish(lb_sim *s);
+/* Halo rows of the lattice that the NEXT step will read (= the one being
+ * written between lb_step_boundary and lb_step_finish, the current one
+ * otherwise).  side 0 = south edge, 1 = north edge.  export: the three
+ * populations leaving through that edge (south: k=4,7,8 of row 0; north:
+ * k=2,5,6 of row H-1) -> buf[3][nx].  import: the three populations entering
+ * through that edge (south ghost row -1: k=2,5,6; north ghost row H: k=4,7,8)
+ * <- buf[3][nx].  buf may be host or device memory (hipMemcpyDefault). */
+int lb_halo_export(lb_sim *s, int side, void *buf);
+int lb_halo_import(lb_sim *s, int side, const void *buf);
+
+/* RCCL point-to-point halo exchange over xGMI, one rank per GPU.  Rank r owns
+ * slab r; neighbours are r-1 (south) and r+1 (north), wrapping for PERIODIC.
+ * unique_id is the 128-byte ncclUniqueId: rank 0 obtains it with
+ * lb_comm_unique_id and the caller broadcasts it (torch.distributed). */
+int lb_comm_unique_id(void *unique_id_128);
+int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
+
+/* ---- measurement --------------------------------------------------------- */
+/* hipEvent pair on the handle's stream: start, [enqueue work], stop -> ms. */
+int lb_timer_start(lb_sim *s);
+int lb_timer_stop(lb_sim *s, float *elapsed_ms);
+/* Device layout facts for DESIGN.md / bench.py: pitch (floats), plane stride
+ * (floats), bytes allocated. */
+int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated);
+/* Kernel variant selector for tuning experiments (0 = default). */
+int lb_set_variant(lb_sim *s, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LB_HIP_H */
