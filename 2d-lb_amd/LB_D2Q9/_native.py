@@ -21,7 +21,7 @@ EXPORTS = (
     "lb_move", "lb_move_bcs", "lb_update_hydro", "lb_update_feq", "lb_collide_particles",
     "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_run",
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
-    "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant",
+    "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration",
 )
 
 
@@ -72,6 +72,7 @@ def lib():
     L.lb_timer_stop.argtypes = [h, fp]
     L.lb_layout.argtypes = [h, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64)]
     L.lb_set_variant.argtypes = [h, I]
+    L.lb_copy_calibration.argtypes = [h, I, ct.POINTER(ct.c_int64)]
     if L.lb_abi_version() != ABI_VERSION:
         raise LbError("liblbhip.so ABI %d != binding ABI %d: rebuild" % (L.lb_abi_version(), ABI_VERSION))
     _lib = L

@@ -218,6 +218,17 @@ class Simulation(object):
         check(self._lib.lb_comm_init(self._h, unique_id, int(rank), int(nranks)))
 
     # -- tuning / introspection ------------------------------------------------
+    def copy_calibration(self, iters=10, nontemporal=False):
+        """Time `iters` plain float4 copies of one lattice into the other (known bytes).
+        Returns (GB/s, bytes per launch).  Only between steps: it overwrites the scratch lattice."""
+        nbytes, ms = ct.c_int64(), ct.c_float()
+        check(self._lib.lb_copy_calibration(self._h, int(nontemporal), ct.byref(nbytes)))
+        check(self._lib.lb_timer_start(self._h))
+        for _ in range(iters):
+            check(self._lib.lb_copy_calibration(self._h, int(nontemporal), ct.byref(nbytes)))
+        check(self._lib.lb_timer_stop(self._h, ct.byref(ms)))
+        return nbytes.value * iters / (ms.value * 1e-3) / 1e9, nbytes.value
+
     def set_variant(self, variant):
         check(self._lib.lb_set_variant(self._h, int(variant)))
 

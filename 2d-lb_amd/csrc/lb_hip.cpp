@@ -183,6 +183,10 @@ __device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
 }
 
 // Moments (D2Q9.cl:92-97), equilibrium (:55-60) and BGK relaxation (:119) of one cell.
+// The products keep the reference's structure -- feq_k = (w_k rho) * inner_k with the float32
+// weights, then f (1-omega) + omega feq -- because the rounding of the weights is a *systematic*
+// mass bias (sum_k fl(w_k) = 1 + 7.5e-9); folding omega into the weights would change that bias
+// and make rho drift away from the reference's by ~3e-8 per step in a periodic box.
 __device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
 {
     rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
@@ -192,18 +196,18 @@ __device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, flo
     const float usq = ux * ux + uy * uy;
     const float base = 1.f - 1.5f * usq;
     const float keep = 1.f - omega;
-    const float r0 = omega * (4.f / 9.f) * rho, r1 = omega * (1.f / 9.f) * rho, r2 = omega * (1.f / 36.f) * rho;
-    // feq_k = w_k rho (1 + 3 cu + 4.5 cu^2 - 1.5 usq)
-    c.f0 = c.f0 * keep + r0 * base;
-    c.f1 = c.f1 * keep + r1 * (base + 3.f * ux + 4.5f * ux * ux);
-    c.f3 = c.f3 * keep + r1 * (base - 3.f * ux + 4.5f * ux * ux);
-    c.f2 = c.f2 * keep + r1 * (base + 3.f * uy + 4.5f * uy * uy);
-    c.f4 = c.f4 * keep + r1 * (base - 3.f * uy + 4.5f * uy * uy);
+    const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+    // inner_k = 1 + 3 cu + 4.5 cu^2 - 1.5 usq
+    c.f0 = c.f0 * keep + omega * (r0 * base);
+    c.f1 = c.f1 * keep + omega * (r1 * (base + 3.f * ux + 4.5f * ux * ux));
+    c.f3 = c.f3 * keep + omega * (r1 * (base - 3.f * ux + 4.5f * ux * ux));
+    c.f2 = c.f2 * keep + omega * (r1 * (base + 3.f * uy + 4.5f * uy * uy));
+    c.f4 = c.f4 * keep + omega * (r1 * (base - 3.f * uy + 4.5f * uy * uy));
     const float p = ux + uy, m = ux - uy;
-    c.f5 = c.f5 * keep + r2 * (base + 3.f * p + 4.5f * p * p);
-    c.f7 = c.f7 * keep + r2 * (base - 3.f * p + 4.5f * p * p);
-    c.f8 = c.f8 * keep + r2 * (base + 3.f * m + 4.5f * m * m);
-    c.f6 = c.f6 * keep + r2 * (base - 3.f * m + 4.5f * m * m);
+    c.f5 = c.f5 * keep + omega * (r2 * (base + 3.f * p + 4.5f * p * p));
+    c.f7 = c.f7 * keep + omega * (r2 * (base - 3.f * p + 4.5f * p * p));
+    c.f8 = c.f8 * keep + omega * (r2 * (base + 3.f * m + 4.5f * m * m));
+    c.f6 = c.f6 * keep + omega * (r2 * (base - 3.f * m + 4.5f * m * m));
 }
 
 template <bool NT>
@@ -230,11 +234,28 @@ __device__ __forceinline__ void store4(float *p, f4a v)
 //   (bounceback_in_obstacle) -> moments (update_hydro) -> equilibrium (update_feq) ->
 //   relaxation (collide_particles), then 9 aligned 16-byte stores.
 // Launch: blockDim = (64, RW): a wave covers 256 cells of one row, RW rows per block.
-template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS>
+//
+// XCD-aware tile order (XCD = true): workgroups are dealt round-robin over the 8 XCDs, each with its
+// own L2.  A misaligned 1 KiB wave read touches 9 cache lines, the 9th shared with the wave to its
+// right; if that neighbour runs on another XCD the line is fetched from HBM twice (measured: +8.3 %
+// FETCH_SIZE = 6/9 planes x 1/8).  Remapping the linear workgroup id so that every XCD sweeps its own
+// contiguous band of rows keeps x-neighbours on one L2.  Only speed depends on it, never results.
+template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS, bool XCD>
 __global__ __launch_bounds__(256) void k_step(const StepArgs a)
 {
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int ri = blockIdx.y * blockDim.y + threadIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (XCD) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned per = total >> 3;                 // tiles per XCD (tail handled below)
+        if (lin < (per << 3)) {
+            const unsigned t = (lin & 7u) * per + (lin >> 3);
+            bx = t % gridDim.x;
+            by = t / gridDim.x;
+        }
+    }
+    const int x4 = (bx * blockDim.x + threadIdx.x) * 4;
+    const int ri = by * blockDim.y + threadIdx.y;
     if (x4 >= a.pitch || ri >= a.row_count) return;
     const int yl = a.row_begin + ri * a.row_step;
     const int yg = a.y0 + yl;
@@ -305,6 +326,32 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
         store4<false>(a.rho + o0, r4);
         store4<false>(a.u + o0, u4);
         store4<false>(a.v + o0, v4);
+    }
+}
+
+// Calibration kernel: plain 16-byte-per-lane copy of n4 float4s.  Known byte count in the same
+// access shape as the fused step, used to (a) correct rocprofv3's FETCH_SIZE on gfx950 and
+// (b) measure the streaming ceiling of the device the bench runs on.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy4(const f4a *__restrict__ src, f4a *__restrict__ dst, long long n4)
+{
+    // 8 independent 16-byte loads in flight per lane (the fused step has 9)
+    const long long tile = 8LL * blockDim.x;
+    for (long long base = (long long)blockIdx.x * tile; base < n4; base += (long long)gridDim.x * tile) {
+        f4a v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            if (i < n4) v[j] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            if (i < n4) {
+                if (NT) __builtin_nontemporal_store(v[j], dst + i);
+                else dst[i] = v[j];
+            }
+        }
     }
 }
 
@@ -467,7 +514,7 @@ struct lb_sim {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
-    int variant = 0;
+    int variant = -1;           // < 0: automatic (effective_variant)
     int64_t bytes = 0;
 
     float *origin(int which) const { return lat[which] + GUARD + pitch; }   // plane 0, row 0, x 0
@@ -500,26 +547,45 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
 }
 
 template <int BC, bool MASK, bool MACRO>
-void launch_step_nt(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block)
+void launch_step_nt(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, int variant)
 {
-    switch (s->variant & 3) {
-    case 0: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, false, false>), grid, block, 0, s->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, false, true>), grid, block, 0, s->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, true, false>), grid, block, 0, s->stream, a); break;
-    default: hipLaunchKernelGGL((k_step<BC, MASK, MACRO, true, true>), grid, block, 0, s->stream, a); break;
+#define LB_LAUNCH(NTL, NTS, XCD) \
+    hipLaunchKernelGGL((k_step<BC, MASK, MACRO, NTL, NTS, XCD>), grid, block, 0, s->stream, a)
+    switch (variant & 19) {           // bit 0: NT stores, bit 1: NT loads, bit 4: XCD-aware tile order
+    case 0: LB_LAUNCH(false, false, false); break;
+    case 1: LB_LAUNCH(false, true, false); break;
+    case 2: LB_LAUNCH(true, false, false); break;
+    case 3: LB_LAUNCH(true, true, false); break;
+    case 16: LB_LAUNCH(false, false, true); break;
+    case 17: LB_LAUNCH(false, true, true); break;
+    case 18: LB_LAUNCH(true, false, true); break;
+    default: LB_LAUNCH(true, true, true); break;
     }
+#undef LB_LAUNCH
 }
 
 template <int BC>
-void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, bool macro)
+void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, bool macro, int variant)
 {
     if (s->has_mask) {
-        if (macro) launch_step_nt<BC, true, true>(s, a, grid, block);
-        else launch_step_nt<BC, true, false>(s, a, grid, block);
+        if (macro) launch_step_nt<BC, true, true>(s, a, grid, block, variant);
+        else launch_step_nt<BC, true, false>(s, a, grid, block, variant);
     } else {
-        if (macro) launch_step_nt<BC, false, true>(s, a, grid, block);
-        else launch_step_nt<BC, false, false>(s, a, grid, block);
+        if (macro) launch_step_nt<BC, false, true>(s, a, grid, block, variant);
+        else launch_step_nt<BC, false, false>(s, a, grid, block, variant);
     }
+}
+
+// variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py):
+//   lattice pair >= 1 GB (4096^2 and up): non-temporal stores + 2 rows x 512 cells per workgroup
+//                                         (+3..4 % over plain stores at 8192^2)
+//   smaller (Infinity-Cache resident)   : plain stores + XCD-aware tile order (+5 % at 2048^2;
+//                                         non-temporal stores cost 15 % there)
+int effective_variant(const lb_sim *s)
+{
+    if (s->variant >= 0) return s->variant;
+    const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
+    return pair_bytes >= 1.0e9 ? 9 : 16;
 }
 
 // Launch the fused step over local rows row_begin + i*row_step, i < row_count.
@@ -527,15 +593,17 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 {
     if (row_count <= 0) return LB_OK;
     const StepArgs a = step_args(s, row_begin, row_step, row_count);
-    const int rows_per_block = ((s->variant >> 2) & 3) == 1 ? 1 : (((s->variant >> 2) & 3) == 2 ? 2 : 4);
+    const int variant = effective_variant(s);
+    const int rpb_sel = (variant >> 2) & 3;          // bits 2-3: rows per block 0 -> 4, 1 -> 1, 2 -> 2
+    const int rows_per_block = rpb_sel == 1 ? 1 : (rpb_sel == 2 ? 2 : 4);
     const int waves_x = 4 / rows_per_block;          // waves side by side in x
     dim3 block(64 * waves_x, rows_per_block);
     const int lanes_x = (int)(s->pitch / 4);
     dim3 grid((lanes_x + block.x - 1) / block.x, (row_count + rows_per_block - 1) / rows_per_block);
     switch (s->p.bc_mode) {
-    case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro); break;
-    case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro); break;
-    default: launch_step_bc<LB_BC_CAVITY>(s, a, grid, block, macro); break;
+    case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro, variant); break;
+    case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro, variant); break;
+    default: launch_step_bc<LB_BC_CAVITY>(s, a, grid, block, macro, variant); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -1074,6 +1142,22 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
 }
 
 // ---- measurement -------------------------------------------------------------------------
+int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_copy_calibration inside a split step");
+    DeviceGuard guard(s->p.device);
+    const long long n4 = s->lat_floats / 4;
+    const f4a *src = reinterpret_cast<const f4a *>(s->lat[s->cur]);
+    f4a *dst = reinterpret_cast<f4a *>(s->lat[s->cur ^ 1]);
+    const int grid = 256 * 8;       // 256 CUs x 8 blocks, grid-stride over the rest
+    if (nontemporal) hipLaunchKernelGGL(k_copy4<true>, dim3(grid), dim3(256), 0, s->stream, src, dst, n4);
+    else hipLaunchKernelGGL(k_copy4<false>, dim3(grid), dim3(256), 0, s->stream, src, dst, n4);
+    HIP_TRY(hipGetLastError());
+    if (bytes_moved) *bytes_moved = 2 * n4 * 16;
+    return LB_OK;
+}
+
 int lb_timer_start(lb_sim *s)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");

@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
+    ap.add_argument("--calibrate", type=int, default=0,
+                    help="also launch N plain float4 copies of known size before the timed region "
+                         "(FETCH_SIZE calibration for rocprofv3 --pmc runs; adds copy_GBps to the line)")
     args = ap.parse_args()
 
     import torch
@@ -133,7 +136,11 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
-    sim.run(args.warmup, wait=False) if world > 1 else sim.run(args.warmup, wait=False)
+    copy_gbs = None
+    if args.calibrate:
+        copy_gbs = {"plain": round(eng.copy_calibration(args.calibrate, False)[0], 1),
+                    "nontemporal": round(eng.copy_calibration(args.calibrate, True)[0], 1)}
+    sim.run(args.warmup, wait=False)
     barrier()
     t0 = time.perf_counter()
     ev_ms = sim.timed_run(args.steps)          # enqueue K steps between two HIP events, wait for them
@@ -173,6 +180,8 @@ def main():
                          "kernel": "k_step<PERIODIC> (fused pull-stream+collide), %d x %d cells per launch" % (n, h),
                          "launch_ms": round(launch_s * 1e3, 4)},
         }
+        if copy_gbs is not None:
+            line["copy_GBps"] = copy_gbs
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -144,7 +144,14 @@ int lb_timer_stop(lb_sim *s, float *elapsed_ms);
 /* Device layout facts for DESIGN.md / bench.py: pitch (floats), plane stride
  * (floats), bytes allocated. */
 int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated);
-/* Kernel variant selector for tuning experiments (0 = default). */
+/* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
+ * (which is scratch between steps).  *bytes_moved = bytes read + written.  Known traffic in the
+ * fused kernel's access shape: corrects rocprofv3 FETCH_SIZE on gfx950 and gives the device's
+ * own streaming ceiling. */
+int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
+/* Kernel variant selector for tuning experiments: -1 = automatic (default); otherwise bit 0
+ * non-temporal stores, bit 1 non-temporal loads, bits 2-3 rows per workgroup (0: 4, 1: 1, 2: 2),
+ * bit 4 XCD-aware tile order.  Results never depend on it. */
 int lb_set_variant(lb_sim *s, int variant);
 
 #ifdef __cplusplus

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/gpu_profile.sh into profiles/: a kernel-time table
+(from --kernel-trace) and HBM traffic per launch (from the two --pmc passes), corrected as
+/opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes: on gfx950 FETCH_SIZE reports half
+the bytes of a wide coalesced read, so the read side is calibrated on the k_copy4 launches of the
+same run, whose byte count is known; WRITE_SIZE is taken as is (checked the same way).
+
+    python tools/pmc_summary.py gpurun_out/prof_<tag> <round-tag> <grid-side>
+"""
+import csv
+import glob
+import json
+import os
+import statistics as st
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rows_of(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        raise SystemExit("no file matches " + pattern)
+    with open(files[0]) as fh:
+        return list(csv.DictReader(fh))
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
+def main():
+    src, tag, side = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    kt = rows_of(os.path.join(src, "kt", "**", "*_kernel_trace.csv"))
+    dur = {}
+    for r in kt:
+        dur.setdefault(short(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    vg = {short(r["Kernel_Name"]): (r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"]) for r in kt}
+    pmc = {}
+    for which, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for r in rows_of(os.path.join(src, which, "**", "*_counter_collection.csv")):
+            if r["Counter_Name"] == cname:
+                pmc.setdefault((short(r["Kernel_Name"]), cname), []).append(float(r["Counter_Value"]))
+
+    lines = ["# rocprofv3 summary %s (grid %dx%d)" % (tag, side, side), "",
+             "Command: `tools/gpu_profile.sh` = `rocprofv3 --kernel-trace --stats` and two `--pmc` passes "
+             "(FETCH_SIZE, WRITE_SIZE) around `bench.py --steps 20 --warmup 5 --calibrate 5`.", "",
+             "## Kernel time (--kernel-trace)", "",
+             "| kernel | calls | avg us | min us | max us | VGPR | SGPR | scratch | LDS |", "|---|---|---|---|---|---|---|---|---|"]
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        lines.append("| %s | %d | %.1f | %.1f | %.1f | %s | %s | %s | %s |" % (
+            k, len(v), st.mean(v) / 1e3, min(v) / 1e3, max(v) / 1e3, *vg[k]))
+
+    # calibration on the copy kernel (bytes known: lattice allocation read once, written once)
+    copy_bytes = (9 * (side + 2) * ((side + 63) // 64 * 64) + 128) * 4
+    copy_fetch = st.mean(pmc[("k_copy4<false>", "FETCH_SIZE")]) * 1024
+    copy_write = st.mean(pmc[("k_copy4<false>", "WRITE_SIZE")]) * 1024
+    fetch_corr = copy_bytes / copy_fetch
+    write_corr = copy_bytes / copy_write
+    lines += ["", "## HBM traffic (--pmc, per launch)", "",
+              "Calibration on `k_copy4<false>` (reads %.0f B, writes the same): FETCH_SIZE x 1024 = %.4g B -> "
+              "read correction x%.3f; WRITE_SIZE x 1024 = %.4g B -> write correction x%.3f." % (
+                  copy_bytes, copy_fetch, fetch_corr, copy_write, write_corr), "",
+              "| kernel | FETCH_SIZE (KiB) | WRITE_SIZE (KiB) | HBM read B (corrected) | HBM write B | total B | algorithmic B | ratio |",
+              "|---|---|---|---|---|---|---|---|"]
+    out = {}
+    for k in sorted(dur):
+        if (k, "FETCH_SIZE") not in pmc or not k.startswith("k_step"):
+            continue
+        f = st.mean(pmc[(k, "FETCH_SIZE")])
+        w = st.mean(pmc[(k, "WRITE_SIZE")])
+        rd, wr = f * 1024 * fetch_corr, w * 1024 * write_corr
+        macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, NTL, NTS, XCD>
+        alg = 72.0 * side * side + (12.0 * side * side if macro else 0.0)
+        lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
+        if not macro:
+            out = {"kernel": k, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
+                   "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
+                   "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.md" % tag), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    jpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    allj = {}
+    if os.path.exists(jpath):
+        with open(jpath) as fh:
+            allj = json.load(fh)
+    allj[str(side)] = out
+    with open(jpath, "w") as fh:
+        json.dump(allj, fh, indent=1, sort_keys=True)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

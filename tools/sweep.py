@@ -41,6 +41,9 @@ def main():
                 sim.run(3)
                 ms = sim.timed_run(args.steps)
                 res[v].append(n * n * args.steps / (ms * 1e-3) / 1e6)
+        for nt in (False, True):
+            gbs, nb = sim.copy_calibration(10, nt)
+            print("n=%5d float4 copy (nt=%d): %.1f GB/s (%.0f MB per launch)" % (n, nt, gbs, nb / 1e6), flush=True)
         for v in variants:
             best, med = max(res[v]), float(np.median(res[v]))
             print("n=%5d bc=%s mask=%d variant=%2d  MLUPS best %9.1f median %9.1f  -> %7.1f GB/s  %.3f of 8 TB/s"
