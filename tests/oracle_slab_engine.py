@@ -1,0 +1,103 @@
+"""CPU stand-in for the slab engine interface of LB_D2Q9.slabs (test infrastructure).
+
+It implements the same methods as LB_D2Q9.simulation.Simulation's slab API (step_boundary,
+step_interior, step_finish, halo_export, halo_import, set_f, get_fields, sync) on top of the
+oracle's C functions, so that the partition / neighbour / exchange logic of DistributedSlab can run
+under torch.distributed+gloo on a machine without a GPU.  The product never imports this file.
+"""
+import ctypes as ct
+
+import numpy as np
+
+from oracle import oracle as O
+
+K_UP, K_DOWN = (2, 5, 6), (4, 7, 8)
+
+
+class OracleSlabEngine(object):
+    def __init__(self, nx, ny, omega, bc="pipe", obstacle_mask=None, device=0, y0=0, local_ny=None,
+                 halo=True, inlet_rho=1., outlet_rho=1., lid_u=0., rho0=1.):
+        self.nx, self.ny, self.y0 = nx, ny, y0
+        self.h = ny if local_ny is None else local_ny
+        self.device = device
+        self.bc = {"pipe": O.BC_PIPE, "periodic": O.BC_PERIODIC, "cavity": O.BC_CAVITY}[bc]
+        periodic = self.bc == O.BC_PERIODIC
+        # a ghost row only where a neighbour exists, so that the array's edge rows are the walls
+        self.gs = 1 if (periodic or y0 > 0) else 0
+        self.gn = 1 if (periodic or y0 + self.h < ny) else 0
+        self.rows = self.h + self.gs + self.gn
+        self.omega, self.rin, self.rout, self.lid, self.rho0 = omega, inlet_rho, outlet_rho, lid_u, rho0
+        z3 = lambda: np.zeros((9, self.rows, nx), np.float32)
+        self.cur, self.new = z3(), None
+        self.feq = z3()
+        self.rho, self.u, self.v = (np.zeros((self.rows, nx), np.float32) for _ in range(3))
+        self.mask = None
+        if obstacle_mask is not None:
+            m = np.zeros((self.rows, nx), np.int32)
+            m[self.gs:self.gs + self.h] = (np.asarray(obstacle_mask) != 0).T
+            self.mask = m
+
+    def sync(self):
+        pass
+
+    def set_f(self, f_slab):
+        self.cur[:, self.gs:self.gs + self.h, :] = np.asarray(f_slab, np.float32).transpose(2, 1, 0)
+
+    def _step(self):
+        L, nx, rows = O.lib(), self.nx, self.rows
+        new = self.cur.copy()                           # stale entries are overwritten or never read
+        wrap_x = 1 if self.bc == O.BC_PERIODIC else 0
+        L.o2_stream(O._f(self.cur), O._f(new), nx, rows, wrap_x, 0)
+        if self.bc == O.BC_PIPE:
+            L.o2_bc_pipe(O._f(new), np.float32(self.rin), np.float32(self.rout), nx, rows)
+        elif self.bc == O.BC_CAVITY:
+            L.o2_bc_cavity(O._f(new), np.float32(self.lid), np.float32(self.rho0), nx, rows)
+        if self.mask is not None:
+            L.o2_bounceback(self.mask.ctypes.data_as(O._ip), O._f(new), nx, rows)
+        L.o2_moments(O._f(new), O._f(self.rho), O._f(self.u), O._f(self.v), nx, rows)
+        L.o2_feq(O._f(self.feq), O._f(self.rho), O._f(self.u), O._f(self.v), np.float32(O.cs2),
+                 np.float32(O.cs22), np.float32(O.two_cs4), nx, rows)
+        L.o2_collide(O._f(new), O._f(self.feq), np.float32(self.omega), nx, rows)
+        return new
+
+    def step_boundary(self, write_macro=False):
+        self.new = self._step()                         # whole slab at once; the split is a GPU concern
+
+    def step_interior(self, write_macro=False):
+        pass
+
+    def step_finish(self):
+        self.cur, self.new = self.new, None
+
+    def _target(self):
+        return self.new if self.new is not None else self.cur
+
+    @staticmethod
+    def _as_array(buf, n):
+        if isinstance(buf, np.ndarray):
+            return buf.reshape(3, n)
+        return np.ctypeslib.as_array((ct.c_float * (3 * n)).from_address(int(buf))).reshape(3, n)
+
+    def halo_export(self, side, buf):
+        a, out = self._target(), self._as_array(buf, self.nx)
+        row = self.gs + (self.h - 1 if side else 0)
+        for i, k in enumerate(K_UP if side else K_DOWN):
+            out[i] = a[k, row]
+
+    def halo_import(self, side, buf):
+        a, src = self._target(), self._as_array(buf, self.nx)
+        if (side == 0 and not self.gs) or (side == 1 and not self.gn):
+            return
+        row = self.rows - 1 if side else 0
+        for i, k in enumerate(K_DOWN if side else K_UP):
+            a[k, row] = src[i]
+
+    def get_fields(self, which=("f", "u", "v", "rho")):
+        sl = slice(self.gs, self.gs + self.h)
+        out = {}
+        if "f" in which:
+            out["f"] = np.asfortranarray(self.cur[:, sl].transpose(2, 1, 0))
+        for k in ("rho", "u", "v"):
+            if k in which:
+                out[k] = np.asfortranarray(getattr(self, k)[sl].T)
+        return out

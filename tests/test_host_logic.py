@@ -1,0 +1,140 @@
+"""Host-side logic of the drop-in classes, without a GPU: parameter derivation against the constants
+the reference's notebooks print, mask ingestion, slab arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+
+
+def dry(cls):
+    """The real constructor code with the device hooks stubbed out (no GPU in this test)."""
+    class Dry(cls):
+        def init_hip(self):
+            self._sim = None
+
+        def init_hydro(self):
+            self.inlet_rho, self.outlet_rho = self._boundary_densities()
+
+        def update_feq(self):
+            pass
+
+        def init_pop(self, amplitude=.001):
+            pass
+    return Dry
+
+
+def test_pipe_flow_constants_match_reference_prints():
+    """opencl Pipe_Flow(D=1.5, rho=10, nu=5, gradP=-100, len=3, N=10/50/200):
+    docs/opencl_dimensionless_verification.ipynb:94-98, 115, 168-172, 189, 221-225, 242."""
+    from LB_D2Q9.dimensionless import opencl_dim as lb
+    expect = {10: dict(ulb=0.1, glob=(32, 32), rin=1.063),
+              50: dict(ulb=0.02, glob=(128, 64), rin=1.002424),
+              200: dict(ulb=0.005, glob=(416, 224), rin=1.000150375)}
+    for N, e in expect.items():
+        s = dry(lb.Pipe_Flow)(diameter=1.5, rho=10., viscosity=5., pressure_grad=-100., pipe_length=3., N=N,
+                              verbose=False)
+        assert s.T == pytest.approx(0.387298334621, rel=1e-11)
+        assert s.W == pytest.approx(1.16189500386, rel=1e-11)
+        assert s.omega == pytest.approx(0.324465802203, rel=1e-11)
+        assert s.ulb == pytest.approx(e["ulb"]) and s.two_d_global_size == e["glob"]
+        assert s.inlet_rho == pytest.approx(e["rin"], rel=1e-12) and s.outlet_rho == 1.
+        assert (s.nx, s.ny) == (2 * N + 1, N + 1) and (s.lx, s.ly) == (2 * N, N)
+        assert s.three_d_global_size == e["glob"] + (9,)
+
+
+def test_pipe_flow_constants_equal_oracle_restatement(oracle):
+    from LB_D2Q9.dimensionless import hip_dim as lb
+    kw = dict(diameter=0.7, rho=2.5, viscosity=0.3, pressure_grad=-4., pipe_length=2.2, N=37, time_prefactor=1.3)
+    s = dry(lb.Pipe_Flow)(verbose=False, **kw)
+    p = oracle.opencl_pipe_parameters(**kw)
+    for k in ("L", "T", "W", "delta_x", "delta_t", "ulb", "lb_viscosity", "omega", "lx", "ly", "nx", "ny",
+              "inlet_rho", "outlet_rho"):
+        assert getattr(s, k) == p[k], k
+    c = dry(lb.Pipe_Flow_Cylinder)(cylinder_center=[.6, .35], cylinder_radius=.1, verbose=False, **kw)
+    q = oracle.opencl_pipe_parameters(cylinder_radius=.1, **kw)
+    for k in ("L", "T", "W", "omega", "nx", "ny", "inlet_rho"):
+        assert getattr(c, k) == q[k], k
+    want = oracle.disc_mask(q["nx"], q["ny"], 37 * .6 / .1, 37 * .35 / .1, 37)
+    assert c.obstacle_mask_host.dtype == np.int32 and c.obstacle_mask_host.flags.f_contiguous
+    assert np.array_equal(c.obstacle_mask_host.astype(bool), want)
+
+
+def test_constructor_rejects_unstable_omega():
+    from LB_D2Q9.dimensionless import hip_dim as lb
+    with pytest.raises(AssertionError):      # reference: `assert self.omega < 2.` (opencl_dim.py:120)
+        dry(lb.Pipe_Flow)(diameter=1., rho=1., viscosity=-0.1, pressure_grad=-1., pipe_length=1., N=8, verbose=False)
+
+
+def test_module_constants_and_helpers():
+    from LB_D2Q9.dimensionless import opencl_dim as lb
+    assert lb.get_divisible_global((3751, 1251), (32, 32)) == (3776, 1280)       # comparison notebook :233
+    assert lb.get_divisible_global((64, 32, 9), (32, 32, 1)) == (64, 32, 9)
+    assert lb.NUM_JUMPERS == 9 and lb.w.dtype == np.float32 and lb.cx.dtype == np.int32
+    assert list(lb.cx) == [0, 1, 0, -1, 0, 1, -1, -1, 1] and list(lb.cy) == [0, 0, 1, 0, -1, 1, 1, -1, -1]
+    assert float(lb.w.sum()) == pytest.approx(1.0, abs=1e-7)
+    assert lb.cs2 == pytest.approx(1. / 3.) and lb.two_cs4 == pytest.approx(2. / 9.)
+
+
+# ---- masks --------------------------------------------------------------------------------------------
+def test_disc_pixels_is_the_strict_disc(oracle):
+    from LB_D2Q9.masks import disc_pixels
+    d = golden("o1_cyl_61x41")                 # mask built by the imported reference class
+    m = np.zeros((61, 41), bool)
+    xs, ys = disc_pixels(4 * .4 / .1, 4 * .5 / .1, 4, m.shape)
+    m[xs, ys] = True
+    assert np.array_equal(m, d["mask"])
+    for xc, yc, r, shape in ((10.5, 7.25, 3.3, (30, 20)), (2., 2., 5., (12, 9)), (0., 0., 1., (4, 4))):
+        m = np.zeros(shape, bool)
+        xs, ys = disc_pixels(xc, yc, r, shape)
+        m[xs, ys] = True
+        assert np.array_equal(m, oracle.disc_mask(shape[0], shape[1], xc, yc, r))
+
+
+def test_tiff_reader_on_the_reference_obstacle_image():
+    """docs/CS205_obstacle_4.tif (ImageJ, big-endian, 8-bit, one strip) committed as input data."""
+    from LB_D2Q9.masks import obstacle_mask_from_tiff, read_tiff_u8
+    path = os.path.join(GOLDEN, "CS205_obstacle_4.tif")
+    img = read_tiff_u8(path)
+    assert img.shape == (400, 1600) and img.dtype == np.uint8
+    assert set(np.unique(img)) <= {0, 255}
+    assert 0.005 < (img > 0).mean() < 0.02                       # SURVEY: 1.08 % solid
+    PIL = pytest.importorskip("PIL.Image")
+    assert np.array_equal(img, np.asarray(PIL.open(path)))
+    mask = obstacle_mask_from_tiff(path, (1600, 400))            # identity rescale, transposed to (x, y)
+    assert mask.dtype == np.int32 and mask.flags.f_contiguous and np.array_equal(mask.astype(bool), (img > 0).T)
+    big = obstacle_mask_from_tiff(path, (4096, 4096))
+    assert big.shape == (4096, 4096) and abs(big.mean() - (img > 0).mean()) < 2e-3
+
+
+def test_tiff_reader_little_endian_multi_strip(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    from LB_D2Q9.masks import read_tiff_u8, resize_nearest
+    rng = np.random.default_rng(0)
+    a = (rng.random((37, 53)) < 0.3).astype(np.uint8) * 255
+    p = str(tmp_path / "m.tif")
+    PIL.fromarray(a).save(p)
+    assert np.array_equal(read_tiff_u8(p), a)
+    assert np.array_equal(resize_nearest(a, a.shape), a)
+    up = resize_nearest(a, (74, 106))
+    assert np.array_equal(up[::2, ::2], a) and np.array_equal(up[1::2, 1::2], a)
+    with pytest.raises(ValueError):
+        read_tiff_u8(__file__)
+
+
+# ---- slab arithmetic -------------------------------------------------------------------------------------
+def test_partition_rows_and_neighbours():
+    from LB_D2Q9.slabs import neighbours, partition_rows
+    for ny, n in ((8192, 8), (8192, 3), (50, 7), (5, 5)):
+        parts = partition_rows(ny, n)
+        assert parts[0][0] == 0 and sum(h for _, h in parts) == ny
+        assert all(a[0] + a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert max(h for _, h in parts) - min(h for _, h in parts) <= 1
+    assert partition_rows(8192, 8) == [(1024 * r, 1024) for r in range(8)]
+    with pytest.raises(ValueError):
+        partition_rows(4, 5)
+    assert neighbours(0, 4, False) == (-1, 1) and neighbours(3, 4, False) == (2, -1)
+    assert neighbours(0, 4, True) == (3, 1) and neighbours(3, 4, True) == (2, 0)
+    assert neighbours(0, 1, True) == (0, 0) and neighbours(0, 1, False) == (-1, -1)
+    assert neighbours(1, 2, True) == (0, 0)

@@ -1,0 +1,192 @@
+"""The CPU oracle against (a) fixtures produced by executing the reference's own sources
+(oracle/make_golden.py), (b) the reference's analytic Poiseuille known-answer test and (c) the
+constants its notebooks print.  No GPU needed.  Fixture comparisons are bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def kwargs_of(d):
+    kw = dict(zip([str(k) for k in d["kw_names"]], [float(v) for v in d["kw_vals"]]))
+    kw["N"] = int(kw["N"])
+    return kw
+
+
+def exact(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+# ---- O2: every kernel of D2Q9.cl ------------------------------------------------------------------
+def test_o2_each_kernel_bit_exact(oracle):
+    O = oracle
+    d = golden("o2_kernels_37x19")
+    nx, ny = int(d["nx"]), int(d["ny"])
+
+    def fresh():
+        s = O.O2Sim(nx, ny, float(d["omega"]), O.BC_PIPE, float(d["inlet_rho"]), float(d["outlet_rho"]), mask=d["mask"])
+        s.set_f(d["f0"])
+        s.fs[...] = d["fs0"].transpose(2, 1, 0)
+        return s
+
+    L = O.lib()
+    s = fresh()
+    L.o2_stream(O._f(s.f), O._f(s.fs), nx, ny, 0, 0)
+    assert exact(s.fs.transpose(2, 1, 0), d["after_move_fs"])          # stale entries included
+    s = fresh()
+    L.o2_bc_pipe(O._f(s.f), np.float32(s.inlet_rho), np.float32(s.outlet_rho), nx, ny)
+    assert exact(s.f.transpose(2, 1, 0), d["after_bcs_f"])
+    s = fresh()
+    L.o2_bounceback(s.mask.ctypes.data_as(O._ip), O._f(s.f), nx, ny)
+    assert exact(s.f.transpose(2, 1, 0), d["after_bounce_f"])
+    s = fresh()
+    s.update_hydro()
+    assert exact(s.rho.T, d["hydro_rho"]) and exact(s.u.T, d["hydro_u"]) and exact(s.v.T, d["hydro_v"])
+    s.update_feq()
+    assert exact(s.feq.transpose(2, 1, 0), d["feq"])
+    s.collide_particles()
+    assert exact(s.f.transpose(2, 1, 0), d["after_collide_f"])
+    s.zero_velocity_in_obstacle()
+    assert exact(s.u.T, d["zeroed_u"]) and exact(s.v.T, d["zeroed_v"])
+
+
+@pytest.mark.parametrize("name", ["o2_pipe_N10", "o2_pipe_noise_49x25", "o2_cyl_61x31"])
+def test_o2_runs_bit_exact(oracle, name):
+    O = oracle
+    d = golden(name)
+    s = O.O2Sim(int(d["nx"]), int(d["ny"]), float(d["omega"]), O.BC_PIPE, float(d["inlet_rho"]),
+                float(d["outlet_rho"]), mask=d["mask"] if "mask" in d.files else None)
+    s.set_f(d["f0"])
+    done = 0
+    for n in sorted(int(k[1:-2]) for k in d.files if k.endswith("_u") and k[0] == "s"):
+        s.run(n - done)
+        done = n
+        g = s.get_fields()
+        for k in ("f", "feq", "rho", "u", "v"):
+            assert exact(g[k], d["s%d_%s" % (n, k)]), (name, n, k)
+
+
+def test_o2_constructor_matches_fixture_and_notebook(oracle):
+    """opencl_dim.Pipe_Flow parameter derivation: the N=10 verification case prints
+    T=0.387298334621, W=1.16189500386, u_lb=0.1, omega=0.324465802203, inlet rho 1.063
+    (docs/opencl_dimensionless_verification.ipynb:94-115); N=50 -> 1.002424, N=200 -> 1.000150375."""
+    O = oracle
+    d = golden("o2_pipe_N10")
+    s = O.O2Sim.pipe_flow(diameter=1.5, rho=10., viscosity=5., pressure_grad=-100., pipe_length=3., N=10)
+    p = s.params
+    assert (p["nx"], p["ny"]) == (int(d["nx"]), int(d["ny"])) == (21, 11)
+    assert p["omega"] == float(d["omega"]) and p["inlet_rho"] == float(d["inlet_rho"])
+    assert p["T"] == pytest.approx(0.387298334621, rel=1e-11)
+    assert p["W"] == pytest.approx(1.16189500386, rel=1e-11)
+    assert p["ulb"] == pytest.approx(0.1) and p["omega"] == pytest.approx(0.324465802203, rel=1e-11)
+    assert p["inlet_rho"] == pytest.approx(1.063, rel=1e-12)
+    assert exact(s.get_fields()["f"], d["f0"])                 # ramp + feq + f = feq
+    for N, rin, glob in ((50, 1.002424, (128, 64)), (200, 1.000150375, (416, 224))):
+        q = O.opencl_pipe_parameters(diameter=1.5, rho=10., viscosity=5., pressure_grad=-100., pipe_length=3., N=N)
+        assert q["inlet_rho"] == pytest.approx(rin, rel=1e-12)
+        assert tuple(-(-v // 32) * 32 for v in (q["nx"], q["ny"])) == glob
+
+
+# ---- the reference's analytic KAT ---------------------------------------------------------------------
+@pytest.mark.parametrize("N,steps,tol", [(10, 999, 0.05), (50, 25000, 0.01)])
+def test_o2_poiseuille_profile(oracle, N, steps, tol):
+    """docs/opencl_dimensionless_verification.ipynb:279-342, 632-696: after t = 10 the physical
+    u(y) at mid-pipe overlays (1/(2 rho nu)) gradP y (y - D); peak 0.5625 m/s."""
+    D, rho, nu, gradP = 1.5, 10., 5., -100.
+    s = oracle.O2Sim.pipe_flow(diameter=D, rho=rho, viscosity=nu, pressure_grad=gradP, pipe_length=3., N=N)
+    p = s.params
+    s.run(steps)
+    u = s.get_fields()["u"] * (p["delta_x"] / p["delta_t"]) * (p["L"] / p["T"])
+    y = np.linspace(0, D, p["ny"])
+    theory = (1. / (2 * rho * nu)) * gradP * y * (y - D)
+    prof = u[p["nx"] // 2]
+    assert theory.max() == pytest.approx(0.5625)
+    assert prof[0] == 0. and prof[-1] == 0.                    # no-slip walls, exactly
+    assert np.abs(prof - theory).max() < tol * theory.max()
+
+
+# ---- O1: the Cython path ------------------------------------------------------------------------------
+def test_o1_pipe_trace_and_runs_bit_exact(oracle):
+    d = golden("o1_pipe_33x17")
+    s = oracle.O1Sim.pipe_flow(perturb=d["perturb"], **kwargs_of(d))
+    assert (s.nx, s.ny) == (int(d["nx"]), int(d["ny"]))
+    assert s.omega == float(d["omega"]) and s.inlet_rho == float(d["inlet_rho"])
+    assert exact(s.rho, d["rho0"]) and exact(s.f, d["f0"])
+    s.run(2)
+    for k in ("f", "feq", "rho", "u", "v"):
+        assert exact(s.get_fields()[k], d["pre_" + k]), k
+    s.move_bcs();          assert exact(s.f, d["t_bcs_f"])
+    s.move();              assert exact(s.f, d["t_move_f"])
+    s.update_hydro()
+    assert exact(s.rho, d["t_hydro_rho"]) and exact(s.u, d["t_hydro_u"]) and exact(s.v, d["t_hydro_v"])
+    s.update_feq();        assert exact(s.feq, d["t_feq"])
+    s.collide_particles(); assert exact(s.f, d["t_collide_f"])
+    done = 3
+    for n in (50, 500):
+        s.run(n - done)
+        done = n
+        for k in ("f", "feq", "rho", "u", "v"):
+            assert exact(s.get_fields()[k], d["s%d_%s" % (n, k)]), (n, k)
+
+
+def test_o1_cylinder_bit_exact(oracle):
+    d = golden("o1_cyl_61x41")
+    s = oracle.O1Sim.pipe_flow(cylinder_center=list(d["cylinder_center"]), cylinder_radius=float(d["cylinder_radius"]),
+                               perturb=d["perturb"], **kwargs_of(d))
+    assert exact(s.mask.astype(bool), d["mask"])               # disc restatement == the mask the reference built
+    assert s.omega == float(d["omega"]) and s.inlet_rho == float(d["inlet_rho"])
+    done = 0
+    for n in (1, 50, 300):
+        s.run(n - done)
+        done = n
+        g = s.get_fields()
+        for k in ("f", "feq", "rho", "u", "v"):
+            assert exact(g[k], d["s%d_%s" % (n, k)]), (n, k)
+        assert np.all(g["u"][d["mask"]] == 0)
+
+
+def test_o1_numpy1_mode_stays_within_one_ulp_per_step(oracle):
+    """numpy2=0 restates what the authors' NumPy 1.x computed (float32 collide); it is unpinned
+    but must track the pinned numpy2=1 mode closely."""
+    d = golden("o1_pipe_33x17")
+    a = oracle.O1Sim.pipe_flow(perturb=d["perturb"], numpy2=True, **kwargs_of(d))
+    b = oracle.O1Sim.pipe_flow(perturb=d["perturb"], numpy2=False, **kwargs_of(d))
+    a.run(100); b.run(100)
+    assert np.abs(a.rho - b.rho).max() < 5e-6 and np.abs(a.u - b.u).max() < 5e-6
+
+
+def test_cython_constructor_constants(oracle):
+    """Derived constants of the Cython-style classes: values printed by the notebooks
+    (docs/python_cython_opencl_comparison.ipynb cell 10-13, docs/vortex_sheet_movie.ipynb:98-154,
+    docs/cs205_movie.ipynb:98-154) and the same quantities read back from the imported reference."""
+    O = oracle
+    p = O.cython_pipe_parameters(diameter=1., rho=1., viscosity=1., pressure_grad=-10., pipe_length=3., N=125,
+                                 cylinder_radius=.1)
+    assert p["L"] == pytest.approx(0.1) and p["T"] == pytest.approx(0.08) and p["Re"] == pytest.approx(1.5625)
+    assert p["omega"] == pytest.approx(0.413223140496, rel=1e-11)
+    assert (p["nx"], p["ny"]) == (3751, 1251) and p["inlet_rho"] == pytest.approx(1.00368738304, rel=1e-11)
+    t = golden("o1_constants")["table"]
+    for N, r, L, T, Re, omega, rin, nx, ny in t:
+        q = O.cython_pipe_parameters(diameter=1., rho=1., viscosity=1., pressure_grad=-100., pipe_length=3.,
+                                     N=int(N), cylinder_radius=r)
+        assert (q["L"], q["T"], q["Re"], q["omega"], q["inlet_rho"], q["nx"], q["ny"]) == (L, T, Re, omega, rin, nx, ny)
+    assert t[0][4] == pytest.approx(156.25) and t[0][5] == pytest.approx(1.92604006163, rel=1e-11)
+    assert t[0][6] == pytest.approx(1.0092209152, rel=1e-10) and t[1][6] == pytest.approx(1.009228288, rel=1e-10)
+
+
+# ---- cross-semantics sanity (the reference authors' own finding) ---------------------------------------------
+def test_o1_and_o2_agree_in_the_interior_on_the_first_step(oracle):
+    """testing/Bryan/opencl_check_03.ipynb:593,778: the two implementations agree to 1e-6 away from
+    walls and corners.  Identical rest state on the density ramp, one step."""
+    O = oracle
+    nx, ny, omega, rin = 48, 24, 1.0, 1.004
+    ramp = O.density_ramp(nx, ny, rin, 1.)
+    o2 = O.O2Sim(nx, ny, omega, O.BC_PIPE, rin, 1.)
+    o2.set_macro(ramp, 0 * ramp, 0 * ramp); o2.update_feq(); o2.init_pop()
+    o1 = O.O1Sim(nx, ny, omega, rin, 1.)
+    o1.rho[...] = ramp; o1.update_feq(); o1.init_pop()
+    o1.run(1); o2.run(1)
+    g = o2.get_fields()
+    inner = (slice(3, -3), slice(3, -3))
+    assert np.abs(g["rho"][inner] - o1.rho[inner]).max() <= 1e-6
+    assert np.abs(g["u"][inner] - o1.u[inner]).max() <= 1e-6
