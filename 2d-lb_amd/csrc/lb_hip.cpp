@@ -31,7 +31,8 @@
 
 namespace {
 
-constexpr int GUARD = 64;  // floats in front of / behind each lattice allocation
+constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (k_step2's edge strips
+                           // read up to 4 cells before a row and 256 cells past its end)
 
 thread_local char g_err[512] = "";
 
@@ -229,6 +230,68 @@ __device__ __forceinline__ void store4(float *p, f4a v)
     else *reinterpret_cast<f4a *>(p) = v;
 }
 
+// Pull-stream gather for 4 consecutive cells (x4..x4+3) of local row yl: q[k] = f_k at (x - cx_k,
+// y - cy_k) of the source lattice.  ym / yp are the source rows of the cy=+1 / cy=-1 links (already
+// wrapped by the caller where the box is periodic in y within this slab).
+template <int BC, bool MASK, bool NTL>
+__device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk)
+{
+    const long long P = a.pitch, S = a.plane;
+    const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
+    const float *s = a.src;
+    q[0] = load4<NTL>(s + o0);
+    q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
+    q[2] = load4<NTL>(s + 2 * S + om);
+    q[3] = load4u<NTL>(s + 3 * S + o0 + 1);
+    q[4] = load4<NTL>(s + 4 * S + op);
+    q[5] = load4u<NTL>(s + 5 * S + om - 1);
+    q[6] = load4u<NTL>(s + 6 * S + om + 1);
+    q[7] = load4u<NTL>(s + 7 * S + op + 1);
+    q[8] = load4u<NTL>(s + 8 * S + op - 1);
+    mk = uc4{0, 0, 0, 0};
+    if (MASK) mk = *reinterpret_cast<const uc4 *>(a.mask + o0);
+    if (BC == LB_BC_PERIODIC) {
+        // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
+        // row padding (wave-divergent, one lane per row).
+        if (x4 == 0) {
+            q[1].x = s[1 * S + (long long)yl * P + a.nx - 1];
+            q[5].x = s[5 * S + (long long)ym * P + a.nx - 1];
+            q[8].x = s[8 * S + (long long)yp * P + a.nx - 1];
+        }
+        const int c = a.nx - 1 - x4;
+        if (c >= 0 && c < 4) {
+            const float w3 = s[3 * S + (long long)yl * P], w6 = s[6 * S + (long long)ym * P],
+                        w7 = s[7 * S + (long long)yp * P];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == c) { q[3][j] = w3; q[6][j] = w6; q[7][j] = w7; }
+        }
+    }
+}
+
+// Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.
+template <int BC, bool MASK>
+__device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
+                                            f4a &u4, f4a &v4)
+{
+    const bool edge = (BC != LB_BC_PERIODIC) &&
+                      (yg == 0 || yg == a.ny - 1 || x4 == 0 || (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+        if (edge) {
+            if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
+        }
+        if (MASK) bounce_cell(c, mk[j] != 0);
+        float rho, ux, uy;
+        relax_cell(c, a.omega, rho, ux, uy);
+        r4[j] = rho; u4[j] = ux; v4[j] = uy;
+        q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
+        q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+    }
+}
+
 // The hot kernel: one full time step for 4 consecutive cells of one row per lane.
 //   pull-stream (move+copy_buffer) -> boundary rule (move_bcs) -> obstacle swap
 //   (bounceback_in_obstacle) -> moments (update_hydro) -> equilibrium (update_feq) ->
@@ -264,61 +327,13 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
         if (ym < 0) ym = a.h - 1;
         if (yp >= a.h) yp = 0;
     }
-    const long long P = a.pitch, S = a.plane;
-    const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
-    const float *s = a.src;
+    const long long o0 = (long long)yl * a.pitch + x4;
+    f4a q[9], r4, u4, v4;
+    uc4 mk;
+    gather_row<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk);
+    collide_row<BC, MASK>(a, x4, yg, q, mk, r4, u4, v4);
 
-    f4a q[9];
-    q[0] = load4<NTL>(s + o0);
-    q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
-    q[2] = load4<NTL>(s + 2 * S + om);
-    q[3] = load4u<NTL>(s + 3 * S + o0 + 1);
-    q[4] = load4<NTL>(s + 4 * S + op);
-    q[5] = load4u<NTL>(s + 5 * S + om - 1);
-    q[6] = load4u<NTL>(s + 6 * S + om + 1);
-    q[7] = load4u<NTL>(s + 7 * S + op + 1);
-    q[8] = load4u<NTL>(s + 8 * S + op - 1);
-
-    uc4 mk = {0, 0, 0, 0};
-    if (MASK) mk = *reinterpret_cast<const uc4 *>(a.mask + o0);
-
-    if (BC == LB_BC_PERIODIC) {
-        // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
-        // row padding (wave-divergent, one lane per row).
-        if (x4 == 0) {
-            q[1].x = s[1 * S + (long long)yl * P + a.nx - 1];
-            q[5].x = s[5 * S + (long long)ym * P + a.nx - 1];
-            q[8].x = s[8 * S + (long long)yp * P + a.nx - 1];
-        }
-        const int c = a.nx - 1 - x4;
-        if (c >= 0 && c < 4) {
-            const float w3 = s[3 * S + (long long)yl * P], w6 = s[6 * S + (long long)ym * P],
-                        w7 = s[7 * S + (long long)yp * P];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j == c) { q[3][j] = w3; q[6][j] = w6; q[7][j] = w7; }
-        }
-    }
-
-    const bool edge = (BC != LB_BC_PERIODIC) &&
-                      (yg == 0 || yg == a.ny - 1 || x4 == 0 || (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4));
-
-    f4a r4, u4, v4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-        if (edge) {
-            if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
-        }
-        if (MASK) bounce_cell(c, mk[j] != 0);
-        float rho, ux, uy;
-        relax_cell(c, a.omega, rho, ux, uy);
-        r4[j] = rho; u4[j] = ux; v4[j] = uy;
-        q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
-        q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
-    }
-
+    const long long S = a.plane;
     float *d = a.dst + o0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, q[k]);
@@ -326,6 +341,106 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
         store4<false>(a.rho + o0, r4);
         store4<false>(a.u + o0, u4);
         store4<false>(a.v + o0, v4);
+    }
+}
+
+// ---- two time steps per pass ------------------------------------------------------------------
+// Temporal blocking without LDS.  A wave owns a strip of 256 cells (64 lanes x 4) and marches up a
+// segment of rows.  For every row r it computes step 1 (gather from the source lattice + collide:
+// exactly gather_row/collide_row above) and keeps the result in registers; the second step of row
+// y = r-1 needs, per link k, the step-1 value of ONE row only (cy=-1: row r, just computed; cy=0:
+// row r-1; cy=+1: row r-2), so a register window of 3+6 float4 holds everything, and the x-neighbour
+// a link comes from is one element to the left/right = a 1-lane shuffle.  The outermost lanes
+// (0 and 63) are halo: their step-1 values feed lanes 1 and 62, their step-2 values are not
+// stored, so strips advance by 248 cells and nothing is exchanged between waves.  HBM traffic per
+// two updates of a cell: 9 reads + 9 writes (+3.2 % strip overlap, +2 rows per segment), i.e.
+// ~37 B per lattice update instead of 72.
+constexpr int STRIP_OUT = 248;     // cells stored per wave-row: lanes 1..62
+
+// value of the cell one to the LEFT of each of my 4 cells (links with cx = +1)
+__device__ __forceinline__ f4a from_left(f4a v)
+{
+    const float w = __shfl_up(v.w, 1);          // left lane's last cell
+    return f4a{w, v.x, v.y, v.z};
+}
+// value of the cell one to the RIGHT of each of my 4 cells (links with cx = -1)
+__device__ __forceinline__ f4a from_right(f4a v)
+{
+    const float x = __shfl_down(v.x, 1);        // right lane's first cell
+    return f4a{v.y, v.z, v.w, x};
+}
+
+template <int BC, bool MASK, bool MACRO, bool NTS>
+__global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows)
+{
+    const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
+    const int item = blockIdx.x * 4 + threadIdx.y;
+    const int sx = item % strips, sy = item / strips;
+    const int ya = sy * seg_rows;
+    if (ya >= a.h) return;
+    const int yb = min(ya + seg_rows, a.h);
+    const int xr = sx * STRIP_OUT - 4 + lane * 4;       // true x of my first cell; may lie outside the box
+    int x4 = xr;                                        // x used for addressing
+    if (BC == LB_BC_PERIODIC) x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? xr - a.nx : xr);
+    // rows are stored by lanes 1..62 whose cells exist; out-of-box lanes compute don't-care values
+    const bool store_lane = lane >= 1 && lane <= 62 && xr < a.nx;
+    const long long S = a.plane;
+
+    f4a d0 = {}, d1 = {}, d3 = {};                      // step-1 links 0,1,3 of row r-1
+    f4a e2 = {}, e5 = {}, e6 = {};                      // step-1 links 2,5,6 of row r-1
+    f4a g2 = {}, g5 = {}, g6 = {};                      //                     of row r-2
+    for (int r = ya - 1; r <= yb; ++r) {
+        // ---- step 1 of row r ---------------------------------------------------------------------
+        f4a q[9], r4, u4, v4;
+        uc4 mk;
+        int rr = r;
+        bool have = true;
+        if (BC == LB_BC_PERIODIC) rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
+        else have = (r >= 0 && r < a.h);                // outside the box: never consumed un-overwritten
+        if (have) {
+            int ym = rr - 1, yp = rr + 1;
+            if (BC == LB_BC_PERIODIC) {
+                if (ym < 0) ym = a.h - 1;
+                if (yp >= a.h) yp = 0;
+            }
+            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
+            collide_row<BC, MASK>(a, x4, a.y0 + rr, q, mk, r4, u4, v4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- step 2 of row y = r-1 from the register window ---------------------------------------
+        if (r >= ya + 1) {
+            const int y = r - 1;
+            f4a t[9];
+            t[0] = d0;
+            t[1] = from_left(d1);
+            t[3] = from_right(d3);
+            t[2] = g2;
+            t[5] = from_left(g5);
+            t[6] = from_right(g6);
+            t[4] = q[4];
+            t[7] = from_right(q[7]);
+            t[8] = from_left(q[8]);
+            const long long o = (long long)y * a.pitch + x4;
+            uc4 mk2 = {0, 0, 0, 0};
+            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + o);
+            collide_row<BC, MASK>(a, x4, a.y0 + y, t, mk2, r4, u4, v4);
+            if (store_lane) {
+                float *d = a.dst + o;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
+                if (MACRO) {
+                    store4<false>(a.rho + o, r4);
+                    store4<false>(a.u + o, u4);
+                    store4<false>(a.v + o, v4);
+                }
+            }
+        }
+        // ---- slide the window -----------------------------------------------------------------------
+        g2 = e2; g5 = e5; g6 = e6;
+        e2 = q[2]; e5 = q[5]; e6 = q[6];
+        d0 = q[0]; d1 = q[1]; d3 = q[3];
     }
 }
 
@@ -506,8 +621,9 @@ struct lb_sim {
     int stepping = 0;           // 1 between lb_step_boundary and lb_step_finish
     float *feq = nullptr;       // raw allocation, lazily created
     float *rho = nullptr, *u = nullptr, *v = nullptr;
-    uint8_t *mask = nullptr;
+    uint8_t *mask_raw = nullptr, *mask = nullptr;   // mask = mask_raw + GUARD (k_step2 over-reads row ends)
     bool has_mask = false;
+    int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
     hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr;
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -604,6 +720,58 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
     case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro, variant); break;
     case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro, variant); break;
     default: launch_step_bc<LB_BC_CAVITY>(s, a, grid, block, macro, variant); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+// Two fused time steps in one pass (k_step2); single-slab handles only.
+template <int BC>
+void launch_step2_bc(const lb_sim *s, const StepArgs &a, dim3 grid, int strips, int seg_rows, bool macro, bool nts)
+{
+    const dim3 block(64, 4);
+#define LB_LAUNCH2(MASK, MACRO, NTS) \
+    hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, NTS>), grid, block, 0, s->stream, a, strips, seg_rows)
+    if (s->has_mask) {
+        if (macro) { if (nts) LB_LAUNCH2(true, true, true); else LB_LAUNCH2(true, true, false); }
+        else       { if (nts) LB_LAUNCH2(true, false, true); else LB_LAUNCH2(true, false, false); }
+    } else {
+        if (macro) { if (nts) LB_LAUNCH2(false, true, true); else LB_LAUNCH2(false, true, false); }
+        else       { if (nts) LB_LAUNCH2(false, false, true); else LB_LAUNCH2(false, false, false); }
+    }
+#undef LB_LAUNCH2
+}
+
+bool step2_applicable(const lb_sim *s)
+{
+    if (s->multi_slab()) return false;
+    if (s->p.nx < 512 || s->H < 64) return false;
+    if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
+    return true;
+}
+
+int launch_step2(lb_sim *s, bool macro)
+{
+    const StepArgs a = step_args(s, 0, 1, s->H);
+    const int variant = effective_variant(s);
+    const int strips = (s->p.nx + STRIP_OUT - 1) / STRIP_OUT;
+    // one balanced round: as many wave-items as the chip holds at once (waves per CU from the
+    // kernel's register budget; tunable), each marching an equal share of the rows
+    int waves_per_cu = 8;
+    if (const char *e = getenv("LB_STEP2_WAVES_PER_CU")) waves_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+    const int capacity = s->cu_count * waves_per_cu;
+    int segs = capacity / strips;
+    if (segs < 1) segs = 1;
+    int seg_rows = (s->H + segs - 1) / segs;
+    if (seg_rows < 16) seg_rows = 16;
+    segs = (s->H + seg_rows - 1) / seg_rows;
+    const int items = strips * segs;
+    const dim3 grid((items + 3) / 4);
+    const bool nts = (variant & 1) != 0;
+    switch (s->p.bc_mode) {
+    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, a, grid, strips, seg_rows, macro, nts); break;
+    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, a, grid, strips, seg_rows, macro, nts); break;
+    default: launch_step2_bc<LB_BC_CAVITY>(s, a, grid, strips, seg_rows, macro, nts); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -729,6 +897,11 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->plane = (long long)(s->H + 2) * s->pitch + skew;
     s->lat_floats = 9 * s->plane + 2 * GUARD;
     if (const char *e = getenv("LB_VARIANT")) s->variant = atoi(e);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+            s->cu_count = prop.multiProcessorCount;
+    }
 
 #define CREATE_TRY(expr)                                                                       \
     do {                                                                                       \
@@ -755,11 +928,12 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipMalloc(&s->rho, fld_bytes));
     CREATE_TRY(hipMalloc(&s->u, fld_bytes));
     CREATE_TRY(hipMalloc(&s->v, fld_bytes));
-    CREATE_TRY(hipMalloc(&s->mask, (size_t)s->pitch * s->H));
+    CREATE_TRY(hipMalloc(&s->mask_raw, (size_t)s->pitch * s->H + 2 * GUARD));
+    s->mask = s->mask_raw + GUARD;
     CREATE_TRY(hipMemsetAsync(s->rho, 0, fld_bytes, s->stream));
     CREATE_TRY(hipMemsetAsync(s->u, 0, fld_bytes, s->stream));
     CREATE_TRY(hipMemsetAsync(s->v, 0, fld_bytes, s->stream));
-    CREATE_TRY(hipMemsetAsync(s->mask, 0, (size_t)s->pitch * s->H, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->mask_raw, 0, (size_t)s->pitch * s->H + 2 * GUARD, s->stream));
     CREATE_TRY(hipStreamSynchronize(s->stream));
 #undef CREATE_TRY
     s->bytes = 2 * lat_bytes + 3 * fld_bytes + (size_t)s->pitch * s->H;
@@ -776,7 +950,7 @@ int lb_destroy(lb_sim *s)
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v})
         if (p) (void)hipFree(p);
-    if (s->mask) (void)hipFree(s->mask);
+    if (s->mask_raw) (void)hipFree(s->mask_raw);
     for (hipEvent_t e : {s->ev_boundary, s->ev_halo, s->ev_t0, s->ev_t1})
         if (e) (void)hipEventDestroy(e);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1075,8 +1249,17 @@ int lb_run(lb_sim *s, int n_steps)
     DeviceGuard guard(s->p.device);
     int rc;
     if (!s->multi_slab()) {
-        for (int it = 0; it < n_steps; ++it) {
-            if ((rc = launch_step(s, 0, 1, s->H, it == n_steps - 1))) return rc;
+        int it = 0;
+        const bool two = (effective_variant(s) & 32) && step2_applicable(s);
+        if (two && (n_steps & 1)) {                    // odd count: one single step first
+            if ((rc = launch_step(s, 0, 1, s->H, n_steps == 1))) return rc;
+            s->cur ^= 1;
+            it = 1;
+        }
+        for (; it < n_steps; it += two ? 2 : 1) {
+            if (two) rc = launch_step2(s, it + 2 >= n_steps);
+            else rc = launch_step(s, 0, 1, s->H, it == n_steps - 1);
+            if (rc) return rc;
             s->cur ^= 1;
         }
         if (n_steps) s->feq_valid = false;

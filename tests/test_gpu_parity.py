@@ -157,6 +157,41 @@ def test_periodic_mass_drift_tracks_reference(lbhip, oracle):
             assert abs(drift - odrift) < 5e-9, (drift, odrift)
 
 
+# ---- the two-steps-per-pass kernel ------------------------------------------------------------------
+@pytest.mark.parametrize("bc,nx,ny", [("periodic", 1000, 130), ("periodic", 512, 64), ("pipe", 1003, 77),
+                                      ("cavity", 777, 201), ("pipe", 2048, 300)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, masked):
+    """variant bit 5 selects k_step2 (two time steps per pass, register window + lane shuffles).  Same
+    per-cell arithmetic as k_step, so the fields must agree to rounding (FMA contraction may differ
+    between the two instantiations), and both must match the oracle."""
+    from LB_D2Q9.simulation import Simulation
+    rng = np.random.default_rng(nx + ny)
+    f0 = _random_state(rng, nx, ny)
+    mask = None
+    if masked:
+        mask = rng.random((nx, ny)) < 0.03
+        mask[0, :] = mask[-1, :] = False
+        mask[:, 0] = mask[:, -1] = False
+    kw = dict(inlet_rho=1.004, lid_u=0.06)
+    sims = []
+    for variant in (0, 32, 33):
+        s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
+        s.set_variant(variant)
+        s.set_f(f0)
+        s.run(7)                      # odd: one single step + three double steps
+        s.run(4)
+        sims.append(s.get_fields(("f", "rho", "u", "v")))
+    for k in ("f", "rho", "u", "v"):
+        assert maxdiff(sims[0][k], sims[1][k]) <= 1e-6, k
+        assert np.array_equal(sims[1][k], sims[2][k]), k          # NT stores never change results
+    code = {"pipe": oracle.BC_PIPE, "periodic": oracle.BC_PERIODIC, "cavity": oracle.BC_CAVITY}[bc]
+    o = oracle.O2Sim(nx, ny, 1.6, code, 1.004, 1., 0.06, 1., mask=mask)
+    o.set_f(f0)
+    o.run(11)
+    assert_fields_close(sims[1], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
+
+
 # ---- row slabs ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
 @pytest.mark.parametrize("nslabs", [2, 3])

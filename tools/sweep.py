@@ -3,7 +3,8 @@
 
 Times the fused step for every (variant, grid) pair inside ONE process, interleaved over rounds
 (cdna_hip_programming.md section 5.4 rule 24), and prints MLUPS / GB/s / fraction of 8 TB/s.
-variant bits: 0 = non-temporal stores, 1 = non-temporal loads, 2-3 = rows per block (0:4, 1:1, 2:2).
+variant bits: 0 = non-temporal stores, 1 = non-temporal loads, 2-3 = rows per block (0:4, 1:1, 2:2),
+4 = XCD-aware tile order, 5 = two time steps per pass (k_step2).
 """
 import argparse
 import os
@@ -18,7 +19,7 @@ sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="4096,8192")
-    ap.add_argument("--variants", default="0,1,2,3,4,5,8,9")
+    ap.add_argument("--variants", default="0,1,9,32,33")
     ap.add_argument("--bc", default="periodic")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
@@ -38,7 +39,7 @@ def main():
         for r in range(args.rounds):
             for v in variants:
                 sim.set_variant(v)
-                sim.run(3)
+                sim.run(4)
                 ms = sim.timed_run(args.steps)
                 res[v].append(n * n * args.steps / (ms * 1e-3) / 1e6)
         for nt in (False, True):
