@@ -30,7 +30,10 @@ def up_to_date():
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -ffp-contract=on: a*b+c fuses to an FMA only inside one source expression, so every kernel
+    # instantiation (single step, two-step, slab edge rows) rounds identically: results are bitwise
+    # independent of the kernel variant and of the slab partition.
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", SRC, "-o", OUT, "-ldl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -370,6 +370,23 @@ __device__ __forceinline__ f4a from_right(f4a v)
     return f4a{v.y, v.z, v.w, x};
 }
 
+// Row r of step 1 for this lane: resolve the (wrapped) row indices and issue the 9 loads.  Returns
+// false when the row lies outside a non-periodic box (its values are never consumed un-overwritten).
+template <int BC, bool MASK>
+__device__ __forceinline__ bool load_step1_row(const StepArgs &a, int x4, int r, f4a (&q)[9], uc4 &mk, int &rr)
+{
+    rr = r;
+    if (BC == LB_BC_PERIODIC) rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
+    else if (r < 0 || r >= a.h) return false;
+    int ym = rr - 1, yp = rr + 1;
+    if (BC == LB_BC_PERIODIC) {
+        if (ym < 0) ym = a.h - 1;
+        if (yp >= a.h) yp = 0;
+    }
+    gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
+    return true;
+}
+
 template <int BC, bool MASK, bool MACRO, bool NTS>
 __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows)
 {
@@ -391,19 +408,13 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
     f4a g2 = {}, g5 = {}, g6 = {};                      //                     of row r-2
     for (int r = ya - 1; r <= yb; ++r) {
         // ---- step 1 of row r ---------------------------------------------------------------------
+        // (an explicit software prefetch of row r+1 was tried: +36 VGPR, -2 %; the memory pipeline, not
+        // load latency, is what the waves wait for -- profiles/r01_pmc_probe.txt)
         f4a q[9], r4, u4, v4;
-        uc4 mk;
-        int rr = r;
-        bool have = true;
-        if (BC == LB_BC_PERIODIC) rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
-        else have = (r >= 0 && r < a.h);                // outside the box: never consumed un-overwritten
+        uc4 mk = {0, 0, 0, 0};
+        int rr = 0;
+        const bool have = load_step1_row<BC, MASK>(a, x4, r, q, mk, rr);
         if (have) {
-            int ym = rr - 1, yp = rr + 1;
-            if (BC == LB_BC_PERIODIC) {
-                if (ym < 0) ym = a.h - 1;
-                if (yp >= a.h) yp = 0;
-            }
-            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
             collide_row<BC, MASK>(a, x4, a.y0 + rr, q, mk, r4, u4, v4);
         } else {
 #pragma unroll
@@ -692,16 +703,21 @@ void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, b
     }
 }
 
-// variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py):
-//   lattice pair >= 1 GB (4096^2 and up): non-temporal stores + 2 rows x 512 cells per workgroup
-//                                         (+3..4 % over plain stores at 8192^2)
-//   smaller (Infinity-Cache resident)   : plain stores + XCD-aware tile order (+5 % at 2048^2;
-//                                         non-temporal stores cost 15 % there)
+// variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py; profiles/r01_sweep_variants.txt):
+//   >= 2048^2 cells, whole grid on this GPU : two time steps per pass (k_step2): 102 k MLUPS at
+//                                             2048^2, 128 k at 4096^2/8192^2 vs 82 k single-step
+//   lattice pair >= 1 GB (4096^2 and up)    : + non-temporal stores (+3..6 %), and 2 rows x 512
+//                                             cells per workgroup wherever the single-step kernel runs
+//   smaller (Infinity-Cache resident)       : single step, plain stores, XCD-aware tile order
+//                                             (87 k MLUPS at 1024^2; k_step2 has too few waves there)
 int effective_variant(const lb_sim *s)
 {
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
-    return pair_bytes >= 1.0e9 ? 9 : 16;
+    const double cells = (double)s->p.nx * s->H;
+    int v = pair_bytes >= 1.0e9 ? 9 : 16;
+    if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32;
+    return v;
 }
 
 // Launch the fused step over local rows row_begin + i*row_step, i < row_count.

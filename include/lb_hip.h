@@ -151,7 +151,8 @@ int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_a
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
 /* Kernel variant selector for tuning experiments: -1 = automatic (default); otherwise bit 0
  * non-temporal stores, bit 1 non-temporal loads, bits 2-3 rows per workgroup (0: 4, 1: 1, 2: 2),
- * bit 4 XCD-aware tile order.  Results never depend on it. */
+ * bit 4 XCD-aware tile order, bit 5 two time steps per pass where applicable (whole-grid handles,
+ * nx >= 512).  Results never depend on it (bitwise). */
 int lb_set_variant(lb_sim *s, int variant);
 
 #ifdef __cplusplus

@@ -163,8 +163,8 @@ def test_periodic_mass_drift_tracks_reference(lbhip, oracle):
 @pytest.mark.parametrize("masked", [False, True])
 def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, masked):
     """variant bit 5 selects k_step2 (two time steps per pass, register window + lane shuffles).  Same
-    per-cell arithmetic as k_step, so the fields must agree to rounding (FMA contraction may differ
-    between the two instantiations), and both must match the oracle."""
+    per-cell arithmetic as k_step and the library is built with -ffp-contract=on, so the fields must
+    be bitwise equal to the single-step kernel's, and match the oracle."""
     from LB_D2Q9.simulation import Simulation
     rng = np.random.default_rng(nx + ny)
     f0 = _random_state(rng, nx, ny)
@@ -183,7 +183,7 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
         s.run(4)
         sims.append(s.get_fields(("f", "rho", "u", "v")))
     for k in ("f", "rho", "u", "v"):
-        assert maxdiff(sims[0][k], sims[1][k]) <= 1e-6, k
+        assert np.array_equal(sims[0][k], sims[1][k]), k          # -ffp-contract=on: same rounding in every kernel
         assert np.array_equal(sims[1][k], sims[2][k]), k          # NT stores never change results
     code = {"pipe": oracle.BC_PIPE, "periodic": oracle.BC_PERIODIC, "cavity": oracle.BC_CAVITY}[bc]
     o = oracle.O2Sim(nx, ny, 1.6, code, 1.004, 1., 0.06, 1., mask=mask)
