@@ -232,6 +232,13 @@ class Simulation(object):
     def set_variant(self, variant):
         check(self._lib.lb_set_variant(self._h, int(variant)))
 
+    def steps_per_launch(self):
+        """2 when run() uses the two-steps-per-pass kernel for this grid/variant, else 1."""
+        n = self._lib.lb_steps_per_launch(self._h)
+        if n < 0:
+            check(n)
+        return n
+
     def layout(self):
         a, b, c = ct.c_int64(), ct.c_int64(), ct.c_int64()
         check(self._lib.lb_layout(self._h, ct.byref(a), ct.byref(b), ct.byref(c)))

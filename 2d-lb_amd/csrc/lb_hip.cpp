@@ -1341,6 +1341,12 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
 }
 
 // ---- measurement -------------------------------------------------------------------------
+int lb_steps_per_launch(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    return ((effective_variant(s) & 32) && step2_applicable(s)) ? 2 : 1;
+}
+
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");

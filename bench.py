@@ -68,14 +68,14 @@ def cpu_baseline(budget_s=12.0, n=4096):
                       "1 thread of %d available" % (sim.nx, sim.ny, steps, el, len(os.sched_getaffinity(0)))}
 
 
-def load_pmc_traffic(n_side):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary of this workload
-    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); None when absent."""
+def load_pmc_traffic(n_side, steps_per_launch=1):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
+    workload (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); None when absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        ent = d.get(str(n_side))
+        ent = d.get("%d/%d" % (n_side, steps_per_launch))
         return ent.get("hbm_bytes_per_launch") if ent else None
     except (OSError, ValueError):
         return None
@@ -159,10 +159,16 @@ def main():
     if rank == 0:
         cells = float(n) * n
         mlups = cells * args.steps / wall / 1e6
-        # dominant kernel = the fused step over this rank's rows; rank 0's slab is representative
-        launch_s = ev_ms / 1e3 / args.steps
-        bytes_per_launch = B_ALG * n * h
+        # dominant kernel = the fused step over this rank's rows; rank 0's slab is representative.
+        # One launch advances spl time steps (2 with the two-steps-per-pass kernel), i.e. it performs
+        # spl x n x h lattice updates = spl x 72 B x n x h algorithmic bytes.
+        spl = eng.steps_per_launch() if args.steps % 2 == 0 else 1
+        launches = args.steps // spl
+        launch_s = ev_ms / 1e3 / launches
+        bytes_per_launch = B_ALG * n * h * spl
         achieved = bytes_per_launch / launch_s / 1e9
+        kname = ("k_step2<PERIODIC> (two fused time steps per pass: pull-stream+collide twice, step-1 "
+                 "results in registers)" if spl == 2 else "k_step<PERIODIC> (fused pull-stream+collide)")
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",
@@ -176,9 +182,10 @@ def main():
                                                                     "" if world == 1 else ", halo via " + args.transport),
                        "grid": [n, n], "bytes_per_lattice_update": B_ALG},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(n) if world == 1 else None,
-                         "kernel": "k_step<PERIODIC> (fused pull-stream+collide), %d x %d cells per launch" % (n, h),
-                         "launch_ms": round(launch_s * 1e3, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(n, spl) if world == 1 else None,
+                         "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
+                         "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if copy_gbs is not None:
             line["copy_GBps"] = copy_gbs

@@ -144,6 +144,9 @@ int lb_timer_stop(lb_sim *s, float *elapsed_ms);
 /* Device layout facts for DESIGN.md / bench.py: pitch (floats), plane stride
  * (floats), bytes allocated. */
 int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated);
+/* Time steps advanced by one launch of the hot kernel in lb_run with the current variant:
+ * 2 when the two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch with it). */
+int lb_steps_per_launch(lb_sim *s);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
  * (which is scratch between steps).  *bytes_moved = bytes read + written.  Known traffic in the
  * fused kernel's access shape: corrects rocprofv3 FETCH_SIZE on gfx950 and gives the device's

@@ -21,7 +21,8 @@ def rows_of(pattern):
     files = glob.glob(pattern, recursive=True)
     if not files:
         raise SystemExit("no file matches " + pattern)
-    with open(files[0]) as fh:
+    files.sort(key=os.path.getmtime)
+    with open(files[-1]) as fh:            # newest, if an older run left files in the same directory
         return list(csv.DictReader(fh))
 
 
@@ -71,11 +72,12 @@ def main():
         f = st.mean(pmc[(k, "FETCH_SIZE")])
         w = st.mean(pmc[(k, "WRITE_SIZE")])
         rd, wr = f * 1024 * fetch_corr, w * 1024 * write_corr
-        macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, NTL, NTS, XCD>
-        alg = 72.0 * side * side + (12.0 * side * side if macro else 0.0)
+        macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS>
+        spl = 2 if k.startswith("k_step2") else 1       # time steps per launch
+        alg = 72.0 * side * side * spl + (12.0 * side * side if macro else 0.0)
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
         if not macro:
-            out = {"kernel": k, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
+            out["%d/%d" % (side, spl)] = {"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
                    "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
                    "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
@@ -86,7 +88,7 @@ def main():
     if os.path.exists(jpath):
         with open(jpath) as fh:
             allj = json.load(fh)
-    allj[str(side)] = out
+    allj.update(out)
     with open(jpath, "w") as fh:
         json.dump(allj, fh, indent=1, sort_keys=True)
     print("\n".join(lines))
