@@ -33,6 +33,15 @@ def _address(buf):
     return int(buf)
 
 
+def run_group(sims, num_iterations, wait=True):
+    """Advance slab handles that tile one grid on one device in lock step (lb_run_group)."""
+    arr = (ct.c_void_p * len(sims))(*[s._h for s in sims])
+    check(_native.lib().lb_run_group(arr, len(sims), int(num_iterations)))
+    if wait:
+        for s in sims:
+            s.sync()
+
+
 def comm_unique_id():
     """128-byte RCCL unique id (rank 0 creates it, the caller broadcasts it)."""
     uid = (ct.c_char * 128)()
@@ -69,6 +78,7 @@ class Simulation(object):
         p.nx, p.ny, p.y0, p.local_ny = self.nx, self.ny, self.y0, self.local_ny
         p.bc_mode, p.device = bc, self.device
         p.flags = _native.LB_FLAG_HALO if halo else 0
+        self._halo = bool(halo)
         p.omega = np.float32(omega)
         p.inlet_rho, p.outlet_rho = np.float32(inlet_rho), np.float32(outlet_rho)
         p.lid_u, p.rho0 = np.float32(lid_u), np.float32(rho0)
@@ -102,6 +112,9 @@ class Simulation(object):
             return
         m = _f_order(np.asarray(mask) != 0, self._shape2, np.int32)
         check(self._lib.lb_set_mask(self._h, m.ctypes.data))
+        if self._halo and self.local_ny == self.ny and self.bc_mode == _native.LB_BC_PERIODIC:
+            # a whole periodic grid run through the halo path is its own neighbour
+            self.set_obstacle_mask_halo(m[:, -1], m[:, 0])
 
     def set_fields(self, rho, u, v):
         """Upload the macroscopic fields (what init_hydro does, opencl_dim.py:291-293)."""
@@ -201,9 +214,21 @@ class Simulation(object):
     def step_finish(self):
         check(self._lib.lb_step_finish(self._h))
 
+    def halo_floats(self):
+        """Length of one halo buffer in floats (9 row segments of nx, two rows deep)."""
+        return 9 * self.nx
+
+    def set_obstacle_mask_halo(self, south_row=None, north_row=None):
+        """Mask rows of the neighbouring slabs adjacent to this one (each (nx,), non-zero = solid)."""
+        rows = []
+        for r in (south_row, north_row):
+            rows.append(None if r is None else np.ascontiguousarray((np.asarray(r) != 0).astype(np.int32)))
+        ptr = lambda a: None if a is None else a.ctypes.data
+        check(self._lib.lb_set_mask_halo(self._h, ptr(rows[0]), ptr(rows[1])))
+
     def halo_export(self, side, buf):
-        """Copy the 3 populations leaving through edge `side` (0 south, 1 north) into buf[3*nx]
-        (numpy float32 array or a raw host/device address)."""
+        """Copy the halo leaving through edge `side` (0 south, 1 north) into buf[9*nx]
+        (numpy float32 array or a raw host/device address); layout: include/lb_hip.h."""
         check(self._lib.lb_halo_export(self._h, int(side), _address(buf)))
 
     def halo_import(self, side, buf):

@@ -2,8 +2,10 @@
 
 The grid is cut along y (the slow axis of the device layout) into contiguous row slabs, one per
 GPU / process.  Streaming reaches one cell, so per step each slab needs from its neighbours only
-the three populations that cross the shared edge: k=2,5,6 travel north, k=4,7,8 travel south
-(3*nx floats per direction per step).  There is no collective on the data path.
+the populations that cross the shared edge (k=2,5,6 travel north, k=4,7,8 travel south).  The halo
+is kept two rows deep (9 row segments of nx floats per direction, include/lb_hip.h) so that the
+two-steps-per-pass kernel can run on slabs and exchange once per two steps.  There is no collective
+on the data path.
 
 * ``partition_rows`` / ``neighbours``  - the arithmetic.
 * ``LocalSlabRing``     - G slabs on ONE device, halos copied with lb_halo_export/import.  Used to
@@ -58,6 +60,14 @@ class _SlabSet(object):
     def _cut(self, a, y0, h):
         return np.asfortranarray(np.asarray(a)[:, y0:y0 + h])
 
+    @staticmethod
+    def _mask_halo_rows(mask, y0, h, ny, periodic):
+        """Mask rows just below / above the slab [y0, y0+h) (None at a wall)."""
+        m = np.asarray(mask)
+        south = m[:, (y0 - 1) % ny] if (periodic or y0 > 0) else None
+        north = m[:, (y0 + h) % ny] if (periodic or y0 + h < ny) else None
+        return south, north
+
 
 class LocalSlabRing(_SlabSet):
     """G virtual slabs on one device.  Not a performance path: it exists so that
@@ -70,9 +80,12 @@ class LocalSlabRing(_SlabSet):
         self.slabs = []
         for (y0, h) in self.parts:
             m = None if obstacle_mask is None else self._cut(obstacle_mask, y0, h)
-            self.slabs.append(_default_engine(nx=nx, ny=ny, omega=omega, bc=bc, obstacle_mask=m,
-                                              device=device, y0=y0, local_ny=h, halo=True, **kw))
-        self._buf = np.zeros((len(self.slabs), 2, 3 * nx), np.float32)
+            eng = _default_engine(nx=nx, ny=ny, omega=omega, bc=bc, obstacle_mask=m,
+                                  device=device, y0=y0, local_ny=h, halo=True, **kw)
+            if obstacle_mask is not None:
+                eng.set_obstacle_mask_halo(*self._mask_halo_rows(obstacle_mask, y0, h, ny, self.periodic))
+            self.slabs.append(eng)
+        self._buf = np.zeros((len(self.slabs), 2, 9 * nx), np.float32)
         self._ghosts_valid = False
 
     def set_f(self, f):
@@ -95,6 +108,17 @@ class LocalSlabRing(_SlabSet):
                 s.halo_import(NORTH, self._buf[north, SOUTH])
         for s in self.slabs:
             s.sync()
+
+    def run_in_library(self, n):
+        """The same slabs advanced by lb_run_group: the multi-GPU schedule (edge bands first, two-step
+        kernel where applicable, halo copies on a side stream) with device-to-device copies."""
+        from .simulation import run_group
+        run_group(self.slabs, n)
+        self._ghosts_valid = False      # lb_run_group refreshes the ghosts itself
+
+    def set_variant(self, variant):
+        for s in self.slabs:
+            s.set_variant(variant)
 
     def run(self, n):
         if not self._ghosts_valid:
@@ -138,6 +162,8 @@ class DistributedSlab(_SlabSet):
             device = int(os.environ.get("LOCAL_RANK", "0")) if engine_factory is None else 0
         self.engine = make(nx=nx, ny=ny, omega=omega, bc=bc, obstacle_mask=m, device=device,
                            y0=self.y0, local_ny=self.h, halo=True, **kw)
+        if obstacle_mask is not None and hasattr(self.engine, "set_obstacle_mask_halo"):
+            self.engine.set_obstacle_mask_halo(*self._mask_halo_rows(obstacle_mask, self.y0, self.h, ny, self.periodic))
         self._ghosts_valid = False
         self._bufs = None
         if transport == "rccl":
@@ -171,7 +197,7 @@ class DistributedSlab(_SlabSet):
                 torch.cuda.set_device(dev)
                 # one stream for kernels, halo copies and torch's collectives' stream dependencies
                 self.engine.use_stream(torch.cuda.current_stream().cuda_stream)
-            mk = lambda: torch.zeros(3 * self.nx, dtype=torch.float32, device=dev)
+            mk = lambda: torch.zeros(9 * self.nx, dtype=torch.float32, device=dev)
             self._bufs = {"send_s": mk(), "send_n": mk(), "recv_s": mk(), "recv_n": mk(), "gpu": on_gpu}
         return self._bufs
 

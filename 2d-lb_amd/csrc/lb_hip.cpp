@@ -11,9 +11,9 @@
 //                                 323-327, 395-407) and the per-step launch sequence of run() (:372-387)
 //
 // Device layout: structure of arrays, nine planes per lattice, two lattices
-// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -1 and H
-// are ghost rows (slab halo / don't-care at walls), so element (k, x, y) of a slab of H rows lives at
-//   lattice + GUARD + k*plane + (y+1)*pitch + x .
+// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -2,-1 and
+// H,H+1 are ghost rows (slab halo, two deep for the two-step kernel / don't-care at walls), so element
+// (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+2)*pitch + x .
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
 // 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
 #include <hip/hip_runtime.h>
@@ -31,6 +31,7 @@
 
 namespace {
 
+constexpr int GHOST = 2;   // ghost rows below row 0 and above row H-1 of every plane
 constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (k_step2's edge strips
                            // read up to 4 cells before a row and 256 cells past its end)
 
@@ -72,6 +73,8 @@ struct StepArgs {
     int y0, h;             // slab origin / height
     int row_begin, row_step, row_count;  // local rows visited: row_begin + i*row_step, i < row_count
     int wrap_y;            // periodic in y inside one slab: wrap the source rows locally
+    int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
+    int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
     float omega, rho_in, rho_out, lid_u, rho0;
 };
 
@@ -370,32 +373,41 @@ __device__ __forceinline__ f4a from_right(f4a v)
     return f4a{v.y, v.z, v.w, x};
 }
 
-// Row r of step 1 for this lane: resolve the (wrapped) row indices and issue the 9 loads.  Returns
-// false when the row lies outside a non-periodic box (its values are never consumed un-overwritten).
+// Row r of step 1 for this lane: resolve the row indices and issue the 9 loads.  Rows -1 and H are
+// wrapped (whole periodic grid on this GPU), read from the ghost rows (slab with a neighbour on that
+// side: rows -2..H+1 hold valid halo data) or skipped: returns false when the row lies outside a wall
+// (its values are never consumed un-overwritten).
 template <int BC, bool MASK>
 __device__ __forceinline__ bool load_step1_row(const StepArgs &a, int x4, int r, f4a (&q)[9], uc4 &mk, int &rr)
 {
     rr = r;
-    if (BC == LB_BC_PERIODIC) rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
-    else if (r < 0 || r >= a.h) return false;
-    int ym = rr - 1, yp = rr + 1;
-    if (BC == LB_BC_PERIODIC) {
-        if (ym < 0) ym = a.h - 1;
-        if (yp >= a.h) yp = 0;
+    int ym = r - 1, yp = r + 1;
+    if (a.wrap_y) {
+        rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
+        ym = rr - 1 < 0 ? a.h - 1 : rr - 1;
+        yp = rr + 1 >= a.h ? 0 : rr + 1;
+    } else if (r < 0) {
+        if (!a.ghost_s) return false;
+    } else if (r >= a.h) {
+        if (!a.ghost_n) return false;
     }
     gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
     return true;
 }
 
+// Segment i of a launch covers output rows [row_begin + i*seg_stride, +seg_rows) clipped to row_end:
+// one contiguous range cut into equal shares (seg_stride == seg_rows), or the two 2-row edge bands
+// of a slab (seg_stride = H-2) that are computed first so their halo can travel early.
 template <int BC, bool MASK, bool MACRO, bool NTS>
-__global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows)
+__global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
     const int item = blockIdx.x * 4 + threadIdx.y;
     const int sx = item % strips, sy = item / strips;
-    const int ya = sy * seg_rows;
-    if (ya >= a.h) return;
-    const int yb = min(ya + seg_rows, a.h);
+    if (sy >= nsegs) return;
+    const int ya = a.row_begin + sy * a.seg_stride;
+    if (ya >= row_end) return;
+    const int yb = min(ya + seg_rows, row_end);
     const int xr = sx * STRIP_OUT - 4 + lane * 4;       // true x of my first cell; may lie outside the box
     int x4 = xr;                                        // x used for addressing
     if (BC == LB_BC_PERIODIC) x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? xr - a.nx : xr);
@@ -632,20 +644,20 @@ struct lb_sim {
     int stepping = 0;           // 1 between lb_step_boundary and lb_step_finish
     float *feq = nullptr;       // raw allocation, lazily created
     float *rho = nullptr, *u = nullptr, *v = nullptr;
-    uint8_t *mask_raw = nullptr, *mask = nullptr;   // mask = mask_raw + GUARD (k_step2 over-reads row ends)
+    uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2][pitch] + guards; mask -> row 0 (rows -1, H: halo)
     bool has_mask = false;
     int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
-    hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr, edge_stream = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
     int variant = -1;           // < 0: automatic (effective_variant)
     int64_t bytes = 0;
 
-    float *origin(int which) const { return lat[which] + GUARD + pitch; }   // plane 0, row 0, x 0
-    float *feq_origin() const { return feq + GUARD + pitch; }
+    float *origin(int which) const { return lat[which] + GUARD + GHOST * pitch; }   // plane 0, row 0, x 0
+    float *feq_origin() const { return feq + GUARD + GHOST * pitch; }
     bool multi_slab() const { return H != p.ny || (p.flags & LB_FLAG_HALO); }
 };
 
@@ -668,6 +680,10 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.nx = s->p.nx; a.ny = s->p.ny; a.y0 = s->p.y0; a.h = s->H;
     a.row_begin = row_begin; a.row_step = row_step; a.row_count = row_count;
     a.wrap_y = (s->p.bc_mode == LB_BC_PERIODIC && !s->multi_slab()) ? 1 : 0;
+    const bool periodic = (s->p.bc_mode == LB_BC_PERIODIC);
+    a.ghost_s = (s->multi_slab() && (periodic || s->p.y0 > 0)) ? 1 : 0;
+    a.ghost_n = (s->multi_slab() && (periodic || s->p.y0 + s->H < s->p.ny)) ? 1 : 0;
+    a.seg_stride = 0;
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     return a;
@@ -741,13 +757,14 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
     return LB_OK;
 }
 
-// Two fused time steps in one pass (k_step2); single-slab handles only.
+// Two fused time steps in one pass (k_step2).
 template <int BC>
-void launch_step2_bc(const lb_sim *s, const StepArgs &a, dim3 grid, int strips, int seg_rows, bool macro, bool nts)
+void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, dim3 grid, int strips, int seg_rows,
+                     int nsegs, int row_end, bool macro, bool nts)
 {
     const dim3 block(64, 4);
 #define LB_LAUNCH2(MASK, MACRO, NTS) \
-    hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, NTS>), grid, block, 0, s->stream, a, strips, seg_rows)
+    hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end)
     if (s->has_mask) {
         if (macro) { if (nts) LB_LAUNCH2(true, true, true); else LB_LAUNCH2(true, true, false); }
         else       { if (nts) LB_LAUNCH2(true, false, true); else LB_LAUNCH2(true, false, false); }
@@ -760,34 +777,48 @@ void launch_step2_bc(const lb_sim *s, const StepArgs &a, dim3 grid, int strips, 
 
 bool step2_applicable(const lb_sim *s)
 {
-    if (s->multi_slab()) return false;
-    if (s->p.nx < 512 || s->H < 64) return false;
+    if (s->p.nx < 512) return false;
+    if (s->H < (s->multi_slab() ? 16 : 64)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
 }
 
-int launch_step2(lb_sim *s, bool macro)
+// Output rows [row_begin, row_end) in `nsegs_fixed` segments of seg_rows_fixed rows spaced seg_stride
+// apart (edge bands), or -- nsegs_fixed == 0 -- cut into equal shares so that the launch is one
+// balanced round of resident waves (reserve = wave slots left to a concurrent edge launch).
+int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool macro, int nsegs_fixed = 0,
+                 int seg_rows_fixed = 0, int seg_stride = 0, int reserve = 0)
 {
-    const StepArgs a = step_args(s, 0, 1, s->H);
+    if (row_end <= row_begin) return LB_OK;
+    StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
     const int strips = (s->p.nx + STRIP_OUT - 1) / STRIP_OUT;
-    // one balanced round: as many wave-items as the chip holds at once (waves per CU from the
-    // kernel's register budget; tunable), each marching an equal share of the rows
-    int waves_per_cu = 8;
-    if (const char *e = getenv("LB_STEP2_WAVES_PER_CU")) waves_per_cu = atoi(e) > 0 ? atoi(e) : 8;
-    const int capacity = s->cu_count * waves_per_cu;
-    int segs = capacity / strips;
-    if (segs < 1) segs = 1;
-    int seg_rows = (s->H + segs - 1) / segs;
-    if (seg_rows < 16) seg_rows = 16;
-    segs = (s->H + seg_rows - 1) / seg_rows;
+    int segs, seg_rows;
+    if (nsegs_fixed > 0) {
+        segs = nsegs_fixed;
+        seg_rows = seg_rows_fixed;
+        a.seg_stride = seg_stride;
+    } else {
+        // as many wave-items as the chip holds at once (waves per CU from the kernel's register
+        // budget; tunable), each marching an equal share of the rows
+        int waves_per_cu = 8;
+        if (const char *e = getenv("LB_STEP2_WAVES_PER_CU")) waves_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+        const int capacity = s->cu_count * waves_per_cu - reserve;
+        const int rows = row_end - row_begin;
+        segs = capacity / strips;
+        if (segs < 1) segs = 1;
+        seg_rows = (rows + segs - 1) / segs;
+        if (seg_rows < 16) seg_rows = 16;
+        segs = (rows + seg_rows - 1) / seg_rows;
+        a.seg_stride = seg_rows;
+    }
     const int items = strips * segs;
     const dim3 grid((items + 3) / 4);
     const bool nts = (variant & 1) != 0;
     switch (s->p.bc_mode) {
-    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, a, grid, strips, seg_rows, macro, nts); break;
-    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, a, grid, strips, seg_rows, macro, nts); break;
-    default: launch_step2_bc<LB_BC_CAVITY>(s, a, grid, strips, seg_rows, macro, nts); break;
+    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts); break;
+    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts); break;
+    default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -837,9 +868,22 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
     return LB_OK;
 }
 
-// Halo rows travel as three contiguous nx-float segments per edge.
-const int K_UP[3] = {2, 5, 6};     // cy = +1: leave through the north edge, enter through the south ghost row
-const int K_DOWN[3] = {4, 7, 8};   // cy = -1
+// Halo of a slab edge: nine contiguous nx-float row segments ("plane-rows"), two rows deep, enough for
+// the two-step kernel (which recomputes step 1 of the neighbour's edge row) and a superset of what the
+// single-step kernel reads.  Entry i of the OUT table of one slab pairs with entry i of the IN table of
+// its neighbour.  Rows are relative: OUT north counts from row H (-1 = row H-1), IN north from row H.
+struct HaloSeg { int k, row; };
+const HaloSeg NORTH_OUT[9] = {{2, -2}, {5, -2}, {6, -2}, {0, -1}, {1, -1}, {3, -1}, {2, -1}, {5, -1}, {6, -1}};  // + H
+const HaloSeg SOUTH_IN[9]  = {{2, -2}, {5, -2}, {6, -2}, {0, -1}, {1, -1}, {3, -1}, {2, -1}, {5, -1}, {6, -1}};
+const HaloSeg SOUTH_OUT[9] = {{0, 0}, {1, 0}, {3, 0}, {4, 0}, {7, 0}, {8, 0}, {4, 1}, {7, 1}, {8, 1}};
+const HaloSeg NORTH_IN[9]  = {{0, 0}, {1, 0}, {3, 0}, {4, 0}, {7, 0}, {8, 0}, {4, 1}, {7, 1}, {8, 1}};          // + H
+constexpr int HALO_SEGS = 9;
+
+float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
+{
+    const long long row = (north ? s->H : 0) + h.row;
+    return s->origin(which) + h.k * s->plane + row * s->pitch;
+}
 
 int exchange_rccl(lb_sim *s, int which)
 {
@@ -847,26 +891,61 @@ int exchange_rccl(lb_sim *s, int which)
     const bool wrap = (s->p.bc_mode == LB_BC_PERIODIC);
     const int south = (s->rank > 0) ? s->rank - 1 : (wrap ? s->nranks - 1 : -1);
     const int north = (s->rank < s->nranks - 1) ? s->rank + 1 : (wrap ? 0 : -1);
-    float *o = s->origin(which);
     const size_t n = (size_t)s->p.nx;
     // Posting order matters when both neighbours are the same rank (2 ranks, or 1 rank talking
     // to itself, in a periodic box): sends go north-then-south, receives south-then-north, so the
     // n-th send to a peer always meets the n-th receive that peer posted for us.
     NCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < HALO_SEGS; ++i) {
         if (north >= 0)
-            NCCL_TRY(g_rccl.Send(o + K_UP[i] * s->plane + (long long)(s->H - 1) * s->pitch, n, ncclFloat, north,
-                                 s->comm, s->comm_stream));
+            NCCL_TRY(g_rccl.Send(halo_ptr(s, which, NORTH_OUT[i], true), n, ncclFloat, north, s->comm, s->comm_stream));
         if (south >= 0)
-            NCCL_TRY(g_rccl.Send(o + K_DOWN[i] * s->plane, n, ncclFloat, south, s->comm, s->comm_stream));
+            NCCL_TRY(g_rccl.Send(halo_ptr(s, which, SOUTH_OUT[i], false), n, ncclFloat, south, s->comm, s->comm_stream));
         if (south >= 0)
-            NCCL_TRY(g_rccl.Recv(o + K_UP[i] * s->plane - s->pitch, n, ncclFloat, south, s->comm,
-                                 s->comm_stream));
+            NCCL_TRY(g_rccl.Recv(halo_ptr(s, which, SOUTH_IN[i], false), n, ncclFloat, south, s->comm, s->comm_stream));
         if (north >= 0)
-            NCCL_TRY(g_rccl.Recv(o + K_DOWN[i] * s->plane + (long long)s->H * s->pitch, n, ncclFloat, north,
-                                 s->comm, s->comm_stream));
+            NCCL_TRY(g_rccl.Recv(halo_ptr(s, which, NORTH_IN[i], true), n, ncclFloat, north, s->comm, s->comm_stream));
     }
     NCCL_TRY(g_rccl.GroupEnd());
+    return LB_OK;
+}
+
+// One (single or double) time step of a slab, edge rows first.  Enqueues on the compute stream
+// (interior) and the edge stream (edge bands), records ev_boundary when the edge rows of the new
+// lattice are complete and ev_interior when the interior is.  The caller then moves the halo of
+// lattice cur^1 and makes both streams wait for it before the next step.
+int slab_step_launch(lb_sim *s, bool two, bool macro)
+{
+    int rc;
+    const int H = s->H;
+    if (two) {
+        const int strips = (s->p.nx + STRIP_OUT - 1) / STRIP_OUT;
+        // edge bands: output rows [0,2) and [H-2,H), one wave per strip and band
+        if ((rc = launch_step2(s, s->edge_stream, 0, H, macro, 2, 2, H - 2))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
+        if ((rc = launch_step2(s, s->stream, 2, H - 2, macro, 0, 0, 0, 2 * strips))) return rc;
+    } else {
+        // single step: the four rows the 2-deep halo is cut from (0, 1, H-2, H-1) first, then the rest
+        const hipStream_t keep = s->stream;
+        s->stream = s->edge_stream;
+        rc = launch_step(s, 0, H - 1, 2, macro);                 // rows 0 and H-1
+        if (!rc) rc = launch_step(s, 1, H - 3, 2, macro);        // rows 1 and H-2
+        s->stream = keep;
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
+        if ((rc = launch_step(s, 2, 1, H - 4, macro))) return rc;
+    }
+    HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
+    return LB_OK;
+}
+
+// Both compute streams wait for the other one's kernel and for the halo of the lattice just written.
+int slab_step_join(lb_sim *s)
+{
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+    HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
+    HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
     return LB_OK;
 }
 
@@ -910,7 +989,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->pitch = ((long long)p->nx + 63) / 64 * 64;
     long long skew = 0;
     if (const char *e = getenv("LB_PLANE_SKEW")) skew = atoll(e) * 64;
-    s->plane = (long long)(s->H + 2) * s->pitch + skew;
+    s->plane = (long long)(s->H + 2 * GHOST) * s->pitch + skew;
     s->lat_floats = 9 * s->plane + 2 * GUARD;
     if (const char *e = getenv("LB_VARIANT")) s->variant = atoi(e);
     {
@@ -931,8 +1010,14 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
     CREATE_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // edge bands and halo first: highest priority the device offers
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, hi));
+    }
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming));
     CREATE_TRY(hipEventCreate(&s->ev_t0));
     CREATE_TRY(hipEventCreate(&s->ev_t1));
     const size_t lat_bytes = sizeof(float) * s->lat_floats;
@@ -944,12 +1029,12 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipMalloc(&s->rho, fld_bytes));
     CREATE_TRY(hipMalloc(&s->u, fld_bytes));
     CREATE_TRY(hipMalloc(&s->v, fld_bytes));
-    CREATE_TRY(hipMalloc(&s->mask_raw, (size_t)s->pitch * s->H + 2 * GUARD));
-    s->mask = s->mask_raw + GUARD;
+    CREATE_TRY(hipMalloc(&s->mask_raw, (size_t)s->pitch * (s->H + 2) + 2 * GUARD));
+    s->mask = s->mask_raw + GUARD + s->pitch;
     CREATE_TRY(hipMemsetAsync(s->rho, 0, fld_bytes, s->stream));
     CREATE_TRY(hipMemsetAsync(s->u, 0, fld_bytes, s->stream));
     CREATE_TRY(hipMemsetAsync(s->v, 0, fld_bytes, s->stream));
-    CREATE_TRY(hipMemsetAsync(s->mask_raw, 0, (size_t)s->pitch * s->H + 2 * GUARD, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->mask_raw, 0, (size_t)s->pitch * (s->H + 2) + 2 * GUARD, s->stream));
     CREATE_TRY(hipStreamSynchronize(s->stream));
 #undef CREATE_TRY
     s->bytes = 2 * lat_bytes + 3 * fld_bytes + (size_t)s->pitch * s->H;
@@ -963,14 +1048,16 @@ int lb_destroy(lb_sim *s)
     DeviceGuard guard(s->p.device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
-    for (hipEvent_t e : {s->ev_boundary, s->ev_halo, s->ev_t0, s->ev_t1})
+    for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_t0, s->ev_t1})
         if (e) (void)hipEventDestroy(e);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+    if (s->edge_stream) (void)hipStreamDestroy(s->edge_stream);
     delete s;
     return LB_OK;
 }
@@ -981,6 +1068,7 @@ int lb_sync(lb_sim *s)
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipStreamSynchronize(s->comm_stream));
+    HIP_TRY(hipStreamSynchronize(s->edge_stream));
     return LB_OK;
 }
 
@@ -1106,6 +1194,28 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     // mask: keep the flag (kernel choice is per handle, results are identical either way).
     (void)any;
     s->has_mask = true;
+    return LB_OK;
+}
+
+int lb_set_mask_halo(lb_sim *s, const int32_t *south_row, const int32_t *north_row)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    uint8_t *tmp = (uint8_t *)calloc((size_t)s->pitch, 1);
+    if (!tmp) return fail(LB_ERR_ARG, "out of host memory");
+    const int32_t *rows[2] = {south_row, north_row};
+    uint8_t *dst[2] = {s->mask - s->pitch, s->mask + (size_t)s->H * s->pitch};
+    for (int side = 0; side < 2; ++side) {
+        memset(tmp, 0, (size_t)s->pitch);
+        if (rows[side])
+            for (int x = 0; x < s->p.nx; ++x) tmp[x] = rows[side][x] == 1;
+        hipError_t e = hipMemcpy(dst[side], tmp, (size_t)s->pitch, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free(tmp);
+            return fail(LB_ERR_HIP, "mask halo upload: %s", hipGetErrorString(e));
+        }
+    }
+    free(tmp);
     return LB_OK;
 }
 
@@ -1236,10 +1346,9 @@ int lb_halo_export(lb_sim *s, int side, void *buf)
     if (!s || !buf || side < 0 || side > 1) return fail(LB_ERR_ARG, "bad argument");
     DeviceGuard guard(s->p.device);
     const int which = s->stepping ? (s->cur ^ 1) : s->cur;
-    const int *ks = side ? K_UP : K_DOWN;
-    const long long row = side ? (long long)(s->H - 1) * s->pitch : 0;
-    for (int i = 0; i < 3; ++i)
-        HIP_TRY(hipMemcpyAsync((float *)buf + (size_t)i * s->p.nx, s->origin(which) + ks[i] * s->plane + row,
+    const HaloSeg *tab = side ? NORTH_OUT : SOUTH_OUT;
+    for (int i = 0; i < HALO_SEGS; ++i)
+        HIP_TRY(hipMemcpyAsync((float *)buf + (size_t)i * s->p.nx, halo_ptr(s, which, tab[i], side != 0),
                                sizeof(float) * s->p.nx, hipMemcpyDefault, s->stream));
     return LB_OK;
 }
@@ -1249,12 +1358,17 @@ int lb_halo_import(lb_sim *s, int side, const void *buf)
     if (!s || !buf || side < 0 || side > 1) return fail(LB_ERR_ARG, "bad argument");
     DeviceGuard guard(s->p.device);
     const int which = s->stepping ? (s->cur ^ 1) : s->cur;
-    const int *ks = side ? K_DOWN : K_UP;
-    const long long row = side ? (long long)s->H * s->pitch : -s->pitch;
-    for (int i = 0; i < 3; ++i)
-        HIP_TRY(hipMemcpyAsync(s->origin(which) + ks[i] * s->plane + row, (const float *)buf + (size_t)i * s->p.nx,
+    const HaloSeg *tab = side ? NORTH_IN : SOUTH_IN;
+    for (int i = 0; i < HALO_SEGS; ++i)
+        HIP_TRY(hipMemcpyAsync(halo_ptr(s, which, tab[i], side != 0), (const float *)buf + (size_t)i * s->p.nx,
                                sizeof(float) * s->p.nx, hipMemcpyDefault, s->stream));
     return LB_OK;
+}
+
+int lb_halo_floats(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    return HALO_SEGS * s->p.nx;
 }
 
 int lb_run(lb_sim *s, int n_steps)
@@ -1273,7 +1387,7 @@ int lb_run(lb_sim *s, int n_steps)
             it = 1;
         }
         for (; it < n_steps; it += two ? 2 : 1) {
-            if (two) rc = launch_step2(s, it + 2 >= n_steps);
+            if (two) rc = launch_step2(s, s->stream, 0, s->H, it + 2 >= n_steps);
             else rc = launch_step(s, 0, 1, s->H, it == n_steps - 1);
             if (rc) return rc;
             s->cur ^= 1;
@@ -1284,31 +1398,117 @@ int lb_run(lb_sim *s, int n_steps)
     if (!s->comm)
         return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
     if (n_steps == 0) return LB_OK;
+    if (s->H < 4) return fail(LB_ERR_ARG, "a slab needs at least 4 rows (has %d)", s->H);
+    // everything enqueued so far on the compute stream happens before the first edge launch
+    HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     if (!s->ghosts_valid) {
         // ghost rows of the current lattice: exchange once before the first step
-        HIP_TRY(hipEventRecord(s->ev_boundary, s->stream));
-        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
+        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_interior, 0));
         if ((rc = exchange_rccl(s, s->cur))) return rc;
         HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
         HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+        HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
     }
-    for (int it = 0; it < n_steps; ++it) {
-        const bool macro = (it == n_steps - 1);
-        // 1. edge rows first, so their halo can travel while the interior is computed
-        if ((rc = launch_step(s, 0, s->H > 1 ? s->H - 1 : 1, s->H > 1 ? 2 : 1, macro))) return rc;
-        HIP_TRY(hipEventRecord(s->ev_boundary, s->stream));
-        // 2. interior rows on the compute stream
-        if ((rc = launch_step(s, 1, 1, s->H - 2, macro))) return rc;
-        // 3. halo of the lattice just written, on the communication stream (RCCL over xGMI)
+    const bool two = (effective_variant(s) & 32) && step2_applicable(s);
+    for (int it = 0; it < n_steps;) {
+        const bool dbl = two && (n_steps - it) >= 2 && ((n_steps - it) % 2 == 0);   // odd count: single step first
+        const int adv = dbl ? 2 : 1;
+        // 1. edge rows (edge stream) and interior rows (compute stream) of the new lattice, concurrently
+        if ((rc = slab_step_launch(s, dbl, it + adv >= n_steps))) return rc;
+        // 2. halo of the lattice just written, on the communication stream (RCCL over xGMI), as soon as
+        //    the edge rows are done and while the interior is still being computed
         HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
         if ((rc = exchange_rccl(s, s->cur ^ 1))) return rc;
         HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
-        // 4. the next step reads the new lattice: wait for its ghost rows
-        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+        // 3. the next step reads the new lattice: both compute streams wait for kernels and halo
+        if ((rc = slab_step_join(s))) return rc;
         s->cur ^= 1;
+        it += adv;
     }
     s->ghosts_valid = true;
     s->feq_valid = false;
+    return LB_OK;
+}
+
+// Virtual slabs: `count` slab handles that together tile one grid (handle i = slab i, south to north),
+// all on one device, advanced in lock step with device-to-device halo copies.  Same kernels, same
+// schedule and same halo tables as the RCCL path; exists so that the slab code can be verified
+// bitwise against the undivided run on a single GPU.
+int lb_run_group(lb_sim **sims, int count, int n_steps)
+{
+    if (!sims || count < 1 || n_steps < 0) return fail(LB_ERR_ARG, "bad argument");
+    for (int i = 0; i < count; ++i) {
+        if (!sims[i]) return fail(LB_ERR_ARG, "null handle in group");
+        if (!sims[i]->multi_slab()) return fail(LB_ERR_ARG, "group members must be slab handles (LB_FLAG_HALO)");
+        if (sims[i]->p.device != sims[0]->p.device) return fail(LB_ERR_ARG, "group members must share a device");
+        if (sims[i]->stepping) return fail(LB_ERR_STATE, "lb_run_group inside a split step");
+        if (sims[i]->H < 4) return fail(LB_ERR_ARG, "a slab needs at least 4 rows");
+    }
+    if (n_steps == 0) return LB_OK;
+    DeviceGuard guard(sims[0]->p.device);
+    const bool wrap = (sims[0]->p.bc_mode == LB_BC_PERIODIC);
+    int rc;
+    // halo of lattice `rel` (0 = current, 1 = the one being written) of every member, receiver-driven:
+    // after the sender's edge rows are complete, copy them into my ghost rows on my comm stream
+    auto exchange = [&](int rel, bool wait_edges) -> int {
+        for (int i = 0; i < count; ++i) {
+            lb_sim *me = sims[i];
+            const int south = i > 0 ? i - 1 : (wrap ? count - 1 : -1);
+            const int north = i < count - 1 ? i + 1 : (wrap ? 0 : -1);
+            for (int side = 0; side < 2; ++side) {
+                const int nb = side ? north : south;
+                if (nb < 0) continue;
+                lb_sim *from = sims[nb];
+                HIP_TRY(hipStreamWaitEvent(me->comm_stream, wait_edges ? from->ev_boundary : from->ev_interior, 0));
+                if (wait_edges) HIP_TRY(hipStreamWaitEvent(me->comm_stream, me->ev_boundary, 0));
+                const HaloSeg *out = side ? SOUTH_OUT : NORTH_OUT;   // my north ghosts <- its south edge
+                const HaloSeg *in = side ? NORTH_IN : SOUTH_IN;
+                for (int k = 0; k < HALO_SEGS; ++k)
+                    HIP_TRY(hipMemcpyAsync(halo_ptr(me, me->cur ^ rel, in[k], side != 0),
+                                           halo_ptr(from, from->cur ^ rel, out[k], side == 0),
+                                           sizeof(float) * me->p.nx, hipMemcpyDeviceToDevice, me->comm_stream));
+            }
+            HIP_TRY(hipEventRecord(me->ev_halo, me->comm_stream));
+        }
+        return LB_OK;
+    };
+    for (int i = 0; i < count; ++i) {
+        HIP_TRY(hipEventRecord(sims[i]->ev_interior, sims[i]->stream));
+        HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_interior, 0));
+    }
+    if ((rc = exchange(0, false))) return rc;
+    for (int i = 0; i < count; ++i) {
+        HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_halo, 0));
+        HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_halo, 0));
+    }
+    bool two = true;
+    for (int i = 0; i < count; ++i) two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i]);
+    for (int it = 0; it < n_steps;) {
+        const bool dbl = two && (n_steps - it) >= 2 && ((n_steps - it) % 2 == 0);
+        const int adv = dbl ? 2 : 1;
+        for (int i = 0; i < count; ++i)
+            if ((rc = slab_step_launch(sims[i], dbl, it + adv >= n_steps))) return rc;
+        if ((rc = exchange(1, true))) return rc;
+        for (int i = 0; i < count; ++i) {
+            if ((rc = slab_step_join(sims[i]))) return rc;
+            // a neighbour's next launch overwrites the lattice my comm stream may still be reading
+            // from (its old lattice): make every member wait for every halo copy that reads it
+            const int south = i > 0 ? i - 1 : (wrap ? count - 1 : -1);
+            const int north = i < count - 1 ? i + 1 : (wrap ? 0 : -1);
+            for (int nb : {south, north}) {
+                if (nb < 0) continue;
+                HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[nb]->ev_halo, 0));
+                HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[nb]->ev_halo, 0));
+            }
+        }
+        for (int i = 0; i < count; ++i) sims[i]->cur ^= 1;
+        it += adv;
+    }
+    for (int i = 0; i < count; ++i) {
+        sims[i]->ghosts_valid = true;
+        sims[i]->feq_valid = false;
+    }
     return LB_OK;
 }
 

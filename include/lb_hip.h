@@ -120,15 +120,24 @@ int lb_run(lb_sim *s, int n_steps);
 int lb_step_boundary(lb_sim *s, int write_macro);
 int lb_step_interior(lb_sim *s, int write_macro);
 int lb_step_finish(lb_sim *s);
-/* Halo rows of the lattice that the NEXT step will read (= the one being
- * written between lb_step_boundary and lb_step_finish, the current one
- * otherwise).  side 0 = south edge, 1 = north edge.  export: the three
- * populations leaving through that edge (south: k=4,7,8 of row 0; north:
- * k=2,5,6 of row H-1) -> buf[3][nx].  import: the three populations entering
- * through that edge (south ghost row -1: k=2,5,6; north ghost row H: k=4,7,8)
- * <- buf[3][nx].  buf may be host or device memory (hipMemcpyDefault). */
+/* Halo rows of the lattice that the NEXT step will read (= the one being written between
+ * lb_step_boundary and lb_step_finish, the current one otherwise).  side 0 = south edge, 1 = north
+ * edge.  A halo is lb_halo_floats() = 9*nx floats: nine row segments, two rows deep (what the
+ * two-step kernel needs; a superset of what the single-step kernel reads):
+ *   north edge out / south ghost in: row H-2 (resp. -2): k=2,5,6; row H-1 (resp. -1): k=0,1,3,2,5,6
+ *   south edge out / north ghost in: row 0 (resp. H): k=0,1,3,4,7,8; row 1 (resp. H+1): k=4,7,8
+ * export copies the edge rows into buf, import copies buf into the ghost rows; the buffer a slab
+ * exports on its north side is what its northern neighbour imports on its south side.  buf may be
+ * host or device memory (hipMemcpyDefault). */
+int lb_halo_floats(lb_sim *s);
 int lb_halo_export(lb_sim *s, int side, void *buf);
 int lb_halo_import(lb_sim *s, int side, const void *buf);
+/* Obstacle-mask rows of the neighbouring slabs adjacent to this one ([nx] int32 each, NULL = no
+ * solid cells): the two-step kernel recomputes the neighbours' edge rows and needs their masks. */
+int lb_set_mask_halo(lb_sim *s, const int32_t *south_row, const int32_t *north_row);
+/* Advance `count` slab handles that tile one grid on ONE device in lock step, moving halos with
+ * device-to-device copies: the multi-GPU schedule and kernels without a second GPU (verification). */
+int lb_run_group(lb_sim **sims, int count, int n_steps);
 
 /* RCCL point-to-point halo exchange over xGMI, one rank per GPU.  Rank r owns
  * slab r; neighbours are r-1 (south) and r+1 (north), wrapping for PERIODIC.

@@ -217,6 +217,60 @@ def test_virtual_slabs_equal_single_slab_bitwise(lbhip, bc, nslabs):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs):
+    """lb_run_group = the multi-GPU schedule (edge bands on a priority stream, interior on the compute
+    stream, 2-deep halo copies on the communication stream, k_step2 on slabs) with device-to-device
+    copies instead of RCCL.  Must equal the undivided run bit for bit, for odd and even step counts."""
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.slabs import LocalSlabRing
+    nx, ny = 1000, 131
+    rng = np.random.default_rng(17)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.03
+    mask[0, :] = mask[-1, :] = False
+    if bc != "periodic":
+        mask[:, 0] = mask[:, -1] = False
+    kw = dict(inlet_rho=1.006, lid_u=0.05)
+    one = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, **kw)
+    one.set_variant(0)
+    one.set_f(f0)
+    for variant in (33, 1):                       # two-step on slabs / single-step on slabs
+        ring = LocalSlabRing(nx, ny, 1.55, nslabs, bc=bc, obstacle_mask=mask, **kw)
+        ring.set_variant(variant)
+        ring.set_f(f0)
+        ring.run_in_library(7)
+        ring.run_in_library(4)
+        if variant == 33:
+            one.run(11)
+        a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (variant, k)
+
+
+def test_rccl_self_ring_two_step_with_mask(lbhip):
+    """1-rank periodic ring over RCCL with the two-step slab kernel and an obstacle mask."""
+    from LB_D2Q9.simulation import Simulation, comm_unique_id
+    nx, ny = 1024, 96
+    rng = np.random.default_rng(23)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.02
+    one = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask)
+    one.set_variant(0)
+    one.set_f(f0)
+    one.run(9)
+    two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
+    two.set_variant(33)
+    two.comm_init(comm_unique_id(), 0, 1)
+    two.set_f(f0)
+    two.run(5)
+    two.run(4)
+    a, b = one.get_fields(("f", "rho", "u", "v")), two.get_fields(("f", "rho", "u", "v"))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_rccl_self_exchange_single_rank(lbhip):
     """One rank, periodic box split as a 'slab' talking to itself over RCCL: exercises
     lb_comm_init + the in-run exchange path on a single GPU."""
