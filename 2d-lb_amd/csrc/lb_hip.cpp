@@ -584,6 +584,38 @@ __global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
     if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
 }
 
+// Halo pack / unpack: the 2-deep halo of one edge is nine row segments scattered over the planes
+// (HaloSeg tables on the host side).  One tiny kernel gathers both edges into two contiguous buffers
+// (so that an exchange is one send + one receive per neighbour instead of nine), one scatters the
+// received buffers into the ghost rows.  Table t: 0 north-out, 1 south-out, 2 south-in, 3 north-in;
+// rows of the north tables count from row H.
+__device__ __constant__ int d_halo_k[4][9] = {{2, 5, 6, 0, 1, 3, 2, 5, 6}, {0, 1, 3, 4, 7, 8, 4, 7, 8},
+                                              {2, 5, 6, 0, 1, 3, 2, 5, 6}, {0, 1, 3, 4, 7, 8, 4, 7, 8}};
+__device__ __constant__ int d_halo_row[4][9] = {{-2, -2, -2, -1, -1, -1, -1, -1, -1}, {0, 0, 0, 0, 0, 0, 1, 1, 1},
+                                                {-2, -2, -2, -1, -1, -1, -1, -1, -1}, {0, 0, 0, 0, 0, 0, 1, 1, 1}};
+
+__global__ void k_halo_pack(const float *origin, long long plane, int pitch, int h, int nx, float *buf_n, float *buf_s)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
+    if (x >= nx) return;
+    float *buf = north ? buf_n : buf_s;
+    if (!buf) return;
+    const int t = north ? 0 : 1;
+    const long long row = (north ? h : 0) + d_halo_row[t][seg];
+    buf[(long long)seg * nx + x] = origin[d_halo_k[t][seg] * plane + row * pitch + x];
+}
+
+__global__ void k_halo_unpack(float *origin, long long plane, int pitch, int h, int nx, const float *buf_s, const float *buf_n)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
+    if (x >= nx) return;
+    const float *buf = north ? buf_n : buf_s;
+    if (!buf) return;
+    const int t = north ? 3 : 2;
+    const long long row = (north ? h : 0) + d_halo_row[t][seg];
+    origin[d_halo_k[t][seg] * plane + row * pitch + x] = buf[(long long)seg * nx + x];
+}
+
 // ------------------------------------------------------------------------------------------
 //  RCCL, loaded lazily so that single-GPU use never touches librccl
 // ------------------------------------------------------------------------------------------
@@ -652,6 +684,7 @@ struct lb_sim {
     hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    float *halo_buf = nullptr;  // 4 x 9*nx floats: send north, send south, recv south, recv north
     bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
     int variant = -1;           // < 0: automatic (effective_variant)
     int64_t bytes = 0;
@@ -891,22 +924,24 @@ int exchange_rccl(lb_sim *s, int which)
     const bool wrap = (s->p.bc_mode == LB_BC_PERIODIC);
     const int south = (s->rank > 0) ? s->rank - 1 : (wrap ? s->nranks - 1 : -1);
     const int north = (s->rank < s->nranks - 1) ? s->rank + 1 : (wrap ? 0 : -1);
-    const size_t n = (size_t)s->p.nx;
-    // Posting order matters when both neighbours are the same rank (2 ranks, or 1 rank talking
-    // to itself, in a periodic box): sends go north-then-south, receives south-then-north, so the
-    // n-th send to a peer always meets the n-th receive that peer posted for us.
+    const size_t n = (size_t)HALO_SEGS * s->p.nx;
+    float *send_n = s->halo_buf, *send_s = s->halo_buf + n, *recv_s = s->halo_buf + 2 * n, *recv_n = s->halo_buf + 3 * n;
+    const dim3 grid((s->p.nx + 255) / 256, HALO_SEGS, 2);
+    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, s->comm_stream, s->origin(which), s->plane, (int)s->pitch,
+                       s->H, s->p.nx, north >= 0 ? send_n : nullptr, south >= 0 ? send_s : nullptr);
+    HIP_TRY(hipGetLastError());
+    // One send and one receive per neighbour.  Posting order matters when both neighbours are the same
+    // rank (2 ranks, or 1 rank talking to itself, in a periodic box): sends go north-then-south,
+    // receives south-then-north, so the n-th send to a peer meets the n-th receive it posted for us.
     NCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < HALO_SEGS; ++i) {
-        if (north >= 0)
-            NCCL_TRY(g_rccl.Send(halo_ptr(s, which, NORTH_OUT[i], true), n, ncclFloat, north, s->comm, s->comm_stream));
-        if (south >= 0)
-            NCCL_TRY(g_rccl.Send(halo_ptr(s, which, SOUTH_OUT[i], false), n, ncclFloat, south, s->comm, s->comm_stream));
-        if (south >= 0)
-            NCCL_TRY(g_rccl.Recv(halo_ptr(s, which, SOUTH_IN[i], false), n, ncclFloat, south, s->comm, s->comm_stream));
-        if (north >= 0)
-            NCCL_TRY(g_rccl.Recv(halo_ptr(s, which, NORTH_IN[i], true), n, ncclFloat, north, s->comm, s->comm_stream));
-    }
+    if (north >= 0) NCCL_TRY(g_rccl.Send(send_n, n, ncclFloat, north, s->comm, s->comm_stream));
+    if (south >= 0) NCCL_TRY(g_rccl.Send(send_s, n, ncclFloat, south, s->comm, s->comm_stream));
+    if (south >= 0) NCCL_TRY(g_rccl.Recv(recv_s, n, ncclFloat, south, s->comm, s->comm_stream));
+    if (north >= 0) NCCL_TRY(g_rccl.Recv(recv_n, n, ncclFloat, north, s->comm, s->comm_stream));
     NCCL_TRY(g_rccl.GroupEnd());
+    hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, s->comm_stream, s->origin(which), s->plane, (int)s->pitch,
+                       s->H, s->p.nx, south >= 0 ? recv_s : nullptr, north >= 0 ? recv_n : nullptr);
+    HIP_TRY(hipGetLastError());
     return LB_OK;
 }
 
@@ -1050,7 +1085,7 @@ int lb_destroy(lb_sim *s)
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v})
+    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
     for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_t0, s->ev_t1})
@@ -1533,6 +1568,10 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
     DeviceGuard guard(s->p.device);
     ncclUniqueId id;
     memcpy(&id, unique_id_128, sizeof(id));
+    if (!s->halo_buf) {
+        HIP_TRY(hipMalloc(&s->halo_buf, sizeof(float) * 4 * HALO_SEGS * s->p.nx));
+        s->bytes += sizeof(float) * 4 * HALO_SEGS * s->p.nx;
+    }
     NCCL_TRY(g_rccl.CommInitRank(&s->comm, nranks, id, rank));
     s->rank = rank;
     s->nranks = nranks;

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""One-GPU proxy for the per-GPU work of an N-GPU strong-scaling run: a periodic (nx x ny/N) grid
+run (a) as a plain whole-grid handle and (b) through the slab path as a 1-rank RCCL ring that sends
+its halo to itself (edge bands first, exchange on the communication stream, two-step kernel).
+Prints MLUPS for both; N x (b) is what N GPUs could reach if peer exchange costs what self exchange does."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=8192)
+    ap.add_argument("--parts", default="1,2,4,8")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--variants", default="-1,9")
+    args = ap.parse_args()
+    from LB_D2Q9.simulation import Simulation, comm_unique_id
+    from bench import shear_layer
+    for parts in [int(p) for p in args.parts.split(",")]:
+        ny = args.nx // parts
+        for variant in [int(v) for v in args.variants.split(",")]:
+            res = {}
+            for mode in ("plain", "slab+rccl-self"):
+                sim = Simulation(args.nx, ny, 1.7, bc="periodic", halo=(mode != "plain"))
+                if variant >= 0:
+                    sim.set_variant(variant)
+                if mode != "plain":
+                    sim.comm_init(comm_unique_id(), 0, 1)
+                sim.init_equilibrium(*shear_layer(args.nx, ny, 0, ny))
+                sim.run(10)
+                best = 0.0
+                host = 1e9
+                for _ in range(3):
+                    import time
+                    t0 = time.perf_counter()
+                    sim.run(args.steps, wait=False)      # host enqueue time only
+                    host = min(host, (time.perf_counter() - t0) / args.steps * 1e6)
+                    sim.sync()
+                    ms = sim.timed_run(args.steps)
+                    sim.sync()
+                    best = max(best, args.nx * ny * args.steps / (ms * 1e-3) / 1e6)
+                res[mode] = best
+                res[mode + "_host_us"] = host
+                sim.close()
+            print("grid %5d x %5d (1/%d of %d^2) variant %3d: plain %9.1f MLUPS, slab path %9.1f MLUPS "
+                  "(%.0f us/step GPU, %.0f us/step host enqueue) -> x%d = %9.1f"
+                  % (args.nx, ny, parts, args.nx, variant, res["plain"], res["slab+rccl-self"],
+                     args.nx * ny / res["slab+rccl-self"], res["slab+rccl-self_host_us"], parts,
+                     parts * res["slab+rccl-self"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
