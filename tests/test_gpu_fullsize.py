@@ -1,0 +1,135 @@
+"""BASELINE.json's configurations at their full sizes on the GPU.  Where the oracle finishes in
+seconds (<= 4096^2, a few steps) the comparison is direct; beyond that the checks are size-independent
+properties of the lattice-Boltzmann step (exact x-periodicity of a periodic initial state, mass drift,
+partition independence)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_gpu_parity import TOL1, assert_fields_close, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def equilibrium(rho, u, v):
+    """f = feq(rho, u, v) in float64 -> float32, (nx, ny, 9) F-ordered."""
+    w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+    cx = np.array([0, 1, 0, -1, 0, 1, -1, -1, 1])
+    cy = np.array([0, 0, 1, 0, -1, 1, 1, -1, -1])
+    f = np.empty(rho.shape + (9,), np.float32, order="F")
+    usq = u.astype(np.float64) ** 2 + v.astype(np.float64) ** 2
+    for k in range(9):
+        cu = cx[k] * u.astype(np.float64) + cy[k] * v.astype(np.float64)
+        f[..., k] = w[k] * rho * (1 + 3 * cu + 4.5 * cu * cu - 1.5 * usq)
+    return f
+
+
+def test_config2_lid_driven_cavity_1024_vs_oracle(lbhip, oracle):
+    """1024x1024 lid-driven cavity, Re = U L / nu = 1000 with U = 0.1: omega = 1/(3 nu + 1/2)."""
+    from LB_D2Q9.simulation import Simulation
+    n, U = 1024, 0.1
+    nu = U * (n - 1) / 1000.
+    omega = 1. / (3 * nu + 0.5)
+    assert omega == pytest.approx(1.2393, abs=1e-3)
+    rng = np.random.default_rng(2)
+    f0 = equilibrium(np.ones((n, n)), 1e-3 * rng.standard_normal((n, n)), 1e-3 * rng.standard_normal((n, n)))
+    sim = Simulation(n, n, omega, bc="cavity", lid_u=U, rho0=1.)
+    ref = oracle.O2Sim(n, n, omega, oracle.BC_CAVITY, lid_u=U, rho0=1.)
+    sim.set_f(f0); ref.set_f(f0)
+    sim.run(1); ref.run(1)
+    assert_fields_close(sim.get_fields(("f", "rho", "u", "v")), ref.get_fields(), dict(f=2.5e-7, rho=5e-7, u=1e-6, v=1e-6))
+    sim.run(19); ref.run(19)
+    g, w = sim.get_fields(("f", "rho", "u", "v")), ref.get_fields()
+    assert_fields_close(g, w, dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
+    assert g["u"][n // 2, -1] > 0.05          # the lid drags the top row along
+
+
+@pytest.mark.parametrize("variant", [9, 33])
+def test_config3_kelvin_helmholtz_4096_vs_oracle(lbhip, oracle, variant):
+    """4096x4096 periodic double shear layer, two steps, single-step and two-step kernels."""
+    from LB_D2Q9.simulation import Simulation
+    import bench
+    n = 4096
+    rho, u, v = bench.shear_layer(n, n, 0, n, U=0.05)
+    f0 = equilibrium(rho, u, v)
+    sim = Simulation(n, n, 1.8, bc="periodic")
+    sim.set_variant(variant)
+    sim.set_f(f0)
+    ref = oracle.O2Sim(n, n, 1.8, oracle.BC_PERIODIC)
+    ref.set_f(f0)
+    sim.run(2); ref.run(2)
+    assert_fields_close(sim.get_fields(("f", "rho", "u", "v")), ref.get_fields(),
+                        dict(f=5e-7, rho=1e-6, u=1e-6, v=1e-6))
+
+
+def test_config4_shear_layer_8192_properties(lbhip):
+    """8192x8192 periodic shear layer (the bench workload).  The initial state has period nx/4 in x,
+    every cell is updated by the same arithmetic from identical neighbourhoods, so the state must stay
+    EXACTLY nx/4-periodic; total mass may only drift by fp32 rounding bias (the float32 weights sum to
+    1 + 7.5e-9, so the reference arithmetic itself gains ~1e-8 x omega per step: bound 5e-8 per step)."""
+    from LB_D2Q9.simulation import Simulation
+    import bench
+    n, steps = 8192, 41                                  # odd: single-step and two-step kernels both run
+    sim = Simulation(n, n, 1.7, bc="periodic")
+    sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
+    assert sim.steps_per_launch() == 2
+    rho0 = sim.get_fields(("rho",))["rho"].astype(np.float64).sum()
+    sim.run(steps)
+    g = sim.get_fields(("rho", "u", "v"))
+    q = n // 4
+    for k in ("rho", "u", "v"):
+        a = g[k]
+        assert np.array_equal(a[:q], a[q:2 * q]) and np.array_equal(a[:q], a[3 * q:]), k
+        assert np.all(np.isfinite(a))
+    drift = (g["rho"].astype(np.float64).sum() - rho0) / rho0 / steps
+    assert abs(drift) < 5e-8, drift
+    assert abs(g["u"]).max() < 0.06 and abs(g["v"]).max() < 0.01
+
+
+def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
+    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, two-step kernel, 2-deep halo)
+    executed as in-library virtual slabs on one device: bitwise equal to the undivided run."""
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.slabs import LocalSlabRing, partition_rows
+    import bench
+    n, steps = 8192, 7
+    one = Simulation(n, n, 1.7, bc="periodic")
+    one.init_equilibrium(*bench.shear_layer(n, n, 0, n))
+    one.run(steps)
+    want = one.get_fields(("rho", "u", "v"))
+    one.close()
+    ring = LocalSlabRing(n, n, 1.7, 8, bc="periodic")
+    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 2
+    for s, (y0, h) in zip(ring.slabs, ring.parts):
+        s.init_equilibrium(*bench.shear_layer(n, n, y0, h))
+    ring.run_in_library(steps)
+    got = ring.get_fields(("rho", "u", "v"))
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_config5_porous_obstacles_4096_vs_oracle(lbhip, oracle):
+    """4096x4096 pipe flow through the reference's obstacle image (docs/CS205_obstacle_4.tif rescaled
+    by nearest neighbour), bounce-back mask, two steps against the oracle + a longer sanity run."""
+    from LB_D2Q9.masks import obstacle_mask_from_tiff
+    from LB_D2Q9.simulation import Simulation
+    n = 4096
+    mask = obstacle_mask_from_tiff(os.path.join(GOLDEN, "CS205_obstacle_4.tif"), (n, n))
+    mask[0, :] = mask[-1, :] = 0
+    mask[:, 0] = mask[:, -1] = 0
+    assert 0.005 < mask.mean() < 0.02
+    rin = 1.001
+    ramp = oracle.density_ramp(n, n, rin, 1.)
+    f0 = equilibrium(ramp.astype(np.float64), np.zeros((n, n)), np.zeros((n, n)))
+    sim = Simulation(n, n, 1.0, bc="pipe", inlet_rho=rin, outlet_rho=1., obstacle_mask=mask)
+    ref = oracle.O2Sim(n, n, 1.0, oracle.BC_PIPE, rin, 1., mask=mask)
+    sim.set_f(f0); ref.set_f(f0)
+    assert sim.steps_per_launch() == 2
+    sim.run(2); ref.run(2)
+    assert_fields_close(sim.get_fields(("f", "rho", "u", "v")), ref.get_fields(), dict(f=5e-7, rho=1e-6, u=1e-6, v=1e-6))
+    sim.run(199)
+    g = sim.get_fields(("rho", "u", "v"))
+    assert np.all(np.isfinite(g["rho"])) and abs(g["rho"].mean() - 1.0005) < 1e-3
+    assert g["u"].mean() > 0                         # flow from inlet to outlet
