@@ -6,7 +6,7 @@ import ctypes as ct
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbhip.so")
+LIB_PATH = os.environ.get("LB_LIB") or os.path.join(_HERE, "liblbhip.so")   # LB_LIB: diagnostic builds only
 
 LB_BC_PIPE, LB_BC_PERIODIC, LB_BC_CAVITY = 0, 1, 2
 LB_FLAG_HALO = 1

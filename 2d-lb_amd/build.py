@@ -27,6 +27,15 @@ def up_to_date():
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in (SRC, HDR, __file__))
 
 
+def build_diag():
+    """Diagnostic build with the ablation switches compiled in (tools/ablate.py): liblbhip_diag.so.
+    Never used by the product; select it with LB_LIB=<path>."""
+    out = OUT.replace("liblbhip.so", "liblbhip_diag.so")
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-DLB_DIAG",
+                           "-fPIC", "-shared", SRC, "-o", out, "-ldl"])
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
@@ -43,4 +52,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    if "--diag" in sys.argv:
+        print(build_diag())
+    else:
+        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -75,6 +75,7 @@ struct StepArgs {
     int wrap_y;            // periodic in y inside one slab: wrap the source rows locally
     int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
     int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
+    int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
     float omega, rho_in, rho_out, lid_u, rho0;
 };
 
@@ -242,6 +243,15 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
     const long long P = a.pitch, S = a.plane;
     const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
     const float *s = a.src;
+#ifdef LB_DIAG
+    if (a.diag & 8) {                      // timing only: all nine planes read aligned (wrong results)
+        q[0] = load4<NTL>(s + o0);          q[1] = load4<NTL>(s + 1 * S + o0);  q[2] = load4<NTL>(s + 2 * S + om);
+        q[3] = load4<NTL>(s + 3 * S + o0);  q[4] = load4<NTL>(s + 4 * S + op);  q[5] = load4<NTL>(s + 5 * S + om);
+        q[6] = load4<NTL>(s + 6 * S + om);  q[7] = load4<NTL>(s + 7 * S + op);  q[8] = load4<NTL>(s + 8 * S + op);
+        mk = uc4{0, 0, 0, 0};
+        return;
+    }
+#endif
     q[0] = load4<NTL>(s + o0);
     q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
     q[2] = load4<NTL>(s + 2 * S + om);
@@ -334,6 +344,9 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
     f4a q[9], r4, u4, v4;
     uc4 mk;
     gather_row<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk);
+#ifdef LB_DIAG
+    if (!(a.diag & 1))
+#endif
     collide_row<BC, MASK>(a, x4, yg, q, mk, r4, u4, v4);
 
     const long long S = a.plane;
@@ -348,51 +361,89 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
 }
 
 // ---- two time steps per pass ------------------------------------------------------------------
-// Temporal blocking without LDS.  A wave owns a strip of 256 cells (64 lanes x 4) and marches up a
-// segment of rows.  For every row r it computes step 1 (gather from the source lattice + collide:
-// exactly gather_row/collide_row above) and keeps the result in registers; the second step of row
-// y = r-1 needs, per link k, the step-1 value of ONE row only (cy=-1: row r, just computed; cy=0:
+// Temporal blocking without LDS.  A wave owns a strip of 256 cells (64 lanes x 4, 1 KiB-aligned) and
+// marches up a segment of rows.  For every row r it computes step 1 (gather from the source lattice +
+// collide: exactly gather_row/collide_row above) and keeps the result in registers; the second step of
+// row y = r-1 needs, per link k, the step-1 value of ONE row only (cy=-1: row r, just computed; cy=0:
 // row r-1; cy=+1: row r-2), so a register window of 3+6 float4 holds everything, and the x-neighbour
-// a link comes from is one element to the left/right = a 1-lane shuffle.  The outermost lanes
-// (0 and 63) are halo: their step-1 values feed lanes 1 and 62, their step-2 values are not
-// stored, so strips advance by 248 cells and nothing is exchanged between waves.  HBM traffic per
-// two updates of a cell: 9 reads + 9 writes (+3.2 % strip overlap, +2 rows per segment), i.e.
-// ~37 B per lattice update instead of 72.
-constexpr int STRIP_OUT = 248;     // cells stored per wave-row: lanes 1..62
+// a link comes from is one element to the left/right = a 1-lane shuffle.  The two cells just outside
+// the strip (x0-1 and x0+256) are recomputed by the edge lanes 0 and 63 as a fifth, scalar cell, so
+// waves never exchange anything, every strip is a whole number of cache lines and every store is a
+// full aligned 1 KiB.  (A first version used lanes 0/63 as halo lanes and advanced strips by 248
+// cells: simpler, but its 992-byte store segments and 34-instead-of-32 strips cost 10-18 %:
+// tools/ablate.py, profiles/r01_ablation.txt.)  HBM traffic per two updates of a cell: 9 reads +
+// 9 writes (+2 rows per segment), i.e. ~37 B per lattice update instead of 72.
+constexpr int STRIP_W = 256;       // cells per wave-row
 
-// value of the cell one to the LEFT of each of my 4 cells (links with cx = +1)
-__device__ __forceinline__ f4a from_left(f4a v)
+// value of the cell one to the LEFT of each of my 4 cells (links with cx = +1); lane 0 takes the
+// strip's left halo cell
+__device__ __forceinline__ f4a from_left(f4a v, float halo, int lane)
 {
-    const float w = __shfl_up(v.w, 1);          // left lane's last cell
+    float w = __shfl_up(v.w, 1);                // left lane's last cell
+    if (lane == 0) w = halo;
     return f4a{w, v.x, v.y, v.z};
 }
-// value of the cell one to the RIGHT of each of my 4 cells (links with cx = -1)
-__device__ __forceinline__ f4a from_right(f4a v)
+// value of the cell one to the RIGHT of each of my 4 cells (links with cx = -1); lane 63 takes the
+// strip's right halo cell
+__device__ __forceinline__ f4a from_right(f4a v, float halo, int lane)
 {
-    const float x = __shfl_down(v.x, 1);        // right lane's first cell
+    float x = __shfl_down(v.x, 1);              // right lane's first cell
+    if (lane == 63) x = halo;
     return f4a{v.y, v.z, v.w, x};
 }
 
-// Row r of step 1 for this lane: resolve the row indices and issue the 9 loads.  Rows -1 and H are
-// wrapped (whole periodic grid on this GPU), read from the ghost rows (slab with a neighbour on that
-// side: rows -2..H+1 hold valid halo data) or skipped: returns false when the row lies outside a wall
-// (its values are never consumed un-overwritten).
-template <int BC, bool MASK>
-__device__ __forceinline__ bool load_step1_row(const StepArgs &a, int x4, int r, f4a (&q)[9], uc4 &mk, int &rr)
+// Resolve the rows step 1 of row r reads.  Rows -1 and H are wrapped (whole periodic grid on this
+// GPU), read from the ghost rows (slab with a neighbour on that side: rows -2..H+1 hold valid halo
+// data) or skipped: returns false when the row lies outside a wall (its values are never consumed
+// un-overwritten).
+__device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, int &ym, int &yp)
 {
-    rr = r;
-    int ym = r - 1, yp = r + 1;
+    rr = r; ym = r - 1; yp = r + 1;
     if (a.wrap_y) {
         rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
         ym = rr - 1 < 0 ? a.h - 1 : rr - 1;
         yp = rr + 1 >= a.h ? 0 : rr + 1;
-    } else if (r < 0) {
-        if (!a.ghost_s) return false;
-    } else if (r >= a.h) {
-        if (!a.ghost_n) return false;
+        return true;
     }
-    gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
+    if (r < 0) return a.ghost_s != 0;
+    if (r >= a.h) return a.ghost_n != 0;
     return true;
+}
+
+// Step 1 of the single cell (hx, row rr): the strip's halo cell, executed by one edge lane.  Same
+// arithmetic as collide_row, so the value equals what the neighbouring strip computes for that cell.
+template <int BC, bool MASK>
+__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c)
+{
+    int xc = hx, xl = hx - 1, xg = hx + 1;
+    if (BC == LB_BC_PERIODIC) {
+        xc = hx < 0 ? hx + a.nx : (hx >= a.nx ? hx - a.nx : hx);
+        xl = xc - 1 < 0 ? a.nx - 1 : xc - 1;
+        xg = xc + 1 >= a.nx ? 0 : xc + 1;
+    } else if (hx < 0 || hx >= a.nx) {
+        c = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // outside the box: don't-care
+        return;
+    }
+    const long long P = a.pitch, S = a.plane;
+    const float *s = a.src;
+    const long long r0 = (long long)rr * P, rm = (long long)ym * P, rp = (long long)yp * P;
+    c.f0 = s[r0 + xc];
+    c.f1 = s[1 * S + r0 + xl];
+    c.f2 = s[2 * S + rm + xc];
+    c.f3 = s[3 * S + r0 + xg];
+    c.f4 = s[4 * S + rp + xc];
+    c.f5 = s[5 * S + rm + xl];
+    c.f6 = s[6 * S + rm + xg];
+    c.f7 = s[7 * S + rp + xg];
+    c.f8 = s[8 * S + rp + xl];
+    const int yg = a.y0 + rr;
+    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
+        if (BC == LB_BC_PIPE) bc_pipe_cell(c, xc, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, xc, yg, a.nx, a.ny, a.lid_u, a.rho0);
+    }
+    if (MASK) bounce_cell(c, a.mask[r0 + xc] != 0);
+    float rho, ux, uy;
+    relax_cell(c, a.omega, rho, ux, uy);
 }
 
 // Segment i of a launch covers output rows [row_begin + i*seg_stride, +seg_rows) clipped to row_end:
@@ -408,25 +459,43 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
     const int ya = a.row_begin + sy * a.seg_stride;
     if (ya >= row_end) return;
     const int yb = min(ya + seg_rows, row_end);
-    const int xr = sx * STRIP_OUT - 4 + lane * 4;       // true x of my first cell; may lie outside the box
+    const int x0 = sx * STRIP_W;
+    const int xr = x0 + lane * 4;                       // true x of my first cell; may lie beyond nx
     int x4 = xr;                                        // x used for addressing
-    if (BC == LB_BC_PERIODIC) x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? xr - a.nx : xr);
-    // rows are stored by lanes 1..62 whose cells exist; out-of-box lanes compute don't-care values
-    const bool store_lane = lane >= 1 && lane <= 62 && xr < a.nx;
+    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;   // duplicates of cells 0.. (nx % 4 == 0)
+    const bool store_lane = xr < a.nx;                  // lanes past the box compute don't-care values
+    const bool edge_lane = (lane == 0) || (lane == 63);
+    const int hx = (lane == 0) ? x0 - 1 : x0 + STRIP_W; // my halo cell (edge lanes only)
     const long long S = a.plane;
 
     f4a d0 = {}, d1 = {}, d3 = {};                      // step-1 links 0,1,3 of row r-1
     f4a e2 = {}, e5 = {}, e6 = {};                      // step-1 links 2,5,6 of row r-1
     f4a g2 = {}, g5 = {}, g6 = {};                      //                     of row r-2
+    // the same window for the halo cell; lane 0 keeps the links entering from the left (1,5,8),
+    // lane 63 those entering from the right (3,6,7)
+    float hd = 0.f, he = 0.f, hg = 0.f;                 // cy=0 link of row r-1; cy=+1 link of rows r-1, r-2
     for (int r = ya - 1; r <= yb; ++r) {
         // ---- step 1 of row r ---------------------------------------------------------------------
-        // (an explicit software prefetch of row r+1 was tried: +36 VGPR, -2 %; the memory pipeline, not
-        // load latency, is what the waves wait for -- profiles/r01_pmc_probe.txt)
+        // (an explicit software prefetch of row r+1 was tried: +36 VGPR, -2 %; removing all
+        // arithmetic does not make the kernel faster either: the memory pipeline is what the waves
+        // wait for -- profiles/r01_ablation.txt)
         f4a q[9], r4, u4, v4;
         uc4 mk = {0, 0, 0, 0};
-        int rr = 0;
-        const bool have = load_step1_row<BC, MASK>(a, x4, r, q, mk, rr);
+        int rr, ym, yp;
+        const bool have = step1_rows(a, r, rr, ym, yp);
+        float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f;          // halo cell, row r: cy=0, cy=+1, cy=-1 link
         if (have) {
+            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
+            if (edge_lane) {
+                Cell hc;
+                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, hc);
+                hq0 = lane == 0 ? hc.f1 : hc.f3;
+                hq1 = lane == 0 ? hc.f5 : hc.f6;
+                hq2 = lane == 0 ? hc.f8 : hc.f7;
+            }
+#ifdef LB_DIAG
+            if (!(a.diag & 1))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + rr, q, mk, r4, u4, v4);
         } else {
 #pragma unroll
@@ -437,18 +506,27 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
             const int y = r - 1;
             f4a t[9];
             t[0] = d0;
-            t[1] = from_left(d1);
-            t[3] = from_right(d3);
+            t[1] = from_left(d1, hd, lane);
+            t[3] = from_right(d3, hd, lane);
             t[2] = g2;
-            t[5] = from_left(g5);
-            t[6] = from_right(g6);
+            t[5] = from_left(g5, hg, lane);
+            t[6] = from_right(g6, hg, lane);
             t[4] = q[4];
-            t[7] = from_right(q[7]);
-            t[8] = from_left(q[8]);
+            t[7] = from_right(q[7], hq2, lane);
+            t[8] = from_left(q[8], hq2, lane);
             const long long o = (long long)y * a.pitch + x4;
             uc4 mk2 = {0, 0, 0, 0};
             if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + o);
+#ifdef LB_DIAG
+            if (!(a.diag & 2))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + y, t, mk2, r4, u4, v4);
+#ifdef LB_DIAG
+            if (a.diag & 4) {              // no stores: keep the values alive instead
+#pragma unroll
+                for (int k = 0; k < 9; ++k) asm volatile("" ::"v"(t[k]));
+            } else
+#endif
             if (store_lane) {
                 float *d = a.dst + o;
 #pragma unroll
@@ -464,6 +542,7 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
         g2 = e2; g5 = e5; g6 = e6;
         e2 = q[2]; e5 = q[5]; e6 = q[6];
         d0 = q[0]; d1 = q[1]; d3 = q[3];
+        hg = he; he = hq1; hd = hq0;
     }
 }
 
@@ -687,6 +766,7 @@ struct lb_sim {
     float *halo_buf = nullptr;  // 4 x 9*nx floats: send north, send south, recv south, recv north
     bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
     int variant = -1;           // < 0: automatic (effective_variant)
+    int diag = 0;
     int64_t bytes = 0;
 
     float *origin(int which) const { return lat[which] + GUARD + GHOST * pitch; }   // plane 0, row 0, x 0
@@ -717,6 +797,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.ghost_s = (s->multi_slab() && (periodic || s->p.y0 > 0)) ? 1 : 0;
     a.ghost_n = (s->multi_slab() && (periodic || s->p.y0 + s->H < s->p.ny)) ? 1 : 0;
     a.seg_stride = 0;
+    a.diag = s->diag;
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     return a;
@@ -825,7 +906,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     if (row_end <= row_begin) return LB_OK;
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
-    const int strips = (s->p.nx + STRIP_OUT - 1) / STRIP_OUT;
+    const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
     int segs, seg_rows;
     if (nsegs_fixed > 0) {
         segs = nsegs_fixed;
@@ -954,7 +1035,7 @@ int slab_step_launch(lb_sim *s, bool two, bool macro)
     int rc;
     const int H = s->H;
     if (two) {
-        const int strips = (s->p.nx + STRIP_OUT - 1) / STRIP_OUT;
+        const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
         // edge bands: output rows [0,2) and [H-2,H), one wave per strip and band
         if ((rc = launch_step2(s, s->edge_stream, 0, H, macro, 2, 2, H - 2))) return rc;
         HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
@@ -1027,6 +1108,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->plane = (long long)(s->H + 2 * GHOST) * s->pitch + skew;
     s->lat_floats = 9 * s->plane + 2 * GUARD;
     if (const char *e = getenv("LB_VARIANT")) s->variant = atoi(e);
+    if (const char *e = getenv("LB_DIAG")) s->diag = atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)

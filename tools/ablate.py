@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Ablation timing of the fused kernels (diagnostic build, wrong results by design, timing only).
+LB_DIAG bits: 1 = skip step-1 collide, 2 = skip step-2 collide, 4 = no stores, 8 = all loads aligned.
+Each configuration runs in its own process (the switches are read at lb_create)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import os, sys
+sys.path[:0] = [os.path.join(%r, "2d-lb_amd"), %r]
+from LB_D2Q9.simulation import Simulation
+from bench import shear_layer
+n = int(sys.argv[1]); variant = int(sys.argv[2])
+sim = Simulation(n, n, 1.7, bc="periodic"); sim.set_variant(variant)
+sim.init_equilibrium(*shear_layer(n, n, 0, n))
+sim.run(6)
+best = min(sim.timed_run(20) for _ in range(3))
+print("%%.1f" %% (n * n * 20 / (best * 1e-3) / 1e6))
+''' % (ROOT, ROOT)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    lib = os.path.join(ROOT, "2d-lb_amd", "LB_D2Q9", "liblbhip_diag.so")
+    for variant, name in ((33, "k_step2"), (9, "k_step")):
+        for diag, what in ((0, "full"), (1, "no step-1 collide"), (2, "no step-2 collide"), (3, "no collide at all"),
+                           (4, "no stores"), (8, "aligned loads"), (11, "no collide, aligned loads"),
+                           (7, "loads only"), (16, "aligned 256-cell strips"), (19, "aligned strips, no collide"),
+                           (17, "aligned strips, no step-1 collide")):
+            if name == "k_step" and diag in (2, 3, 4, 7, 11, 16, 19, 17):
+                continue
+            env = dict(os.environ, LB_LIB=lib, LB_DIAG=str(diag))
+            out = subprocess.run([sys.executable, "-c", CHILD, str(n), str(variant)], env=env, capture_output=True, text=True)
+            val = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "ERR " + out.stderr[-200:]
+            print("%-8s diag=%2d %-28s %s MLUPS-equivalent" % (name, diag, what, val), flush=True)
+
+
+if __name__ == "__main__":
+    main()
