@@ -190,6 +190,13 @@ class Pipe_Flow(object):
     def step(self):
         self._sim.run(1)
 
+    # ---- state I/O (new: the reference has no checkpointing) ----------------------------------------
+    def save_checkpoint(self, path):
+        self._sim.save_checkpoint(path)
+
+    def load_checkpoint(self, path):
+        self._sim.load_checkpoint(path)
+
     # ---- read-back (:390-438) -------------------------------------------------------------------
     def get_fields(self):
         return self._sim.get_fields()

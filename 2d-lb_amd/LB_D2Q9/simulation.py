@@ -86,6 +86,7 @@ class Simulation(object):
         check(self._lib.lb_create(ct.byref(p), ct.byref(self._h)))
         self._shape2 = (self.nx, self.local_ny)
         self._shape3 = (self.nx, self.local_ny, NUM_JUMPERS)
+        self._mask_host = None
         if obstacle_mask is not None:
             self.set_obstacle_mask(obstacle_mask)
 
@@ -109,8 +110,10 @@ class Simulation(object):
         """(nx, local_ny) array; cells equal to 1/True are solid.  None removes the obstacle."""
         if mask is None:
             check(self._lib.lb_set_mask(self._h, None))
+            self._mask_host = None
             return
         m = _f_order(np.asarray(mask) != 0, self._shape2, np.int32)
+        self._mask_host = m
         check(self._lib.lb_set_mask(self._h, m.ctypes.data))
         if self._halo and self.local_ny == self.ny and self.bc_mode == _native.LB_BC_PERIODIC:
             # a whole periodic grid run through the halo path is its own neighbour
@@ -203,6 +206,42 @@ class Simulation(object):
             ptr = lambda k: out[k].ctypes.data if k in out else None
             check(self._lib.lb_get_macro(self._h, ptr("rho"), ptr("u"), ptr("v")))
         return out
+
+    # -- state I/O (the reference has none: state only leaves through get_fields) --------------
+    def save_checkpoint(self, path):
+        """Write everything needed to continue this run bit for bit: populations, the macroscopic
+        fields of the last step, the obstacle mask and the lattice parameters (.npz)."""
+        g = self.get_fields(("f", "rho", "u", "v"))
+        np.savez(path, f=g["f"], rho=g["rho"], u=g["u"], v=g["v"],
+                 mask=(self._mask_host if self._mask_host is not None else np.zeros((0, 0), np.int32)),
+                 nx=self.nx, ny=self.ny, y0=self.y0, local_ny=self.local_ny, bc_mode=self.bc_mode,
+                 omega=self.omega, inlet_rho=self.inlet_rho, outlet_rho=self.outlet_rho,
+                 lid_u=self.lid_u, rho0=self.rho0)
+
+    def load_checkpoint(self, path):
+        """Restore a state written by save_checkpoint into this (same-shaped) lattice."""
+        with np.load(path) as d:
+            if (int(d["nx"]), int(d["ny"]), int(d["y0"]), int(d["local_ny"])) != (self.nx, self.ny, self.y0, self.local_ny):
+                raise ValueError("checkpoint is for a %dx%d lattice (slab %d+%d), this one is %dx%d (slab %d+%d)"
+                                 % (int(d["nx"]), int(d["ny"]), int(d["y0"]), int(d["local_ny"]),
+                                    self.nx, self.ny, self.y0, self.local_ny))
+            if int(d["bc_mode"]) != self.bc_mode:
+                raise ValueError("checkpoint was written with a different boundary family")
+            if d["mask"].size:
+                self.set_obstacle_mask(d["mask"])
+            self.set_fields(d["rho"], d["u"], d["v"])
+            self.set_f(d["f"])
+
+    @classmethod
+    def from_checkpoint(cls, path, device=0):
+        """Build a new Simulation from a checkpoint file."""
+        with np.load(path) as d:
+            sim = cls(int(d["nx"]), int(d["ny"]), float(d["omega"]), bc=int(d["bc_mode"]),
+                      inlet_rho=float(d["inlet_rho"]), outlet_rho=float(d["outlet_rho"]), lid_u=float(d["lid_u"]),
+                      rho0=float(d["rho0"]), device=device, y0=int(d["y0"]), local_ny=int(d["local_ny"]),
+                      halo=int(d["local_ny"]) != int(d["ny"]))
+        sim.load_checkpoint(path)
+        return sim
 
     # -- row-slab stepping (driven by LB_D2Q9.slabs) -------------------------------
     def step_boundary(self, write_macro=False):

@@ -314,3 +314,39 @@ def test_pipe_flow_class_poiseuille_kat(lbhip):
     d = golden("o2_pipe_N10")
     g = sim.get_fields()
     assert_fields_close(g, d, TOLN, "s999_")
+
+
+# ---- state I/O and the frame dumper on the real engine ---------------------------------------------------
+def test_checkpoint_restart_is_bitwise(lbhip, tmp_path):
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 600, 90
+    rng = np.random.default_rng(4)
+    mask = rng.random((nx, ny)) < 0.03
+    mask[0, :] = mask[-1, :] = False
+    mask[:, 0] = mask[:, -1] = False
+    a = Simulation(nx, ny, 1.45, bc="pipe", inlet_rho=1.003, obstacle_mask=mask)
+    a.set_variant(33)
+    a.set_f(_random_state(rng, nx, ny))
+    a.run(9)
+    path = str(tmp_path / "state.npz")
+    a.save_checkpoint(path)
+    a.run(10)
+    b = Simulation.from_checkpoint(path)
+    g = b.get_fields(("rho", "u"))
+    b.run(10)
+    ga, gb = a.get_fields(("f", "rho", "u", "v")), b.get_fields(("f", "rho", "u", "v"))
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    assert g["rho"].shape == (nx, ny)
+
+
+def test_frame_dumper_on_pipe_flow_cylinder(lbhip, tmp_path):
+    from LB_D2Q9.dimensionless import opencl_dim as lb
+    from LB_D2Q9.frames import Frame_Dumper
+    sim = lb.Pipe_Flow_Cylinder(diameter=1., rho=1., viscosity=1., pressure_grad=-10., pipe_length=3., N=8,
+                                cylinder_center=[.75, .5], cylinder_radius=.1, verbose=False)
+    d = Frame_Dumper(sim, sim.u, num_steps_per_draw=10, max_magnitude=0.05, render_folder=str(tmp_path))
+    d.run(2)
+    assert d.total_num_steps == 20 and d.I.shape == (sim.nx, sim.ny) and np.isfinite(d.I).all()
+    assert np.array_equal(d.I, sim.get_fields()["u"])
+    assert all(open(f, "rb").read(8) == b"\x89PNG\r\n\x1a\n" for f in d.frames_written)

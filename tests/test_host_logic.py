@@ -138,3 +138,41 @@ def test_partition_rows_and_neighbours():
     assert neighbours(0, 4, True) == (3, 1) and neighbours(3, 4, True) == (2, 0)
     assert neighbours(0, 1, True) == (0, 0) and neighbours(0, 1, False) == (-1, -1)
     assert neighbours(1, 2, True) == (0, 0)
+
+
+# ---- headless frame dumper (reference: field_visualizer.py:146-161) -------------------------------------------
+class _FakeSim(object):
+    """run()/get_fields() provider without a GPU: a rigid rotation whose angle grows with the step count."""
+    nx, ny = 24, 16
+
+    def __init__(self):
+        self.steps = 0
+
+    def run(self, n):
+        self.steps += n
+
+    def get_fields(self):
+        x = np.arange(self.nx)[:, None] - self.nx / 2.
+        y = np.arange(self.ny)[None, :] - self.ny / 2.
+        w = 1e-3 * self.steps
+        return {"rho": np.ones((self.nx, self.ny), np.float32), "u": (-w * y * np.ones_like(x)).astype(np.float32),
+                "v": (w * x * np.ones_like(y)).astype(np.float32)}
+
+
+def test_frame_dumper_loop_and_png(tmp_path):
+    from LB_D2Q9.frames import Frame_Dumper, vorticity
+    sim = _FakeSim()
+    d = Frame_Dumper(sim, "vorticity", num_steps_per_draw=5, max_magnitude=0.02, render_folder=str(tmp_path))
+    frames = d.run(3)
+    assert sim.steps == 15 and d.total_num_steps == 15 and len(frames) == 3
+    assert [os.path.basename(f) for f in frames] == ["00000005.png", "00000010.png", "00000015.png"]
+    g = sim.get_fields()
+    assert np.allclose(vorticity(g["u"], g["v"]), 2 * 1e-3 * 15, atol=1e-9)       # curl of a rigid rotation = 2 w
+    PIL = pytest.importorskip("PIL.Image")
+    img = np.asarray(PIL.open(frames[-1]))
+    assert img.shape == (sim.ny, sim.nx, 3)                                         # rows = y, drawn upwards
+    assert img[0, 0, 0] == 255 and img[0, 0, 2] < 255                               # positive vorticity -> red side
+    d2 = Frame_Dumper(sim, lambda: sim.get_fields()["u"], num_steps_per_draw=1, render_folder=str(tmp_path / "n"),
+                      image_format="npy", run_func=lambda n: sim.run(2 * n))
+    d2.on_draw()
+    assert sim.steps == 17 and np.load(d2.frames_written[0]).shape == (sim.nx, sim.ny)
