@@ -181,13 +181,21 @@ class Simulation(object):
     def step(self):
         self.run(1)
 
-    def timed_run(self, num_iterations):
-        """run() bracketed by HIP events on the engine's stream; returns milliseconds."""
-        ms = ct.c_float()
+    def timer_start(self):
+        """Record the start HIP event on the engine's stream."""
         check(self._lib.lb_timer_start(self._h))
-        check(self._lib.lb_run(self._h, int(num_iterations)))
+
+    def timer_stop(self):
+        """Record the stop event, wait for it, return the milliseconds since timer_start()."""
+        ms = ct.c_float()
         check(self._lib.lb_timer_stop(self._h, ct.byref(ms)))
         return ms.value
+
+    def timed_run(self, num_iterations):
+        """run() bracketed by HIP events on the engine's stream; returns milliseconds."""
+        self.timer_start()
+        check(self._lib.lb_run(self._h, int(num_iterations)))
+        return self.timer_stop()
 
     # -- read-back -------------------------------------------------------------
     def get_fields(self, which=("f", "feq", "u", "v", "rho")):

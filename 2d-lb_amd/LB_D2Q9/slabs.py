@@ -267,8 +267,10 @@ class DistributedSlab(_SlabSet):
             self.engine.sync()
 
     def timed_run(self, n):
-        """HIP-event time of run(n) on this rank's stream, ms (transport 'rccl' only)."""
-        return self.engine.timed_run(n)
+        """HIP-event time of run(n) on this rank's stream, ms."""
+        self.engine.timer_start()
+        self.run(n, wait=False)
+        return self.engine.timer_stop()
 
     def get_local_fields(self, which=("f", "feq", "u", "v", "rho")):
         return self.engine.get_fields(which)

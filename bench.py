@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
+    ap.add_argument("--force-slab-path", action="store_true",
+                    help="run through DistributedSlab / the RCCL halo path even with one rank (a 1-rank periodic "
+                         "ring exchanging with itself): exercises the multi-GPU code on a single GPU")
     ap.add_argument("--calibrate", type=int, default=0,
                     help="also launch N plain float4 copies of known size before the timed region "
                          "(FETCH_SIZE calibration for rocprofv3 --pmc runs; adds copy_GBps to the line)")
@@ -107,16 +110,17 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_slab_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import DistributedSlab, partition_rows
 
     n = args.size
-    if world == 1:
+    if world == 1 and not args.force_slab_path:
         sim = Simulation(n, n, args.omega, bc="periodic", device=local_rank)
         eng, y0, h = sim, 0, n
     else:
@@ -162,7 +166,8 @@ def main():
         # dominant kernel = the fused step over this rank's rows; rank 0's slab is representative.
         # One launch advances spl time steps (2 with the two-steps-per-pass kernel), i.e. it performs
         # spl x n x h lattice updates = spl x 72 B x n x h algorithmic bytes.
-        spl = eng.steps_per_launch() if args.steps % 2 == 0 else 1
+        python_driven = dist is not None and args.transport == "torch"      # that path is single-step
+        spl = eng.steps_per_launch() if (args.steps % 2 == 0 and not python_driven) else 1
         launches = args.steps // spl
         launch_s = ev_ms / 1e3 / launches
         bytes_per_launch = B_ALG * n * h * spl
@@ -179,10 +184,10 @@ def main():
             "achieved_hbm_GBps": round(mlups * 1e6 * B_ALG / 1e9, 1),
             "config": {"workload": "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
                                    "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
-                                                                    "" if world == 1 else ", halo via " + args.transport),
+                                                                    "" if dist is None else ", halo via " + args.transport),
                        "grid": [n, n], "bytes_per_lattice_update": B_ALG},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(n, spl) if world == 1 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(n, spl) if dist is None else None,
                          "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
                          "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
