@@ -1103,9 +1103,9 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->p = *p;
     s->H = p->local_ny;
     s->pitch = ((long long)p->nx + 63) / 64 * 64;
-    long long skew = 0;
-    if (const char *e = getenv("LB_PLANE_SKEW")) skew = atoll(e) * 64;
-    s->plane = (long long)(s->H + 2 * GHOST) * s->pitch + skew;
+    // (padding the row pitch or skewing the plane stride away from powers of two was measured:
+    //  no gain for k_step2, -5..-8 % for k_step -- profiles/r01_sweep_variants.txt)
+    s->plane = (long long)(s->H + 2 * GHOST) * s->pitch;
     s->lat_floats = 9 * s->plane + 2 * GUARD;
     if (const char *e = getenv("LB_VARIANT")) s->variant = atoi(e);
     if (const char *e = getenv("LB_DIAG")) s->diag = atoi(e);
