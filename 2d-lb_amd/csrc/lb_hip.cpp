@@ -546,6 +546,184 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
     }
 }
 
+// ---- three time steps per pass ----------------------------------------------------------------
+// The two-step kernel is bound by HBM alone (removing all of its arithmetic does not speed it up), so
+// a third step per pass is free bytes: the same march with one more register window.  Per row r:
+// step 1 of row r (from memory), step 2 of row r-1 (from window 1), step 3 of row r-2 (from window 2,
+// stored).  The edge lanes now recompute two cells beyond the strip for step 1 (x0-2, x0-1 |
+// x0+256, x0+257) and one for step 2 (x0-1 | x0+256), all as scalar cells with the same arithmetic.
+// Whole-grid handles only (a slab would need a 3-deep halo).  ~25 B of HBM traffic per lattice update.
+
+// Post-collision links of one halo cell that later stages can ask for: the centre links (cx = 0) and
+// the three links that point toward the strip (cx = +1 on the left side, -1 on the right side),
+// each indexed by cy = 0, +1, -1.
+struct HaloLinks {
+    float c0, c2, c4;      // links 0, 2 (cy=+1), 4 (cy=-1)
+    float t0, tp, tm;      // toward-strip links with cy = 0, +1, -1: (1,5,8) on the left, (3,6,7) on the right
+};
+
+__device__ __forceinline__ HaloLinks halo_links(const Cell &c, bool left)
+{
+    HaloLinks h;
+    h.c0 = c.f0; h.c2 = c.f2; h.c4 = c.f4;
+    h.t0 = left ? c.f1 : c.f3;
+    h.tp = left ? c.f5 : c.f6;
+    h.tm = left ? c.f8 : c.f7;
+    return h;
+}
+
+// The 4-cell-wide register window one stage hands to the next (see k_step2).
+struct Window {
+    f4a d0, d1, d3;        // links 0,1,3 of the previous row
+    f4a e2, e5, e6;        // links 2,5,6 of the previous row
+    f4a g2, g5, g6;        //                 of the row before that
+};
+__device__ __forceinline__ void window_push(Window &w, const f4a (&q)[9])
+{
+    w.g2 = w.e2; w.g5 = w.e5; w.g6 = w.e6;
+    w.e2 = q[2]; w.e5 = q[5]; w.e6 = q[6];
+    w.d0 = q[0]; w.d1 = q[1]; w.d3 = q[3];
+}
+// The same for one halo cell (scalars): toward links always, centre links when a later stage
+// recomputes this cell.
+struct HaloWindow {
+    float t0_d, tp_e, tp_g;     // toward links: cy=0 of the previous row; cy=+1 of the previous row / the one before
+    float c0_d, c2_e, c2_g;     // centre links, same delays
+};
+__device__ __forceinline__ void halo_push(HaloWindow &w, const HaloLinks &h)
+{
+    w.tp_g = w.tp_e; w.tp_e = h.tp; w.t0_d = h.t0;
+    w.c2_g = w.c2_e; w.c2_e = h.c2; w.c0_d = h.c0;
+}
+
+// Gather for the next stage of row y from the previous stage's window `w`, its newest row `q`
+// (= row y+1) and the inner halo cell's toward links (window hw, newest row hnew).
+__device__ __forceinline__ void window_gather(const Window &w, const f4a (&q)[9], const HaloWindow &hw,
+                                              const HaloLinks &hnew, int lane, f4a (&t)[9])
+{
+    t[0] = w.d0;
+    t[1] = from_left(w.d1, hw.t0_d, lane);
+    t[3] = from_right(w.d3, hw.t0_d, lane);
+    t[2] = w.g2;
+    t[5] = from_left(w.g5, hw.tp_g, lane);
+    t[6] = from_right(w.g6, hw.tp_g, lane);
+    t[4] = q[4];
+    t[7] = from_right(q[7], hnew.tm, lane);
+    t[8] = from_left(q[8], hnew.tm, lane);
+}
+
+template <int BC, bool MASK, bool MACRO, bool NTS>
+__global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+{
+    const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
+    const int item = blockIdx.x * 4 + threadIdx.y;
+    const int sx = item % strips, sy = item / strips;
+    if (sy >= nsegs) return;
+    const int ya = a.row_begin + sy * a.seg_stride;
+    if (ya >= row_end) return;
+    const int yb = min(ya + seg_rows, row_end);
+    const int x0 = sx * STRIP_W;
+    const int xr = x0 + lane * 4;
+    int x4 = xr;
+    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;
+    const bool store_lane = xr < a.nx;
+    const bool left = (lane == 0);
+    const bool edge_lane = left || (lane == 63);
+    const int hxi = left ? x0 - 1 : x0 + STRIP_W;       // inner halo cell (adjacent to the strip)
+    const int hxo = left ? x0 - 2 : x0 + STRIP_W + 1;   // outer halo cell
+    int hxi_c = hxi;                                    // inner halo cell, wrapped, for mask / boundary tests
+    if (BC == LB_BC_PERIODIC) hxi_c = hxi < 0 ? hxi + a.nx : (hxi >= a.nx ? hxi - a.nx : hxi);
+    const bool hxi_in = (BC == LB_BC_PERIODIC) || (hxi >= 0 && hxi < a.nx);
+    const long long S = a.plane;
+
+    Window w1 = {}, w2 = {};                            // step-1 / step-2 results of my 4 cells
+    HaloWindow hi1 = {}, ho1 = {}, hi2 = {};            // step 1 of the inner / outer halo cell, step 2 of the inner one
+    for (int r = ya - 2; r <= yb + 1; ++r) {
+        // ---- step 1 of row r (from memory) --------------------------------------------------------
+        f4a q1[9], r4, u4, v4;
+        uc4 mk = {0, 0, 0, 0};
+        int rr, ym, yp;
+        const bool have = step1_rows(a, r, rr, ym, yp);
+        HaloLinks hi_new = {}, ho_new = {};
+        if (have) {
+            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);
+            if (edge_lane) {
+                Cell c;
+                halo_cell_step1<BC, MASK>(a, hxi, rr, ym, yp, c);
+                hi_new = halo_links(c, left);
+                halo_cell_step1<BC, MASK>(a, hxo, rr, ym, yp, c);
+                ho_new = halo_links(c, left);
+            }
+            collide_row<BC, MASK>(a, x4, a.y0 + rr, q1, mk, r4, u4, v4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q1[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- step 2 of row r-1 (from window 1) ----------------------------------------------------
+        int r2, r2m, r2p;
+        (void)step1_rows(a, r - 1, r2, r2m, r2p);       // r2 = local row of r-1 (wrapped when periodic)
+        f4a q2[9];
+        window_gather(w1, q1, hi1, hi_new, lane, q2);
+        HaloLinks h2_new = {};
+        if (edge_lane) {
+            // the inner halo cell, step 2: centre links from itself, toward links from the outer halo
+            // cell, the remaining three from the strip's own edge cell
+            Cell c;
+            c.f0 = hi1.c0_d; c.f2 = hi1.c2_g; c.f4 = hi_new.c4;
+            const float a0 = ho1.t0_d, ap = ho1.tp_g, am = ho_new.tm;          // from the outer cell
+            const float b0 = left ? w1.d3.x : w1.d1.w;                         // from my edge cell: cy = 0
+            const float bp = left ? w1.g6.x : w1.g5.w;                         //                   cy = +1
+            const float bm = left ? q1[7].x : q1[8].w;                         //                   cy = -1
+            c.f1 = left ? a0 : b0; c.f3 = left ? b0 : a0;
+            c.f5 = left ? ap : bp; c.f6 = left ? bp : ap;
+            c.f8 = left ? am : bm; c.f7 = left ? bm : am;
+            if (hxi_in) {
+                const int yg = a.y0 + r2;
+                if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
+                    if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+                    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
+                }
+                if (MASK) bounce_cell(c, a.mask[(long long)r2 * a.pitch + hxi_c] != 0);
+                float rho, ux, uy;
+                relax_cell(c, a.omega, rho, ux, uy);
+            }
+            h2_new = halo_links(c, left);
+        }
+        {
+            uc4 mk2 = {0, 0, 0, 0};
+            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + (long long)r2 * a.pitch + x4);
+            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk2, r4, u4, v4);
+        }
+        // ---- step 3 of row r-2 (from window 2), stored ---------------------------------------------
+        if (r >= ya + 2) {
+            int r3, r3m, r3p;
+            (void)step1_rows(a, r - 2, r3, r3m, r3p);
+            f4a t[9];
+            window_gather(w2, q2, hi2, h2_new, lane, t);
+            const long long o = (long long)r3 * a.pitch + x4;
+            uc4 mk3 = {0, 0, 0, 0};
+            if (MASK) mk3 = *reinterpret_cast<const uc4 *>(a.mask + o);
+            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk3, r4, u4, v4);
+            if (store_lane) {
+                float *d = a.dst + o;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
+                if (MACRO) {
+                    store4<false>(a.rho + o, r4);
+                    store4<false>(a.u + o, u4);
+                    store4<false>(a.v + o, v4);
+                }
+            }
+        }
+        // ---- slide the windows -------------------------------------------------------------------------
+        window_push(w1, q1);
+        window_push(w2, q2);
+        halo_push(hi1, hi_new);
+        halo_push(ho1, ho_new);
+        halo_push(hi2, h2_new);
+    }
+}
+
 // Calibration kernel: plain 16-byte-per-lane copy of n4 float4s.  Known byte count in the same
 // access shape as the fused step, used to (a) correct rocprofv3's FETCH_SIZE on gfx950 and
 // (b) measure the streaming ceiling of the device the bench runs on.
@@ -874,11 +1052,18 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 // Two fused time steps in one pass (k_step2).
 template <int BC>
 void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, dim3 grid, int strips, int seg_rows,
-                     int nsegs, int row_end, bool macro, bool nts)
+                     int nsegs, int row_end, bool macro, bool nts, bool three)
 {
     const dim3 block(64, 4);
-#define LB_LAUNCH2(MASK, MACRO, NTS) \
-    hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end)
+#define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
+    do {                                                                                                         \
+        if (three)                                                                                               \
+            hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
+                               row_end);                                                                         \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
+                               row_end);                                                                         \
+    } while (0)
     if (s->has_mask) {
         if (macro) { if (nts) LB_LAUNCH2(true, true, true); else LB_LAUNCH2(true, true, false); }
         else       { if (nts) LB_LAUNCH2(true, false, true); else LB_LAUNCH2(true, false, false); }
@@ -887,6 +1072,14 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, dim3 gr
         else       { if (nts) LB_LAUNCH2(false, false, true); else LB_LAUNCH2(false, false, false); }
     }
 #undef LB_LAUNCH2
+}
+
+bool step3_applicable(const lb_sim *s)
+{
+    if (s->multi_slab()) return false;                 // a slab would need a 3-deep halo
+    if (s->p.nx < 512 || s->H < 128) return false;
+    if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
+    return true;
 }
 
 bool step2_applicable(const lb_sim *s)
@@ -901,7 +1094,7 @@ bool step2_applicable(const lb_sim *s)
 // apart (edge bands), or -- nsegs_fixed == 0 -- cut into equal shares so that the launch is one
 // balanced round of resident waves (reserve = wave slots left to a concurrent edge launch).
 int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool macro, int nsegs_fixed = 0,
-                 int seg_rows_fixed = 0, int seg_stride = 0, int reserve = 0)
+                 int seg_rows_fixed = 0, int seg_stride = 0, int reserve = 0, bool three = false)
 {
     if (row_end <= row_begin) return LB_OK;
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
@@ -930,9 +1123,9 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     const dim3 grid((items + 3) / 4);
     const bool nts = (variant & 1) != 0;
     switch (s->p.bc_mode) {
-    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts); break;
-    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts); break;
-    default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts); break;
+    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
+    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
+    default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -1496,18 +1689,22 @@ int lb_run(lb_sim *s, int n_steps)
     DeviceGuard guard(s->p.device);
     int rc;
     if (!s->multi_slab()) {
-        int it = 0;
-        const bool two = (effective_variant(s) & 32) && step2_applicable(s);
-        if (two && (n_steps & 1)) {                    // odd count: one single step first
-            if ((rc = launch_step(s, 0, 1, s->H, n_steps == 1))) return rc;
-            s->cur ^= 1;
-            it = 1;
-        }
-        for (; it < n_steps; it += two ? 2 : 1) {
-            if (two) rc = launch_step2(s, s->stream, 0, s->H, it + 2 >= n_steps);
-            else rc = launch_step(s, 0, 1, s->H, it == n_steps - 1);
+        // largest fused kernel first in the remainder: n = 3a + rem (three-step), or 2a + rem (two-step)
+        const int v = effective_variant(s);
+        const bool three = (v & 64) && step3_applicable(s);
+        const bool two = (v & 32) && step2_applicable(s);
+        int left = n_steps;
+        while (left > 0) {
+            int adv = 1;
+            if (three && left % 3 == 0) adv = 3;
+            else if (two && (left % 3 == 2 || !three) && left >= 2 && (three || left % 2 == 0)) adv = 2;
+            const bool macro = (left == adv);
+            if (adv == 3) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, true);
+            else if (adv == 2) rc = launch_step2(s, s->stream, 0, s->H, macro);
+            else rc = launch_step(s, 0, 1, s->H, macro);
             if (rc) return rc;
             s->cur ^= 1;
+            left -= adv;
         }
         if (n_steps) s->feq_valid = false;
         return LB_OK;
@@ -1665,7 +1862,9 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
 int lb_steps_per_launch(lb_sim *s)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
-    return ((effective_variant(s) & 32) && step2_applicable(s)) ? 2 : 1;
+    const int v = effective_variant(s);
+    if ((v & 64) && step3_applicable(s)) return 3;
+    return ((v & 32) && step2_applicable(s)) ? 2 : 1;
 }
 
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)
