@@ -660,39 +660,44 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
             for (int k = 0; k < 9; ++k) q1[k] = f4a{0.f, 0.f, 0.f, 0.f};
         }
         // ---- step 2 of row r-1 (from window 1) ----------------------------------------------------
-        int r2, r2m, r2p;
-        (void)step1_rows(a, r - 1, r2, r2m, r2p);       // r2 = local row of r-1 (wrapped when periodic)
+        // (skipped while the window is still filling, r < ya: nothing consumes those rows and their
+        //  mask rows r-1 < ya-1 may not exist)
         f4a q2[9];
-        window_gather(w1, q1, hi1, hi_new, lane, q2);
         HaloLinks h2_new = {};
-        if (edge_lane) {
-            // the inner halo cell, step 2: centre links from itself, toward links from the outer halo
-            // cell, the remaining three from the strip's own edge cell
-            Cell c;
-            c.f0 = hi1.c0_d; c.f2 = hi1.c2_g; c.f4 = hi_new.c4;
-            const float a0 = ho1.t0_d, ap = ho1.tp_g, am = ho_new.tm;          // from the outer cell
-            const float b0 = left ? w1.d3.x : w1.d1.w;                         // from my edge cell: cy = 0
-            const float bp = left ? w1.g6.x : w1.g5.w;                         //                   cy = +1
-            const float bm = left ? q1[7].x : q1[8].w;                         //                   cy = -1
-            c.f1 = left ? a0 : b0; c.f3 = left ? b0 : a0;
-            c.f5 = left ? ap : bp; c.f6 = left ? bp : ap;
-            c.f8 = left ? am : bm; c.f7 = left ? bm : am;
-            if (hxi_in) {
-                const int yg = a.y0 + r2;
-                if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
-                    if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-                    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
+        if (r >= ya) {
+            int r2, r2m, r2p;
+            (void)step1_rows(a, r - 1, r2, r2m, r2p);   // r2 = local row of r-1 (wrapped when periodic)
+            window_gather(w1, q1, hi1, hi_new, lane, q2);
+            if (edge_lane) {
+                // the inner halo cell, step 2: centre links from itself, toward links from the outer halo
+                // cell, the remaining three from the strip's own edge cell
+                Cell c;
+                c.f0 = hi1.c0_d; c.f2 = hi1.c2_g; c.f4 = hi_new.c4;
+                const float a0 = ho1.t0_d, ap = ho1.tp_g, am = ho_new.tm;          // from the outer cell
+                const float b0 = left ? w1.d3.x : w1.d1.w;                         // from my edge cell: cy = 0
+                const float bp = left ? w1.g6.x : w1.g5.w;                         //                   cy = +1
+                const float bm = left ? q1[7].x : q1[8].w;                         //                   cy = -1
+                c.f1 = left ? a0 : b0; c.f3 = left ? b0 : a0;
+                c.f5 = left ? ap : bp; c.f6 = left ? bp : ap;
+                c.f8 = left ? am : bm; c.f7 = left ? bm : am;
+                if (hxi_in) {
+                    const int yg = a.y0 + r2;
+                    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
+                        if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+                        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
+                    }
+                    if (MASK) bounce_cell(c, a.mask[(long long)r2 * a.pitch + hxi_c] != 0);
+                    float rho, ux, uy;
+                    relax_cell(c, a.omega, rho, ux, uy);
                 }
-                if (MASK) bounce_cell(c, a.mask[(long long)r2 * a.pitch + hxi_c] != 0);
-                float rho, ux, uy;
-                relax_cell(c, a.omega, rho, ux, uy);
+                h2_new = halo_links(c, left);
             }
-            h2_new = halo_links(c, left);
-        }
-        {
             uc4 mk2 = {0, 0, 0, 0};
             if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + (long long)r2 * a.pitch + x4);
             collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk2, r4, u4, v4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
         }
         // ---- step 3 of row r-2 (from window 2), stored ---------------------------------------------
         if (r >= ya + 2) {
@@ -1012,19 +1017,20 @@ void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, b
 }
 
 // variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py; profiles/r01_sweep_variants.txt):
-//   >= 2048^2 cells, whole grid on this GPU : two time steps per pass (k_step2): 102 k MLUPS at
-//                                             2048^2, 128 k at 4096^2/8192^2 vs 82 k single-step
-//   lattice pair >= 1 GB (4096^2 and up)    : + non-temporal stores (+3..6 %), and 2 rows x 512
-//                                             cells per workgroup wherever the single-step kernel runs
-//   smaller (Infinity-Cache resident)       : single step, plain stores, XCD-aware tile order
-//                                             (87 k MLUPS at 1024^2; k_step2 has too few waves there)
+//   >= 2048^2 cells on this GPU        : temporal blocking -- three time steps per pass on whole-grid
+//                                        handles (k_step3: 141 k MLUPS at 2048^2, 190 k at 4096^2, 201 k at
+//                                        8192^2), two on row slabs (k_step2: 141 k at 8192^2), vs 83 k single-step
+//   lattice pair >= 1 GB (4096^2 up)   : + non-temporal stores (+3..6 %), and 2 rows x 512 cells per
+//                                        workgroup wherever the single-step kernel runs
+//   smaller (Infinity-Cache resident)  : single step, plain stores, XCD-aware tile order (87 k MLUPS at
+//                                        1024^2; the marching kernels have too few waves there)
 int effective_variant(const lb_sim *s)
 {
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
     const double cells = (double)s->p.nx * s->H;
     int v = pair_bytes >= 1.0e9 ? 9 : 16;
-    if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32;
+    if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32 | 64;
     return v;
 }
 

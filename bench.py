@@ -167,13 +167,15 @@ def main():
         # One launch advances spl time steps (2 with the two-steps-per-pass kernel), i.e. it performs
         # spl x n x h lattice updates = spl x 72 B x n x h algorithmic bytes.
         python_driven = dist is not None and args.transport == "torch"      # that path is single-step
-        spl = eng.steps_per_launch() if (args.steps % 2 == 0 and not python_driven) else 1
-        launches = args.steps // spl
-        launch_s = ev_ms / 1e3 / launches
+        spl = 1 if python_driven else eng.steps_per_launch()
+        # K timed steps = (K // spl) launches of the spl-step kernel (+ at most one shorter launch for the
+        # remainder, priced at the same per-step rate)
+        launch_s = ev_ms / 1e3 / args.steps * spl
         bytes_per_launch = B_ALG * n * h * spl
         achieved = bytes_per_launch / launch_s / 1e9
-        kname = ("k_step2<PERIODIC> (two fused time steps per pass: pull-stream+collide twice, step-1 "
-                 "results in registers)" if spl == 2 else "k_step<PERIODIC> (fused pull-stream+collide)")
+        kname = {3: "k_step3<PERIODIC> (three fused time steps per pass: step-1 and step-2 results in registers)",
+                 2: "k_step2<PERIODIC> (two fused time steps per pass: step-1 results in registers)",
+                 1: "k_step<PERIODIC> (fused pull-stream+collide)"}[spl]
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",

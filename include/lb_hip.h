@@ -154,7 +154,7 @@ int lb_timer_stop(lb_sim *s, float *elapsed_ms);
  * (floats), bytes allocated. */
 int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated);
 /* Time steps advanced by one launch of the hot kernel in lb_run with the current variant:
- * 2 when the two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch with it). */
+ * 3 / 2 when the three- / two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch with it). */
 int lb_steps_per_launch(lb_sim *s);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
  * (which is scratch between steps).  *bytes_moved = bytes read + written.  Known traffic in the
@@ -163,8 +163,8 @@ int lb_steps_per_launch(lb_sim *s);
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
 /* Kernel variant selector for tuning experiments: -1 = automatic (default); otherwise bit 0
  * non-temporal stores, bit 1 non-temporal loads, bits 2-3 rows per workgroup (0: 4, 1: 1, 2: 2),
- * bit 4 XCD-aware tile order, bit 5 two time steps per pass where applicable (whole-grid handles,
- * nx >= 512).  Results never depend on it (bitwise). */
+ * bit 4 XCD-aware tile order, bit 5 two time steps per pass where applicable (nx >= 512), bit 6 three
+ * time steps per pass (whole-grid handles).  Results never depend on it (bitwise). */
 int lb_set_variant(lb_sim *s, int variant);
 
 #ifdef __cplusplus
