@@ -117,7 +117,7 @@ class Simulation(object):
         check(self._lib.lb_set_mask(self._h, m.ctypes.data))
         if self._halo and self.local_ny == self.ny and self.bc_mode == _native.LB_BC_PERIODIC:
             # a whole periodic grid run through the halo path is its own neighbour
-            self.set_obstacle_mask_halo(m[:, -1], m[:, 0])
+            self.set_obstacle_mask_halo(m[:, [-2, -1]].T, m[:, [0, 1]].T)
 
     def set_fields(self, rho, u, v):
         """Upload the macroscopic fields (what init_hydro does, opencl_dim.py:291-293)."""
@@ -261,20 +261,25 @@ class Simulation(object):
     def step_finish(self):
         check(self._lib.lb_step_finish(self._h))
 
-    def halo_floats(self):
-        """Length of one halo buffer in floats (9 row segments of nx, two rows deep)."""
-        return 9 * self.nx
+    HALO_SEGMENTS = 18
 
-    def set_obstacle_mask_halo(self, south_row=None, north_row=None):
-        """Mask rows of the neighbouring slabs adjacent to this one (each (nx,), non-zero = solid)."""
+    def halo_floats(self):
+        """Length of one halo buffer in floats (18 row segments of nx, three rows deep)."""
+        return self.HALO_SEGMENTS * self.nx
+
+    def set_obstacle_mask_halo(self, south_rows=None, north_rows=None):
+        """Mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-2, y0-1,
+        north_rows = rows y0+H, y0+H+1, each (2, nx), non-zero = solid; None = no solid cells."""
         rows = []
-        for r in (south_row, north_row):
+        for r in (south_rows, north_rows):
+            if r is not None and np.asarray(r).shape != (2, self.nx):
+                raise ValueError("mask halo must have shape (2, nx)")
             rows.append(None if r is None else np.ascontiguousarray((np.asarray(r) != 0).astype(np.int32)))
         ptr = lambda a: None if a is None else a.ctypes.data
         check(self._lib.lb_set_mask_halo(self._h, ptr(rows[0]), ptr(rows[1])))
 
     def halo_export(self, side, buf):
-        """Copy the halo leaving through edge `side` (0 south, 1 north) into buf[9*nx]
+        """Copy the halo leaving through edge `side` (0 south, 1 north) into buf[18*nx]
         (numpy float32 array or a raw host/device address); layout: include/lb_hip.h."""
         check(self._lib.lb_halo_export(self._h, int(side), _address(buf)))
 

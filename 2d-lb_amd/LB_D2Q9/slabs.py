@@ -3,8 +3,8 @@
 The grid is cut along y (the slow axis of the device layout) into contiguous row slabs, one per
 GPU / process.  Streaming reaches one cell, so per step each slab needs from its neighbours only
 the populations that cross the shared edge (k=2,5,6 travel north, k=4,7,8 travel south).  The halo
-is kept two rows deep (9 row segments of nx floats per direction, include/lb_hip.h) so that the
-two-steps-per-pass kernel can run on slabs and exchange once per two steps.  There is no collective
+is kept three rows deep (18 row segments of nx floats per direction, include/lb_hip.h) so that the
+multi-step kernels can run on slabs and exchange once per two or three steps.  There is no collective
 on the data path.
 
 * ``partition_rows`` / ``neighbours``  - the arithmetic.
@@ -62,10 +62,20 @@ class _SlabSet(object):
 
     @staticmethod
     def _mask_halo_rows(mask, y0, h, ny, periodic):
-        """Mask rows just below / above the slab [y0, y0+h) (None at a wall)."""
-        m = np.asarray(mask)
-        south = m[:, (y0 - 1) % ny] if (periodic or y0 > 0) else None
-        north = m[:, (y0 + h) % ny] if (periodic or y0 + h < ny) else None
+        """The two mask rows below / above the slab [y0, y0+h), each (2, nx) (None at a wall; rows that
+        fall outside a non-periodic box are empty)."""
+        m = np.asarray(mask) != 0
+
+        def rows(ys):
+            out = np.zeros((2, m.shape[0]), bool)
+            for i, y in enumerate(ys):
+                if periodic:
+                    out[i] = m[:, y % ny]
+                elif 0 <= y < ny:
+                    out[i] = m[:, y]
+            return out
+        south = rows((y0 - 2, y0 - 1)) if (periodic or y0 > 0) else None
+        north = rows((y0 + h, y0 + h + 1)) if (periodic or y0 + h < ny) else None
         return south, north
 
 
@@ -85,7 +95,7 @@ class LocalSlabRing(_SlabSet):
             if obstacle_mask is not None:
                 eng.set_obstacle_mask_halo(*self._mask_halo_rows(obstacle_mask, y0, h, ny, self.periodic))
             self.slabs.append(eng)
-        self._buf = np.zeros((len(self.slabs), 2, 9 * nx), np.float32)
+        self._buf = np.zeros((len(self.slabs), 2, 18 * nx), np.float32)
         self._ghosts_valid = False
 
     def set_f(self, f):
@@ -197,7 +207,7 @@ class DistributedSlab(_SlabSet):
                 torch.cuda.set_device(dev)
                 # one stream for kernels, halo copies and torch's collectives' stream dependencies
                 self.engine.use_stream(torch.cuda.current_stream().cuda_stream)
-            mk = lambda: torch.zeros(9 * self.nx, dtype=torch.float32, device=dev)
+            mk = lambda: torch.zeros(18 * self.nx, dtype=torch.float32, device=dev)
             self._bufs = {"send_s": mk(), "send_n": mk(), "recv_s": mk(), "recv_n": mk(), "gpu": on_gpu}
         return self._bufs
 

@@ -11,9 +11,9 @@
 //                                 323-327, 395-407) and the per-step launch sequence of run() (:372-387)
 //
 // Device layout: structure of arrays, nine planes per lattice, two lattices
-// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -2,-1 and
-// H,H+1 are ghost rows (slab halo, two deep for the two-step kernel / don't-care at walls), so element
-// (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+2)*pitch + x .
+// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -3..-1 and
+// H..H+2 are ghost rows (slab halo, three deep for the three-step kernel / don't-care at walls), so
+// element (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+3)*pitch + x .
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
 // 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
 #include <hip/hip_runtime.h>
@@ -31,7 +31,8 @@
 
 namespace {
 
-constexpr int GHOST = 2;   // ghost rows below row 0 and above row H-1 of every plane
+constexpr int GHOST = 3;   // ghost rows below row 0 and above row H-1 of every plane (3-step kernel on slabs)
+constexpr int MASK_GHOST = 2;   // mask rows kept of each neighbouring slab
 constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (k_step2's edge strips
                            // read up to 4 cells before a row and 256 cells past its end)
 
@@ -846,15 +847,19 @@ __global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
     if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
 }
 
-// Halo pack / unpack: the 2-deep halo of one edge is nine row segments scattered over the planes
+// Halo pack / unpack: the 3-deep halo of one edge is 18 row segments scattered over the planes
 // (HaloSeg tables on the host side).  One tiny kernel gathers both edges into two contiguous buffers
-// (so that an exchange is one send + one receive per neighbour instead of nine), one scatters the
+// (so that an exchange is one send + one receive per neighbour instead of eighteen), one scatters the
 // received buffers into the ghost rows.  Table t: 0 north-out, 1 south-out, 2 south-in, 3 north-in;
 // rows of the north tables count from row H.
-__device__ __constant__ int d_halo_k[4][9] = {{2, 5, 6, 0, 1, 3, 2, 5, 6}, {0, 1, 3, 4, 7, 8, 4, 7, 8},
-                                              {2, 5, 6, 0, 1, 3, 2, 5, 6}, {0, 1, 3, 4, 7, 8, 4, 7, 8}};
-__device__ __constant__ int d_halo_row[4][9] = {{-2, -2, -2, -1, -1, -1, -1, -1, -1}, {0, 0, 0, 0, 0, 0, 1, 1, 1},
-                                                {-2, -2, -2, -1, -1, -1, -1, -1, -1}, {0, 0, 0, 0, 0, 0, 1, 1, 1}};
+__device__ __constant__ int d_halo_k[4][18] = {
+    {2, 5, 6, 0, 1, 3, 2, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 3, 4, 7, 8, 4, 7, 8},
+    {2, 5, 6, 0, 1, 3, 2, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 3, 4, 7, 8, 4, 7, 8}};
+__device__ __constant__ int d_halo_row[4][18] = {
+    {-3, -3, -3, -2, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2},
+    {-3, -3, -3, -2, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2}};
 
 __global__ void k_halo_pack(const float *origin, long long plane, int pitch, int h, int nx, float *buf_n, float *buf_s)
 {
@@ -938,7 +943,7 @@ struct lb_sim {
     int stepping = 0;           // 1 between lb_step_boundary and lb_step_finish
     float *feq = nullptr;       // raw allocation, lazily created
     float *rho = nullptr, *u = nullptr, *v = nullptr;
-    uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2][pitch] + guards; mask -> row 0 (rows -1, H: halo)
+    uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
     bool has_mask = false;
     int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
@@ -1082,8 +1087,7 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, dim3 gr
 
 bool step3_applicable(const lb_sim *s)
 {
-    if (s->multi_slab()) return false;                 // a slab would need a 3-deep halo
-    if (s->p.nx < 512 || s->H < 128) return false;
+    if (s->p.nx < 512 || s->H < (s->multi_slab() ? 32 : 128)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
 }
@@ -1181,16 +1185,19 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
     return LB_OK;
 }
 
-// Halo of a slab edge: nine contiguous nx-float row segments ("plane-rows"), two rows deep, enough for
-// the two-step kernel (which recomputes step 1 of the neighbour's edge row) and a superset of what the
-// single-step kernel reads.  Entry i of the OUT table of one slab pairs with entry i of the IN table of
-// its neighbour.  Rows are relative: OUT north counts from row H (-1 = row H-1), IN north from row H.
+// Halo of a slab edge: 18 contiguous nx-float row segments ("plane-rows"), three rows deep: what the
+// three-step kernel needs to recompute steps 1 and 2 of the neighbour's edge rows (row -3: the links
+// step 1 of row -2 pulls upward; row -2: those plus its cy=0 links; row -1: everything), and a
+// superset of what the two- and single-step kernels read.  Entry i of the OUT table of one slab pairs
+// with entry i of the IN table of its neighbour.  Rows are relative: north tables count from row H.
 struct HaloSeg { int k, row; };
-const HaloSeg NORTH_OUT[9] = {{2, -2}, {5, -2}, {6, -2}, {0, -1}, {1, -1}, {3, -1}, {2, -1}, {5, -1}, {6, -1}};  // + H
-const HaloSeg SOUTH_IN[9]  = {{2, -2}, {5, -2}, {6, -2}, {0, -1}, {1, -1}, {3, -1}, {2, -1}, {5, -1}, {6, -1}};
-const HaloSeg SOUTH_OUT[9] = {{0, 0}, {1, 0}, {3, 0}, {4, 0}, {7, 0}, {8, 0}, {4, 1}, {7, 1}, {8, 1}};
-const HaloSeg NORTH_IN[9]  = {{0, 0}, {1, 0}, {3, 0}, {4, 0}, {7, 0}, {8, 0}, {4, 1}, {7, 1}, {8, 1}};          // + H
-constexpr int HALO_SEGS = 9;
+constexpr int HALO_SEGS = 18;
+const HaloSeg NORTH_OUT[HALO_SEGS] = {{2, -3}, {5, -3}, {6, -3}, {0, -2}, {1, -2}, {3, -2}, {2, -2}, {5, -2}, {6, -2},
+                                      {0, -1}, {1, -1}, {2, -1}, {3, -1}, {4, -1}, {5, -1}, {6, -1}, {7, -1}, {8, -1}};  // + H
+const HaloSeg *const SOUTH_IN = NORTH_OUT;                                                                        // + 0
+const HaloSeg SOUTH_OUT[HALO_SEGS] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}, {5, 0}, {6, 0}, {7, 0}, {8, 0},
+                                      {0, 1}, {1, 1}, {3, 1}, {4, 1}, {7, 1}, {8, 1}, {4, 2}, {7, 2}, {8, 2}};
+const HaloSeg *const NORTH_IN = SOUTH_OUT;                                                                        // + H
 
 float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
 {
@@ -1225,33 +1232,44 @@ int exchange_rccl(lb_sim *s, int which)
     return LB_OK;
 }
 
-// One (single or double) time step of a slab, edge rows first.  Enqueues on the compute stream
-// (interior) and the edge stream (edge bands), records ev_boundary when the edge rows of the new
-// lattice are complete and ev_interior when the interior is.  The caller then moves the halo of
-// lattice cur^1 and makes both streams wait for it before the next step.
-int slab_step_launch(lb_sim *s, bool two, bool macro)
+// adv (1, 2 or 3) time steps of a slab, edge rows first.  Enqueues on the edge stream (the three
+// rows at each end that the halo is cut from) and on the compute stream (the rest), records ev_boundary
+// when the edge rows of the new lattice are complete and ev_interior when the interior is.  The caller
+// then moves the halo of lattice cur^1 and makes both streams wait for it before the next step.
+int slab_step_launch(lb_sim *s, int adv, bool macro)
 {
     int rc;
     const int H = s->H;
-    if (two) {
+    if (adv >= 2) {
         const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
-        // edge bands: output rows [0,2) and [H-2,H), one wave per strip and band
-        if ((rc = launch_step2(s, s->edge_stream, 0, H, macro, 2, 2, H - 2))) return rc;
+        const bool three = (adv == 3);
+        // edge bands: output rows [0,3) and [H-3,H), one wave per strip and band
+        if ((rc = launch_step2(s, s->edge_stream, 0, H, macro, 2, 3, H - 3, 0, three))) return rc;
         HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-        if ((rc = launch_step2(s, s->stream, 2, H - 2, macro, 0, 0, 0, 2 * strips))) return rc;
+        if ((rc = launch_step2(s, s->stream, 3, H - 3, macro, 0, 0, 0, 2 * strips, three))) return rc;
     } else {
-        // single step: the four rows the 2-deep halo is cut from (0, 1, H-2, H-1) first, then the rest
+        // single step: the six rows the 3-deep halo is cut from (0..2, H-3..H-1) first, then the rest
         const hipStream_t keep = s->stream;
         s->stream = s->edge_stream;
         rc = launch_step(s, 0, H - 1, 2, macro);                 // rows 0 and H-1
         if (!rc) rc = launch_step(s, 1, H - 3, 2, macro);        // rows 1 and H-2
+        if (!rc) rc = launch_step(s, 2, H - 5, 2, macro);        // rows 2 and H-3
         s->stream = keep;
         if (rc) return rc;
         HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-        if ((rc = launch_step(s, 2, 1, H - 4, macro))) return rc;
+        if ((rc = launch_step(s, 3, 1, H - 6, macro))) return rc;
     }
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
+}
+
+// How many time steps the next launch of a run with `left` steps to go advances: the largest fused
+// kernel first in the remainder (left = 3a + rem with the three-step kernel, 2a + rem with the two-step).
+int next_advance(bool three, bool two, int left)
+{
+    if (three && left % 3 == 0) return 3;
+    if (two && left >= 2 && (three ? left % 3 == 2 : left % 2 == 0)) return 2;
+    return 1;
 }
 
 // Both compute streams wait for the other one's kernel and for the halo of the lattice just written.
@@ -1345,12 +1363,12 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipMalloc(&s->rho, fld_bytes));
     CREATE_TRY(hipMalloc(&s->u, fld_bytes));
     CREATE_TRY(hipMalloc(&s->v, fld_bytes));
-    CREATE_TRY(hipMalloc(&s->mask_raw, (size_t)s->pitch * (s->H + 2) + 2 * GUARD));
-    s->mask = s->mask_raw + GUARD + s->pitch;
+    CREATE_TRY(hipMalloc(&s->mask_raw, (size_t)s->pitch * (s->H + 2 * MASK_GHOST) + 2 * GUARD));
+    s->mask = s->mask_raw + GUARD + MASK_GHOST * s->pitch;
     CREATE_TRY(hipMemsetAsync(s->rho, 0, fld_bytes, s->stream));
     CREATE_TRY(hipMemsetAsync(s->u, 0, fld_bytes, s->stream));
     CREATE_TRY(hipMemsetAsync(s->v, 0, fld_bytes, s->stream));
-    CREATE_TRY(hipMemsetAsync(s->mask_raw, 0, (size_t)s->pitch * (s->H + 2) + 2 * GUARD, s->stream));
+    CREATE_TRY(hipMemsetAsync(s->mask_raw, 0, (size_t)s->pitch * (s->H + 2 * MASK_GHOST) + 2 * GUARD, s->stream));
     CREATE_TRY(hipStreamSynchronize(s->stream));
 #undef CREATE_TRY
     s->bytes = 2 * lat_bytes + 3 * fld_bytes + (size_t)s->pitch * s->H;
@@ -1513,19 +1531,22 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     return LB_OK;
 }
 
-int lb_set_mask_halo(lb_sim *s, const int32_t *south_row, const int32_t *north_row)
+int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_rows)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
-    uint8_t *tmp = (uint8_t *)calloc((size_t)s->pitch, 1);
+    uint8_t *tmp = (uint8_t *)calloc((size_t)s->pitch * MASK_GHOST, 1);
     if (!tmp) return fail(LB_ERR_ARG, "out of host memory");
-    const int32_t *rows[2] = {south_row, north_row};
-    uint8_t *dst[2] = {s->mask - s->pitch, s->mask + (size_t)s->H * s->pitch};
+    // south_rows = global rows y0-2, y0-1; north_rows = rows y0+H, y0+H+1 (each [2][nx], nearest last / first)
+    const int32_t *rows[2] = {south_rows, north_rows};
+    uint8_t *dst[2] = {s->mask - (size_t)MASK_GHOST * s->pitch, s->mask + (size_t)s->H * s->pitch};
     for (int side = 0; side < 2; ++side) {
-        memset(tmp, 0, (size_t)s->pitch);
+        memset(tmp, 0, (size_t)s->pitch * MASK_GHOST);
         if (rows[side])
-            for (int x = 0; x < s->p.nx; ++x) tmp[x] = rows[side][x] == 1;
-        hipError_t e = hipMemcpy(dst[side], tmp, (size_t)s->pitch, hipMemcpyHostToDevice);
+            for (int r = 0; r < MASK_GHOST; ++r)
+                for (int x = 0; x < s->p.nx; ++x)
+                    tmp[(size_t)r * s->pitch + x] = rows[side][(size_t)r * s->p.nx + x] == 1;
+        hipError_t e = hipMemcpy(dst[side], tmp, (size_t)s->pitch * MASK_GHOST, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             free(tmp);
             return fail(LB_ERR_HIP, "mask halo upload: %s", hipGetErrorString(e));
@@ -1701,9 +1722,7 @@ int lb_run(lb_sim *s, int n_steps)
         const bool two = (v & 32) && step2_applicable(s);
         int left = n_steps;
         while (left > 0) {
-            int adv = 1;
-            if (three && left % 3 == 0) adv = 3;
-            else if (two && (left % 3 == 2 || !three) && left >= 2 && (three || left % 2 == 0)) adv = 2;
+            const int adv = next_advance(three, two, left);
             const bool macro = (left == adv);
             if (adv == 3) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, true);
             else if (adv == 2) rc = launch_step2(s, s->stream, 0, s->H, macro);
@@ -1718,7 +1737,7 @@ int lb_run(lb_sim *s, int n_steps)
     if (!s->comm)
         return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
     if (n_steps == 0) return LB_OK;
-    if (s->H < 4) return fail(LB_ERR_ARG, "a slab needs at least 4 rows (has %d)", s->H);
+    if (s->H < 6) return fail(LB_ERR_ARG, "a slab needs at least 6 rows (has %d)", s->H);
     // everything enqueued so far on the compute stream happens before the first edge launch
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
@@ -1731,11 +1750,11 @@ int lb_run(lb_sim *s, int n_steps)
         HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
     }
     const bool two = (effective_variant(s) & 32) && step2_applicable(s);
-    for (int it = 0; it < n_steps;) {
-        const bool dbl = two && (n_steps - it) >= 2 && ((n_steps - it) % 2 == 0);   // odd count: single step first
-        const int adv = dbl ? 2 : 1;
+    const bool three = (effective_variant(s) & 64) && step3_applicable(s);
+    for (int left = n_steps; left > 0;) {
+        const int adv = next_advance(three, two, left);
         // 1. edge rows (edge stream) and interior rows (compute stream) of the new lattice, concurrently
-        if ((rc = slab_step_launch(s, dbl, it + adv >= n_steps))) return rc;
+        if ((rc = slab_step_launch(s, adv, left == adv))) return rc;
         // 2. halo of the lattice just written, on the communication stream (RCCL over xGMI), as soon as
         //    the edge rows are done and while the interior is still being computed
         HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
@@ -1744,7 +1763,7 @@ int lb_run(lb_sim *s, int n_steps)
         // 3. the next step reads the new lattice: both compute streams wait for kernels and halo
         if ((rc = slab_step_join(s))) return rc;
         s->cur ^= 1;
-        it += adv;
+        left -= adv;
     }
     s->ghosts_valid = true;
     s->feq_valid = false;
@@ -1763,7 +1782,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         if (!sims[i]->multi_slab()) return fail(LB_ERR_ARG, "group members must be slab handles (LB_FLAG_HALO)");
         if (sims[i]->p.device != sims[0]->p.device) return fail(LB_ERR_ARG, "group members must share a device");
         if (sims[i]->stepping) return fail(LB_ERR_STATE, "lb_run_group inside a split step");
-        if (sims[i]->H < 4) return fail(LB_ERR_ARG, "a slab needs at least 4 rows");
+        if (sims[i]->H < 6) return fail(LB_ERR_ARG, "a slab needs at least 6 rows");
     }
     if (n_steps == 0) return LB_OK;
     DeviceGuard guard(sims[0]->p.device);
@@ -1802,13 +1821,15 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_halo, 0));
         HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_halo, 0));
     }
-    bool two = true;
-    for (int i = 0; i < count; ++i) two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i]);
-    for (int it = 0; it < n_steps;) {
-        const bool dbl = two && (n_steps - it) >= 2 && ((n_steps - it) % 2 == 0);
-        const int adv = dbl ? 2 : 1;
+    bool two = true, three = true;
+    for (int i = 0; i < count; ++i) {
+        two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i]);
+        three = three && (effective_variant(sims[i]) & 64) && step3_applicable(sims[i]);
+    }
+    for (int left = n_steps; left > 0;) {
+        const int adv = next_advance(three, two, left);
         for (int i = 0; i < count; ++i)
-            if ((rc = slab_step_launch(sims[i], dbl, it + adv >= n_steps))) return rc;
+            if ((rc = slab_step_launch(sims[i], adv, left == adv))) return rc;
         if ((rc = exchange(1, true))) return rc;
         for (int i = 0; i < count; ++i) {
             if ((rc = slab_step_join(sims[i]))) return rc;
@@ -1823,7 +1844,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
             }
         }
         for (int i = 0; i < count; ++i) sims[i]->cur ^= 1;
-        it += adv;
+        left -= adv;
     }
     for (int i = 0; i < count; ++i) {
         sims[i]->ghosts_valid = true;

@@ -122,19 +122,22 @@ int lb_step_interior(lb_sim *s, int write_macro);
 int lb_step_finish(lb_sim *s);
 /* Halo rows of the lattice that the NEXT step will read (= the one being written between
  * lb_step_boundary and lb_step_finish, the current one otherwise).  side 0 = south edge, 1 = north
- * edge.  A halo is lb_halo_floats() = 9*nx floats: nine row segments, two rows deep (what the
- * two-step kernel needs; a superset of what the single-step kernel reads):
- *   north edge out / south ghost in: row H-2 (resp. -2): k=2,5,6; row H-1 (resp. -1): k=0,1,3,2,5,6
- *   south edge out / north ghost in: row 0 (resp. H): k=0,1,3,4,7,8; row 1 (resp. H+1): k=4,7,8
+ * edge.  A halo is lb_halo_floats() = 18*nx floats: 18 row segments, three rows deep (what the
+ * three-step kernel needs; a superset of what the two- and single-step kernels read):
+ *   north edge out / south ghost in: row H-3 (resp. -3): k=2,5,6; row H-2 (resp. -2): k=0,1,3,2,5,6;
+ *                                    row H-1 (resp. -1): k=0..8
+ *   south edge out / north ghost in: row 0 (resp. H): k=0..8; row 1 (resp. H+1): k=0,1,3,4,7,8;
+ *                                    row 2 (resp. H+2): k=4,7,8
  * export copies the edge rows into buf, import copies buf into the ghost rows; the buffer a slab
  * exports on its north side is what its northern neighbour imports on its south side.  buf may be
  * host or device memory (hipMemcpyDefault). */
 int lb_halo_floats(lb_sim *s);
 int lb_halo_export(lb_sim *s, int side, void *buf);
 int lb_halo_import(lb_sim *s, int side, const void *buf);
-/* Obstacle-mask rows of the neighbouring slabs adjacent to this one ([nx] int32 each, NULL = no
- * solid cells): the two-step kernel recomputes the neighbours' edge rows and needs their masks. */
-int lb_set_mask_halo(lb_sim *s, const int32_t *south_row, const int32_t *north_row);
+/* Obstacle-mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-2, y0-1,
+ * north_rows = rows y0+H, y0+H+1 (each [2][nx] int32, NULL = no solid cells).  The multi-step kernels
+ * recompute the neighbours' edge rows and need their masks. */
+int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_rows);
 /* Advance `count` slab handles that tile one grid on ONE device in lock step, moving halos with
  * device-to-device copies: the multi-GPU schedule and kernels without a second GPU (verification). */
 int lb_run_group(lb_sim **sims, int count, int n_steps);

@@ -12,11 +12,13 @@ import numpy as np
 from oracle import oracle as O
 
 K_UP, K_DOWN = (2, 5, 6), (4, 7, 8)
-# halo buffer layout of include/lb_hip.h: 9 row segments, two rows deep.  This single-step CPU engine
-# only consumes the nearest ghost row's cy=+-1 links (segments 6..8 going north, 3..5 going south)
-# but produces and accepts the full format.
-NORTH_OUT = ((2, -2), (5, -2), (6, -2), (0, -1), (1, -1), (3, -1), (2, -1), (5, -1), (6, -1))   # rows from H
-SOUTH_OUT = ((0, 0), (1, 0), (3, 0), (4, 0), (7, 0), (8, 0), (4, 1), (7, 1), (8, 1))
+# halo buffer layout of include/lb_hip.h: 18 row segments, three rows deep.  This single-step CPU engine
+# only consumes the nearest ghost row's cy=+-1 links but produces and accepts the full format.
+NORTH_OUT = ((2, -3), (5, -3), (6, -3), (0, -2), (1, -2), (3, -2), (2, -2), (5, -2), (6, -2),
+             (0, -1), (1, -1), (2, -1), (3, -1), (4, -1), (5, -1), (6, -1), (7, -1), (8, -1))      # rows from H
+SOUTH_OUT = ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (8, 0),
+             (0, 1), (1, 1), (3, 1), (4, 1), (7, 1), (8, 1), (4, 2), (7, 2), (8, 2))
+NSEG = 18
 
 
 class OracleSlabEngine(object):
@@ -80,8 +82,8 @@ class OracleSlabEngine(object):
     @staticmethod
     def _as_array(buf, n):
         if isinstance(buf, np.ndarray):
-            return buf.reshape(9, n)
-        return np.ctypeslib.as_array((ct.c_float * (9 * n)).from_address(int(buf))).reshape(9, n)
+            return buf.reshape(NSEG, n)
+        return np.ctypeslib.as_array((ct.c_float * (NSEG * n)).from_address(int(buf))).reshape(NSEG, n)
 
     def halo_export(self, side, buf):
         a, out = self._target(), self._as_array(buf, self.nx)
@@ -95,11 +97,11 @@ class OracleSlabEngine(object):
         # one ghost row per side here: keep the nearest-row segments only
         if side == 0:          # south ghost row -1  <- neighbour's NORTH_OUT entries with row -1
             for i, (k, row) in enumerate(NORTH_OUT):
-                if row == -1:
+                if row == -1 and k in K_UP:
                     a[k, 0] = src[i]
         else:                  # north ghost row H   <- neighbour's SOUTH_OUT entries with row 0
             for i, (k, row) in enumerate(SOUTH_OUT):
-                if row == 0:
+                if row == 0 and k in K_DOWN:
                     a[k, self.rows - 1] = src[i]
 
     def get_fields(self, which=("f", "u", "v", "rho")):

@@ -101,7 +101,7 @@ def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
     want = one.get_fields(("rho", "u", "v"))
     one.close()
     ring = LocalSlabRing(n, n, 1.7, 8, bc="periodic")
-    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 2
+    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 3
     for s, (y0, h) in zip(ring.slabs, ring.parts):
         s.init_equilibrium(*bench.shear_layer(n, n, y0, h))
     ring.run_in_library(steps)

@@ -226,7 +226,7 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
     copies instead of RCCL.  Must equal the undivided run bit for bit, for odd and even step counts."""
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing
-    nx, ny = 1000, 131
+    nx, ny = 1000, 137
     rng = np.random.default_rng(17)
     f0 = _random_state(rng, nx, ny)
     mask = rng.random((nx, ny)) < 0.03
@@ -237,13 +237,13 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
     one = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, **kw)
     one.set_variant(0)
     one.set_f(f0)
-    for variant in (33, 1):                       # two-step on slabs / single-step on slabs
+    for variant in (97, 33, 1):                   # three-step / two-step / single-step kernels on slabs
         ring = LocalSlabRing(nx, ny, 1.55, nslabs, bc=bc, obstacle_mask=mask, **kw)
         ring.set_variant(variant)
         ring.set_f(f0)
         ring.run_in_library(7)
         ring.run_in_library(4)
-        if variant == 33:
+        if variant == 97:
             one.run(11)
         a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
         for k in a:
@@ -253,7 +253,7 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
 def test_rccl_self_ring_two_step_with_mask(lbhip):
     """1-rank periodic ring over RCCL with the two-step slab kernel and an obstacle mask."""
     from LB_D2Q9.simulation import Simulation, comm_unique_id
-    nx, ny = 1024, 96
+    nx, ny = 1024, 160
     rng = np.random.default_rng(23)
     f0 = _random_state(rng, nx, ny)
     mask = rng.random((nx, ny)) < 0.02
@@ -262,7 +262,7 @@ def test_rccl_self_ring_two_step_with_mask(lbhip):
     one.set_f(f0)
     one.run(9)
     two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
-    two.set_variant(33)
+    two.set_variant(97)
     two.comm_init(comm_unique_id(), 0, 1)
     two.set_f(f0)
     two.run(5)
