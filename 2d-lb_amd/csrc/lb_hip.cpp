@@ -376,6 +376,17 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
 // 9 writes (+2 rows per segment), i.e. ~37 B per lattice update instead of 72.
 constexpr int STRIP_W = 256;       // cells per wave-row
 
+// Workgroup -> work item order of the marching kernels.  Workgroups are dealt round-robin over the 8
+// XCDs; transposing every 8x8 block of workgroup ids puts 8 consecutive items (= up to 32 adjacent
+// strips, one segment row at nx = 8192) on ONE XCD, so the cache line a strip shares with its
+// neighbour is fetched into one L2 instead of two (+1.8 % at 8192^2, profiles/r01_ablation.txt).
+// Only speed depends on it.
+__device__ __forceinline__ int xcd_item(int wg, int nwg)
+{
+    const int blk = wg & ~63, i = wg & 63;
+    return (blk + 64 <= nwg) ? blk + (i & 7) * 8 + (i >> 3) : wg;
+}
+
 // value of the cell one to the LEFT of each of my 4 cells (links with cx = +1); lane 0 takes the
 // strip's left halo cell
 __device__ __forceinline__ f4a from_left(f4a v, float halo, int lane)
@@ -454,7 +465,7 @@ template <int BC, bool MASK, bool MACRO, bool NTS>
 __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
-    const int item = blockIdx.x * 4 + threadIdx.y;
+    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
     const int sx = item % strips, sy = item / strips;
     if (sy >= nsegs) return;
     const int ya = a.row_begin + sy * a.seg_stride;
@@ -617,7 +628,7 @@ template <int BC, bool MASK, bool MACRO, bool NTS>
 __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
-    const int item = blockIdx.x * 4 + threadIdx.y;
+    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
     const int sx = item % strips, sy = item / strips;
     if (sy >= nsegs) return;
     const int ya = a.row_begin + sy * a.seg_stride;
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
         const bool have = step1_rows(a, r, rr, ym, yp);
         HaloLinks hi_new = {}, ho_new = {};
         if (have) {
-            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);
+            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);   // (non-temporal loads: no gain, measured)
             if (edge_lane) {
                 Cell c;
                 halo_cell_step1<BC, MASK>(a, hxi, rr, ym, yp, c);

@@ -71,7 +71,7 @@ def test_config4_shear_layer_8192_properties(lbhip):
     1 + 7.5e-9, so the reference arithmetic itself gains ~1e-8 x omega per step: bound 5e-8 per step)."""
     from LB_D2Q9.simulation import Simulation
     import bench
-    n, steps = 8192, 41                                  # odd: single-step and two-step kernels both run
+    n, steps = 8192, 1000                                # 1000 = 1 + 333 x 3: single-step and three-step kernels both run
     sim = Simulation(n, n, 1.7, bc="periodic")
     sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
     assert sim.steps_per_launch() == 3

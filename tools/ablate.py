@@ -22,14 +22,21 @@ print("%%.1f" %% (n * n * 20 / (best * 1e-3) / 1e6))
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8192
     lib = os.path.join(ROOT, "2d-lb_amd", "LB_D2Q9", "liblbhip_diag.so")
-    for variant, name in ((33, "k_step2"), (9, "k_step")):
+    configs = ((33, "k_step2"), (9, "k_step"))
+    if "--step3" in sys.argv:
+        configs = ((97, "k_step3"),)
+    for variant, name in configs:
         for diag, what in ((0, "full"), (1, "no step-1 collide"), (2, "no step-2 collide"), (3, "no collide at all"),
                            (4, "no stores"), (8, "aligned loads"), (11, "no collide, aligned loads"),
                            (7, "loads only"), (16, "aligned 256-cell strips"), (19, "aligned strips, no collide"),
-                           (17, "aligned strips, no step-1 collide")):
+                           (17, "aligned strips, no step-1 collide")) + \
+                (((32, "NT loads"), (64, "segment row per XCD"), (96, "NT loads + segment row per XCD"), (0, "full again"))
+                 if name == "k_step3" else ()):
             if name == "k_step" and diag in (2, 3, 4, 7, 11, 16, 19, 17):
+                continue
+            if name == "k_step3" and diag not in (0, 1, 32, 64, 96):
                 continue
             env = dict(os.environ, LB_LIB=lib, LB_DIAG=str(diag))
             out = subprocess.run([sys.executable, "-c", CHILD, str(n), str(variant)], env=env, capture_output=True, text=True)
