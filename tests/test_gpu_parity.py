@@ -351,3 +351,27 @@ def test_frame_dumper_on_pipe_flow_cylinder(lbhip, tmp_path):
     assert d.total_num_steps == 20 and d.I.shape == (sim.nx, sim.ny) and np.isfinite(d.I).all()
     assert np.array_equal(d.I, sim.get_fields()["u"])
     assert all(open(f, "rb").read(8) == b"\x89PNG\r\n\x1a\n" for f in d.frames_written)
+
+
+def test_pipe_flow_cylinder_docs_case_vs_oracle(lbhip, oracle):
+    """The reference's movie notebook case (docs/vortex_sheet_movie.ipynb: D=1, rho=1, nu=1, gradP=-100,
+    len=3, N=25, cylinder r=1/25 at (.75,.5), 62 steps per 0.1 t) through the drop-in class, against the
+    oracle's restatement of the same constructor with the same numpy RNG stream for init_pop."""
+    from LB_D2Q9.dimensionless import opencl_dim as lb
+    kw = dict(diameter=1., rho=1., viscosity=1., pressure_grad=-100., pipe_length=3., N=25)
+    cyl = dict(cylinder_center=[.75, .5], cylinder_radius=1. / 25)
+    np.random.seed(1234)
+    sim = lb.Pipe_Flow_Cylinder(verbose=False, **cyl, **kw)
+    np.random.seed(1234)
+    perturb = 1. + .001 * np.random.randn(sim.nx, sim.ny, 9)
+    ref = oracle.O2Sim.pipe_flow(perturb=perturb, **cyl, **kw)
+    assert (sim.nx, sim.ny) == (ref.nx, ref.ny) == (1876, 626)
+    assert sim.omega == ref.params["omega"] and sim.inlet_rho == ref.params["inlet_rho"]
+    assert np.array_equal(sim.obstacle_mask_host.astype(bool), ref.mask.T.astype(bool))
+    g0 = sim.get_fields()
+    assert np.array_equal(g0["f"], ref.get_fields()["f"])          # identical initial populations
+    sim.run(62)
+    ref.run(62)
+    assert_fields_close(sim.get_fields(), ref.get_fields(), TOLN)
+    phys = sim.get_physical_fields()
+    assert np.allclose(phys["u"], sim.get_fields()["u"] * (sim.delta_x / sim.delta_t) * (sim.L / sim.T))
