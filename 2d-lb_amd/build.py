@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "lb_hip.cpp")
+SRC = os.path.join(HERE, "csrc", "lb_hip.cpp")            # one translation unit; includes the csrc/*.h kernels
 HDR = os.path.join(os.path.dirname(HERE), "include", "lb_hip.h")
 OUT = os.path.join(HERE, "LB_D2Q9", "liblbhip.so")
 
@@ -23,8 +23,13 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
 
 
+def sources():
+    csrc = os.path.join(HERE, "csrc")
+    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".cpp", ".h"))] + [HDR, __file__]
+
+
 def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in (SRC, HDR, __file__))
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in sources())
 
 
 def build_diag():

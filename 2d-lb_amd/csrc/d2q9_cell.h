@@ -1,0 +1,171 @@
+// d2q9_cell.h -- device-side arithmetic of one D2Q9 cell (boundary rules, obstacle swap, moments,
+// equilibrium, BGK relaxation) and the vector load/store helpers shared by every kernel.
+// Included by lb_hip.cpp only (one translation unit); see the header comment there for the
+// reference lines each function follows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lb_hip.h"
+
+namespace {
+
+typedef float f4a __attribute__((ext_vector_type(4)));              // 16-byte aligned
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword aligned
+typedef unsigned char uc4 __attribute__((ext_vector_type(4)));
+
+// One cell's nine populations as named scalars (never an indexable array: the boundary rules
+// below assign different members on different branches, and an array would be demoted to scratch).
+struct Cell {
+    float f0, f1, f2, f3, f4, f5, f6, f7, f8;
+};
+
+// D2Q9.cl:173-261 (move_bcs) for one cell, float arithmetic (the reference's double literals
+// are not mimicked: SURVEY.md Appendix D.1 measured that difference at <= 1e-6 over 5000 steps).
+__device__ __forceinline__ void bc_pipe_cell(Cell &c, int x, int y, int nx, int ny, float rin, float rout)
+{
+    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
+    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    if (w && !s && !n) {                                   // inlet :198-203
+        const float uu = -((f0 + f2 + 2.f * f3 + f4 + 2.f * f6 + 2.f * f7 - rin) / rin);
+        const float a = (1.f / 6.f) * uu * rin;
+        c.f1 = f3 + (2.f / 3.f) * rin * uu;
+        c.f5 = -.5f * f2 + .5f * f4 + f7 + a;
+        c.f8 = .5f * f2 - .5f * f4 + f6 + a;
+    }
+    if (e && !s && !n) {                                   // outlet :205-210
+        const float uu = -1.f + (f0 + 2.f * f1 + f2 + f4 + 2.f * f5 + 2.f * f8) / rout;
+        const float a = (1.f / 6.f) * uu * rout;
+        c.f3 = f1 - (2.f / 3.f) * rout * uu;
+        c.f6 = -.5f * f2 + .5f * f4 + f8 - a;
+        c.f7 = .5f * f2 - .5f * f4 + f5 - a;
+    }
+    if (n && !w && !e) {                                   // north wall :213-217
+        c.f4 = f2;
+        c.f8 = .5f * (-f1 + f3 + 2.f * f6);
+        c.f7 = .5f * (f1 - f3 + 2.f * f5);
+    }
+    if (s && !w && !e) {                                   // south wall :219-223
+        c.f2 = f4;
+        c.f6 = .5f * (f1 - f3 + 2.f * f8);
+        c.f5 = .5f * (-f1 + f3 + 2.f * f7);
+    }
+    if (w && s) {                                          // corners :228-259
+        const float t = .5f * (-f0 - 2.f * f3 - 2.f * f4 - 2.f * f7 + rin);
+        c.f1 = f3; c.f2 = f4; c.f5 = f7; c.f6 = t; c.f8 = t;
+    }
+    if (w && n) {
+        const float t = .5f * (-f0 - 2.f * f2 - 2.f * f3 - 2.f * f6 + rin);
+        c.f1 = f3; c.f4 = f2; c.f8 = f6; c.f5 = t; c.f7 = t;
+    }
+    if (e && s) {
+        const float t = .5f * (-f0 - 2.f * f1 - 2.f * f4 - 2.f * f8 + rout);
+        c.f3 = f1; c.f2 = f4; c.f6 = f8; c.f5 = t; c.f7 = t;
+    }
+    if (e && n) {
+        const float t = .5f * (-f0 - 2.f * f1 - 2.f * f2 - 2.f * f5 + rout);
+        c.f3 = f1; c.f4 = f2; c.f7 = f5; c.f6 = t; c.f8 = t;
+    }
+}
+
+// Build-defined lid-driven cavity closure, oracle/d2q9_oracle.c o2_bc_cavity.
+__device__ __forceinline__ void bc_cavity_cell(Cell &c, int x, int y, int nx, int ny, float lid, float rho0)
+{
+    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
+    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    if (n && !w && !e) {
+        const float rw = f0 + f1 + f3 + 2.f * (f2 + f5 + f6);
+        c.f4 = f2;
+        c.f7 = 0.5f * (f1 - f3 + 2.f * f5) - 0.5f * rw * lid;
+        c.f8 = 0.5f * (-f1 + f3 + 2.f * f6) + 0.5f * rw * lid;
+    }
+    if (s && !w && !e) {
+        c.f2 = f4;
+        c.f6 = 0.5f * (f1 - f3 + 2.f * f8);
+        c.f5 = 0.5f * (-f1 + f3 + 2.f * f7);
+    }
+    if (w && !s && !n) {
+        c.f1 = f3;
+        c.f5 = 0.5f * (-f2 + f4 + 2.f * f7);
+        c.f8 = 0.5f * (f2 - f4 + 2.f * f6);
+    }
+    if (e && !s && !n) {
+        c.f3 = f1;
+        c.f6 = 0.5f * (-f2 + f4 + 2.f * f8);
+        c.f7 = 0.5f * (f2 - f4 + 2.f * f5);
+    }
+    if (w && s) {
+        const float t = 0.5f * (-f0 - 2.f * f3 - 2.f * f4 - 2.f * f7 + rho0);
+        c.f1 = f3; c.f2 = f4; c.f5 = f7; c.f6 = t; c.f8 = t;
+    }
+    if (w && n) {
+        const float t = 0.5f * (-f0 - 2.f * f2 - 2.f * f3 - 2.f * f6 + rho0);
+        c.f1 = f3; c.f4 = f2; c.f8 = f6; c.f5 = t; c.f7 = t;
+    }
+    if (e && s) {
+        const float t = 0.5f * (-f0 - 2.f * f1 - 2.f * f4 - 2.f * f8 + rho0);
+        c.f3 = f1; c.f2 = f4; c.f6 = f8; c.f5 = t; c.f7 = t;
+    }
+    if (e && n) {
+        const float t = 0.5f * (-f0 - 2.f * f1 - 2.f * f2 - 2.f * f5 + rho0);
+        c.f3 = f1; c.f4 = f2; c.f7 = f5; c.f6 = t; c.f8 = t;
+    }
+}
+
+// D2Q9.cl:398-433 (bounceback_in_obstacle): exchange opposite links on a solid cell.
+__device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
+{
+    const float f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    c.f1 = solid ? f3 : f1; c.f3 = solid ? f1 : f3;
+    c.f2 = solid ? f4 : f2; c.f4 = solid ? f2 : f4;
+    c.f5 = solid ? f7 : f5; c.f7 = solid ? f5 : f7;
+    c.f6 = solid ? f8 : f6; c.f8 = solid ? f6 : f8;
+}
+
+// Moments (D2Q9.cl:92-97), equilibrium (:55-60) and BGK relaxation (:119) of one cell.
+// The products keep the reference's structure -- feq_k = (w_k rho) * inner_k with the float32
+// weights, then f (1-omega) + omega feq -- because the rounding of the weights is a *systematic*
+// mass bias (sum_k fl(w_k) = 1 + 7.5e-9); folding omega into the weights would change that bias
+// and make rho drift away from the reference's by ~3e-8 per step in a periodic box.
+__device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
+{
+    rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
+    const float inv = 1.0f / rho;
+    ux = (c.f1 - c.f3 + c.f5 - c.f6 - c.f7 + c.f8) * inv;
+    uy = (c.f5 + c.f2 + c.f6 - c.f7 - c.f4 - c.f8) * inv;
+    const float usq = ux * ux + uy * uy;
+    const float base = 1.f - 1.5f * usq;
+    const float keep = 1.f - omega;
+    const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+    // inner_k = 1 + 3 cu + 4.5 cu^2 - 1.5 usq
+    c.f0 = c.f0 * keep + omega * (r0 * base);
+    c.f1 = c.f1 * keep + omega * (r1 * (base + 3.f * ux + 4.5f * ux * ux));
+    c.f3 = c.f3 * keep + omega * (r1 * (base - 3.f * ux + 4.5f * ux * ux));
+    c.f2 = c.f2 * keep + omega * (r1 * (base + 3.f * uy + 4.5f * uy * uy));
+    c.f4 = c.f4 * keep + omega * (r1 * (base - 3.f * uy + 4.5f * uy * uy));
+    const float p = ux + uy, m = ux - uy;
+    c.f5 = c.f5 * keep + omega * (r2 * (base + 3.f * p + 4.5f * p * p));
+    c.f7 = c.f7 * keep + omega * (r2 * (base - 3.f * p + 4.5f * p * p));
+    c.f8 = c.f8 * keep + omega * (r2 * (base + 3.f * m + 4.5f * m * m));
+    c.f6 = c.f6 * keep + omega * (r2 * (base - 3.f * m + 4.5f * m * m));
+}
+
+template <bool NT>
+__device__ __forceinline__ f4a load4(const float *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4a *>(p));
+    return *reinterpret_cast<const f4a *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ f4a load4u(const float *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
+    return *reinterpret_cast<const f4u *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void store4(float *p, f4a v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4a *>(p));
+    else *reinterpret_cast<f4a *>(p) = v;
+}
+
+}  // namespace

@@ -1,0 +1,558 @@
+// kernels_fused.h -- the hot path: k_step (one time step per launch), k_step2 / k_step3 (two / three
+// time steps per launch: wave-private strips marching in y with register windows) and the float4
+// copy used for calibration.  Included by lb_hip.cpp only.
+#pragma once
+#include "d2q9_cell.h"
+
+namespace {
+
+struct StepArgs {
+    const float *src;      // plane 0, row 0, x 0 of the lattice being read
+    float *dst;            // same element of the lattice being written
+    const uint8_t *mask;   // [H][pitch] or nullptr
+    float *rho, *u, *v;    // [H][pitch]
+    long long plane;       // plane stride, floats
+    int pitch;             // row pitch, floats
+    int nx, ny;            // global grid
+    int y0, h;             // slab origin / height
+    int row_begin, row_step, row_count;  // local rows visited: row_begin + i*row_step, i < row_count
+    int wrap_y;            // periodic in y inside one slab: wrap the source rows locally
+    int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
+    int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
+    int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
+    float omega, rho_in, rho_out, lid_u, rho0;
+};
+
+// Pull-stream gather for 4 consecutive cells (x4..x4+3) of local row yl: q[k] = f_k at (x - cx_k,
+// y - cy_k) of the source lattice.  ym / yp are the source rows of the cy=+1 / cy=-1 links (already
+// wrapped by the caller where the box is periodic in y within this slab).
+template <int BC, bool MASK, bool NTL>
+__device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk)
+{
+    const long long P = a.pitch, S = a.plane;
+    const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
+    const float *s = a.src;
+#ifdef LB_DIAG
+    if (a.diag & 8) {                      // timing only: all nine planes read aligned (wrong results)
+        q[0] = load4<NTL>(s + o0);          q[1] = load4<NTL>(s + 1 * S + o0);  q[2] = load4<NTL>(s + 2 * S + om);
+        q[3] = load4<NTL>(s + 3 * S + o0);  q[4] = load4<NTL>(s + 4 * S + op);  q[5] = load4<NTL>(s + 5 * S + om);
+        q[6] = load4<NTL>(s + 6 * S + om);  q[7] = load4<NTL>(s + 7 * S + op);  q[8] = load4<NTL>(s + 8 * S + op);
+        mk = uc4{0, 0, 0, 0};
+        return;
+    }
+#endif
+    q[0] = load4<NTL>(s + o0);
+    q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
+    q[2] = load4<NTL>(s + 2 * S + om);
+    q[3] = load4u<NTL>(s + 3 * S + o0 + 1);
+    q[4] = load4<NTL>(s + 4 * S + op);
+    q[5] = load4u<NTL>(s + 5 * S + om - 1);
+    q[6] = load4u<NTL>(s + 6 * S + om + 1);
+    q[7] = load4u<NTL>(s + 7 * S + op + 1);
+    q[8] = load4u<NTL>(s + 8 * S + op - 1);
+    mk = uc4{0, 0, 0, 0};
+    if (MASK) mk = *reinterpret_cast<const uc4 *>(a.mask + o0);
+    if (BC == LB_BC_PERIODIC) {
+        // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
+        // row padding (wave-divergent, one lane per row).
+        if (x4 == 0) {
+            q[1].x = s[1 * S + (long long)yl * P + a.nx - 1];
+            q[5].x = s[5 * S + (long long)ym * P + a.nx - 1];
+            q[8].x = s[8 * S + (long long)yp * P + a.nx - 1];
+        }
+        const int c = a.nx - 1 - x4;
+        if (c >= 0 && c < 4) {
+            const float w3 = s[3 * S + (long long)yl * P], w6 = s[6 * S + (long long)ym * P],
+                        w7 = s[7 * S + (long long)yp * P];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == c) { q[3][j] = w3; q[6][j] = w6; q[7][j] = w7; }
+        }
+    }
+}
+
+// Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.
+template <int BC, bool MASK>
+__device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
+                                            f4a &u4, f4a &v4)
+{
+    const bool edge = (BC != LB_BC_PERIODIC) &&
+                      (yg == 0 || yg == a.ny - 1 || x4 == 0 || (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+        if (edge) {
+            if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
+        }
+        if (MASK) bounce_cell(c, mk[j] != 0);
+        float rho, ux, uy;
+        relax_cell(c, a.omega, rho, ux, uy);
+        r4[j] = rho; u4[j] = ux; v4[j] = uy;
+        q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
+        q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+    }
+}
+
+// The hot kernel: one full time step for 4 consecutive cells of one row per lane.
+//   pull-stream (move+copy_buffer) -> boundary rule (move_bcs) -> obstacle swap
+//   (bounceback_in_obstacle) -> moments (update_hydro) -> equilibrium (update_feq) ->
+//   relaxation (collide_particles), then 9 aligned 16-byte stores.
+// Launch: blockDim = (64, RW): a wave covers 256 cells of one row, RW rows per block.
+//
+// XCD-aware tile order (XCD = true): workgroups are dealt round-robin over the 8 XCDs, each with its
+// own L2.  A misaligned 1 KiB wave read touches 9 cache lines, the 9th shared with the wave to its
+// right; if that neighbour runs on another XCD the line is fetched from HBM twice (measured: +8.3 %
+// FETCH_SIZE = 6/9 planes x 1/8).  Remapping the linear workgroup id so that every XCD sweeps its own
+// contiguous band of rows keeps x-neighbours on one L2.  Only speed depends on it, never results.
+template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS, bool XCD>
+__global__ __launch_bounds__(256) void k_step(const StepArgs a)
+{
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (XCD) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned per = total >> 3;                 // tiles per XCD (tail handled below)
+        if (lin < (per << 3)) {
+            const unsigned t = (lin & 7u) * per + (lin >> 3);
+            bx = t % gridDim.x;
+            by = t / gridDim.x;
+        }
+    }
+    const int x4 = (bx * blockDim.x + threadIdx.x) * 4;
+    const int ri = by * blockDim.y + threadIdx.y;
+    if (x4 >= a.pitch || ri >= a.row_count) return;
+    const int yl = a.row_begin + ri * a.row_step;
+    const int yg = a.y0 + yl;
+    int ym = yl - 1, yp = yl + 1;          // source rows of the cy=+1 / cy=-1 links
+    if (a.wrap_y) {
+        if (ym < 0) ym = a.h - 1;
+        if (yp >= a.h) yp = 0;
+    }
+    const long long o0 = (long long)yl * a.pitch + x4;
+    f4a q[9], r4, u4, v4;
+    uc4 mk;
+    gather_row<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk);
+#ifdef LB_DIAG
+    if (!(a.diag & 1))
+#endif
+    collide_row<BC, MASK>(a, x4, yg, q, mk, r4, u4, v4);
+
+    const long long S = a.plane;
+    float *d = a.dst + o0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, q[k]);
+    if (MACRO) {
+        store4<false>(a.rho + o0, r4);
+        store4<false>(a.u + o0, u4);
+        store4<false>(a.v + o0, v4);
+    }
+}
+
+// ---- two time steps per pass ------------------------------------------------------------------
+// Temporal blocking without LDS.  A wave owns a strip of 256 cells (64 lanes x 4, 1 KiB-aligned) and
+// marches up a segment of rows.  For every row r it computes step 1 (gather from the source lattice +
+// collide: exactly gather_row/collide_row above) and keeps the result in registers; the second step of
+// row y = r-1 needs, per link k, the step-1 value of ONE row only (cy=-1: row r, just computed; cy=0:
+// row r-1; cy=+1: row r-2), so a register window of 3+6 float4 holds everything, and the x-neighbour
+// a link comes from is one element to the left/right = a 1-lane shuffle.  The two cells just outside
+// the strip (x0-1 and x0+256) are recomputed by the edge lanes 0 and 63 as a fifth, scalar cell, so
+// waves never exchange anything, every strip is a whole number of cache lines and every store is a
+// full aligned 1 KiB.  (A first version used lanes 0/63 as halo lanes and advanced strips by 248
+// cells: simpler, but its 992-byte store segments and 34-instead-of-32 strips cost 10-18 %:
+// tools/ablate.py, profiles/r01_ablation.txt.)  HBM traffic per two updates of a cell: 9 reads +
+// 9 writes (+2 rows per segment), i.e. ~37 B per lattice update instead of 72.
+constexpr int STRIP_W = 256;       // cells per wave-row
+
+// Workgroup -> work item order of the marching kernels.  Workgroups are dealt round-robin over the 8
+// XCDs; transposing every 8x8 block of workgroup ids puts 8 consecutive items (= up to 32 adjacent
+// strips, one segment row at nx = 8192) on ONE XCD, so the cache line a strip shares with its
+// neighbour is fetched into one L2 instead of two (+1.8 % at 8192^2, profiles/r01_ablation.txt).
+// Only speed depends on it.
+__device__ __forceinline__ int xcd_item(int wg, int nwg)
+{
+    const int blk = wg & ~63, i = wg & 63;
+    return (blk + 64 <= nwg) ? blk + (i & 7) * 8 + (i >> 3) : wg;
+}
+
+// value of the cell one to the LEFT of each of my 4 cells (links with cx = +1); lane 0 takes the
+// strip's left halo cell
+__device__ __forceinline__ f4a from_left(f4a v, float halo, int lane)
+{
+    float w = __shfl_up(v.w, 1);                // left lane's last cell
+    if (lane == 0) w = halo;
+    return f4a{w, v.x, v.y, v.z};
+}
+// value of the cell one to the RIGHT of each of my 4 cells (links with cx = -1); lane 63 takes the
+// strip's right halo cell
+__device__ __forceinline__ f4a from_right(f4a v, float halo, int lane)
+{
+    float x = __shfl_down(v.x, 1);              // right lane's first cell
+    if (lane == 63) x = halo;
+    return f4a{v.y, v.z, v.w, x};
+}
+
+// Resolve the rows step 1 of row r reads.  Rows -1 and H are wrapped (whole periodic grid on this
+// GPU), read from the ghost rows (slab with a neighbour on that side: rows -2..H+1 hold valid halo
+// data) or skipped: returns false when the row lies outside a wall (its values are never consumed
+// un-overwritten).
+__device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, int &ym, int &yp)
+{
+    rr = r; ym = r - 1; yp = r + 1;
+    if (a.wrap_y) {
+        rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
+        ym = rr - 1 < 0 ? a.h - 1 : rr - 1;
+        yp = rr + 1 >= a.h ? 0 : rr + 1;
+        return true;
+    }
+    if (r < 0) return a.ghost_s != 0;
+    if (r >= a.h) return a.ghost_n != 0;
+    return true;
+}
+
+// Step 1 of the single cell (hx, row rr): the strip's halo cell, executed by one edge lane.  Same
+// arithmetic as collide_row, so the value equals what the neighbouring strip computes for that cell.
+template <int BC, bool MASK>
+__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c)
+{
+    int xc = hx, xl = hx - 1, xg = hx + 1;
+    if (BC == LB_BC_PERIODIC) {
+        xc = hx < 0 ? hx + a.nx : (hx >= a.nx ? hx - a.nx : hx);
+        xl = xc - 1 < 0 ? a.nx - 1 : xc - 1;
+        xg = xc + 1 >= a.nx ? 0 : xc + 1;
+    } else if (hx < 0 || hx >= a.nx) {
+        c = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // outside the box: don't-care
+        return;
+    }
+    const long long P = a.pitch, S = a.plane;
+    const float *s = a.src;
+    const long long r0 = (long long)rr * P, rm = (long long)ym * P, rp = (long long)yp * P;
+    c.f0 = s[r0 + xc];
+    c.f1 = s[1 * S + r0 + xl];
+    c.f2 = s[2 * S + rm + xc];
+    c.f3 = s[3 * S + r0 + xg];
+    c.f4 = s[4 * S + rp + xc];
+    c.f5 = s[5 * S + rm + xl];
+    c.f6 = s[6 * S + rm + xg];
+    c.f7 = s[7 * S + rp + xg];
+    c.f8 = s[8 * S + rp + xl];
+    const int yg = a.y0 + rr;
+    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
+        if (BC == LB_BC_PIPE) bc_pipe_cell(c, xc, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, xc, yg, a.nx, a.ny, a.lid_u, a.rho0);
+    }
+    if (MASK) bounce_cell(c, a.mask[r0 + xc] != 0);
+    float rho, ux, uy;
+    relax_cell(c, a.omega, rho, ux, uy);
+}
+
+// Segment i of a launch covers output rows [row_begin + i*seg_stride, +seg_rows) clipped to row_end:
+// one contiguous range cut into equal shares (seg_stride == seg_rows), or the two 2-row edge bands
+// of a slab (seg_stride = H-2) that are computed first so their halo can travel early.
+template <int BC, bool MASK, bool MACRO, bool NTS>
+__global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+{
+    const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
+    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
+    const int sx = item % strips, sy = item / strips;
+    if (sy >= nsegs) return;
+    const int ya = a.row_begin + sy * a.seg_stride;
+    if (ya >= row_end) return;
+    const int yb = min(ya + seg_rows, row_end);
+    const int x0 = sx * STRIP_W;
+    const int xr = x0 + lane * 4;                       // true x of my first cell; may lie beyond nx
+    int x4 = xr;                                        // x used for addressing
+    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;   // duplicates of cells 0.. (nx % 4 == 0)
+    const bool store_lane = xr < a.nx;                  // lanes past the box compute don't-care values
+    const bool edge_lane = (lane == 0) || (lane == 63);
+    const int hx = (lane == 0) ? x0 - 1 : x0 + STRIP_W; // my halo cell (edge lanes only)
+    const long long S = a.plane;
+
+    f4a d0 = {}, d1 = {}, d3 = {};                      // step-1 links 0,1,3 of row r-1
+    f4a e2 = {}, e5 = {}, e6 = {};                      // step-1 links 2,5,6 of row r-1
+    f4a g2 = {}, g5 = {}, g6 = {};                      //                     of row r-2
+    // the same window for the halo cell; lane 0 keeps the links entering from the left (1,5,8),
+    // lane 63 those entering from the right (3,6,7)
+    float hd = 0.f, he = 0.f, hg = 0.f;                 // cy=0 link of row r-1; cy=+1 link of rows r-1, r-2
+    for (int r = ya - 1; r <= yb; ++r) {
+        // ---- step 1 of row r ---------------------------------------------------------------------
+        // (an explicit software prefetch of row r+1 was tried: +36 VGPR, -2 %; removing all
+        // arithmetic does not make the kernel faster either: the memory pipeline is what the waves
+        // wait for -- profiles/r01_ablation.txt)
+        f4a q[9], r4, u4, v4;
+        uc4 mk = {0, 0, 0, 0};
+        int rr, ym, yp;
+        const bool have = step1_rows(a, r, rr, ym, yp);
+        float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f;          // halo cell, row r: cy=0, cy=+1, cy=-1 link
+        if (have) {
+            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
+            if (edge_lane) {
+                Cell hc;
+                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, hc);
+                hq0 = lane == 0 ? hc.f1 : hc.f3;
+                hq1 = lane == 0 ? hc.f5 : hc.f6;
+                hq2 = lane == 0 ? hc.f8 : hc.f7;
+            }
+#ifdef LB_DIAG
+            if (!(a.diag & 1))
+#endif
+            collide_row<BC, MASK>(a, x4, a.y0 + rr, q, mk, r4, u4, v4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- step 2 of row y = r-1 from the register window ---------------------------------------
+        if (r >= ya + 1) {
+            const int y = r - 1;
+            f4a t[9];
+            t[0] = d0;
+            t[1] = from_left(d1, hd, lane);
+            t[3] = from_right(d3, hd, lane);
+            t[2] = g2;
+            t[5] = from_left(g5, hg, lane);
+            t[6] = from_right(g6, hg, lane);
+            t[4] = q[4];
+            t[7] = from_right(q[7], hq2, lane);
+            t[8] = from_left(q[8], hq2, lane);
+            const long long o = (long long)y * a.pitch + x4;
+            uc4 mk2 = {0, 0, 0, 0};
+            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + o);
+#ifdef LB_DIAG
+            if (!(a.diag & 2))
+#endif
+            collide_row<BC, MASK>(a, x4, a.y0 + y, t, mk2, r4, u4, v4);
+#ifdef LB_DIAG
+            if (a.diag & 4) {              // no stores: keep the values alive instead
+#pragma unroll
+                for (int k = 0; k < 9; ++k) asm volatile("" ::"v"(t[k]));
+            } else
+#endif
+            if (store_lane) {
+                float *d = a.dst + o;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
+                if (MACRO) {
+                    store4<false>(a.rho + o, r4);
+                    store4<false>(a.u + o, u4);
+                    store4<false>(a.v + o, v4);
+                }
+            }
+        }
+        // ---- slide the window -----------------------------------------------------------------------
+        g2 = e2; g5 = e5; g6 = e6;
+        e2 = q[2]; e5 = q[5]; e6 = q[6];
+        d0 = q[0]; d1 = q[1]; d3 = q[3];
+        hg = he; he = hq1; hd = hq0;
+    }
+}
+
+// ---- three time steps per pass ----------------------------------------------------------------
+// The two-step kernel is bound by HBM alone (removing all of its arithmetic does not speed it up), so
+// a third step per pass is free bytes: the same march with one more register window.  Per row r:
+// step 1 of row r (from memory), step 2 of row r-1 (from window 1), step 3 of row r-2 (from window 2,
+// stored).  The edge lanes now recompute two cells beyond the strip for step 1 (x0-2, x0-1 |
+// x0+256, x0+257) and one for step 2 (x0-1 | x0+256), all as scalar cells with the same arithmetic.
+// Whole-grid handles only (a slab would need a 3-deep halo).  ~25 B of HBM traffic per lattice update.
+
+// Post-collision links of one halo cell that later stages can ask for: the centre links (cx = 0) and
+// the three links that point toward the strip (cx = +1 on the left side, -1 on the right side),
+// each indexed by cy = 0, +1, -1.
+struct HaloLinks {
+    float c0, c2, c4;      // links 0, 2 (cy=+1), 4 (cy=-1)
+    float t0, tp, tm;      // toward-strip links with cy = 0, +1, -1: (1,5,8) on the left, (3,6,7) on the right
+};
+
+__device__ __forceinline__ HaloLinks halo_links(const Cell &c, bool left)
+{
+    HaloLinks h;
+    h.c0 = c.f0; h.c2 = c.f2; h.c4 = c.f4;
+    h.t0 = left ? c.f1 : c.f3;
+    h.tp = left ? c.f5 : c.f6;
+    h.tm = left ? c.f8 : c.f7;
+    return h;
+}
+
+// The 4-cell-wide register window one stage hands to the next (see k_step2).
+struct Window {
+    f4a d0, d1, d3;        // links 0,1,3 of the previous row
+    f4a e2, e5, e6;        // links 2,5,6 of the previous row
+    f4a g2, g5, g6;        //                 of the row before that
+};
+__device__ __forceinline__ void window_push(Window &w, const f4a (&q)[9])
+{
+    w.g2 = w.e2; w.g5 = w.e5; w.g6 = w.e6;
+    w.e2 = q[2]; w.e5 = q[5]; w.e6 = q[6];
+    w.d0 = q[0]; w.d1 = q[1]; w.d3 = q[3];
+}
+// The same for one halo cell (scalars): toward links always, centre links when a later stage
+// recomputes this cell.
+struct HaloWindow {
+    float t0_d, tp_e, tp_g;     // toward links: cy=0 of the previous row; cy=+1 of the previous row / the one before
+    float c0_d, c2_e, c2_g;     // centre links, same delays
+};
+__device__ __forceinline__ void halo_push(HaloWindow &w, const HaloLinks &h)
+{
+    w.tp_g = w.tp_e; w.tp_e = h.tp; w.t0_d = h.t0;
+    w.c2_g = w.c2_e; w.c2_e = h.c2; w.c0_d = h.c0;
+}
+
+// Gather for the next stage of row y from the previous stage's window `w`, its newest row `q`
+// (= row y+1) and the inner halo cell's toward links (window hw, newest row hnew).
+__device__ __forceinline__ void window_gather(const Window &w, const f4a (&q)[9], const HaloWindow &hw,
+                                              const HaloLinks &hnew, int lane, f4a (&t)[9])
+{
+    t[0] = w.d0;
+    t[1] = from_left(w.d1, hw.t0_d, lane);
+    t[3] = from_right(w.d3, hw.t0_d, lane);
+    t[2] = w.g2;
+    t[5] = from_left(w.g5, hw.tp_g, lane);
+    t[6] = from_right(w.g6, hw.tp_g, lane);
+    t[4] = q[4];
+    t[7] = from_right(q[7], hnew.tm, lane);
+    t[8] = from_left(q[8], hnew.tm, lane);
+}
+
+template <int BC, bool MASK, bool MACRO, bool NTS>
+__global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+{
+    const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
+    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
+    const int sx = item % strips, sy = item / strips;
+    if (sy >= nsegs) return;
+    const int ya = a.row_begin + sy * a.seg_stride;
+    if (ya >= row_end) return;
+    const int yb = min(ya + seg_rows, row_end);
+    const int x0 = sx * STRIP_W;
+    const int xr = x0 + lane * 4;
+    int x4 = xr;
+    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;
+    const bool store_lane = xr < a.nx;
+    const bool left = (lane == 0);
+    const bool edge_lane = left || (lane == 63);
+    const int hxi = left ? x0 - 1 : x0 + STRIP_W;       // inner halo cell (adjacent to the strip)
+    const int hxo = left ? x0 - 2 : x0 + STRIP_W + 1;   // outer halo cell
+    int hxi_c = hxi;                                    // inner halo cell, wrapped, for mask / boundary tests
+    if (BC == LB_BC_PERIODIC) hxi_c = hxi < 0 ? hxi + a.nx : (hxi >= a.nx ? hxi - a.nx : hxi);
+    const bool hxi_in = (BC == LB_BC_PERIODIC) || (hxi >= 0 && hxi < a.nx);
+    const long long S = a.plane;
+
+    Window w1 = {}, w2 = {};                            // step-1 / step-2 results of my 4 cells
+    HaloWindow hi1 = {}, ho1 = {}, hi2 = {};            // step 1 of the inner / outer halo cell, step 2 of the inner one
+    for (int r = ya - 2; r <= yb + 1; ++r) {
+        // ---- step 1 of row r (from memory) --------------------------------------------------------
+        f4a q1[9], r4, u4, v4;
+        uc4 mk = {0, 0, 0, 0};
+        int rr, ym, yp;
+        const bool have = step1_rows(a, r, rr, ym, yp);
+        HaloLinks hi_new = {}, ho_new = {};
+        if (have) {
+            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);   // (non-temporal loads: no gain, measured)
+            if (edge_lane) {
+                Cell c;
+                halo_cell_step1<BC, MASK>(a, hxi, rr, ym, yp, c);
+                hi_new = halo_links(c, left);
+                halo_cell_step1<BC, MASK>(a, hxo, rr, ym, yp, c);
+                ho_new = halo_links(c, left);
+            }
+            collide_row<BC, MASK>(a, x4, a.y0 + rr, q1, mk, r4, u4, v4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q1[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- step 2 of row r-1 (from window 1) ----------------------------------------------------
+        // (skipped while the window is still filling, r < ya: nothing consumes those rows and their
+        //  mask rows r-1 < ya-1 may not exist)
+        f4a q2[9];
+        HaloLinks h2_new = {};
+        if (r >= ya) {
+            int r2, r2m, r2p;
+            (void)step1_rows(a, r - 1, r2, r2m, r2p);   // r2 = local row of r-1 (wrapped when periodic)
+            window_gather(w1, q1, hi1, hi_new, lane, q2);
+            if (edge_lane) {
+                // the inner halo cell, step 2: centre links from itself, toward links from the outer halo
+                // cell, the remaining three from the strip's own edge cell
+                Cell c;
+                c.f0 = hi1.c0_d; c.f2 = hi1.c2_g; c.f4 = hi_new.c4;
+                const float a0 = ho1.t0_d, ap = ho1.tp_g, am = ho_new.tm;          // from the outer cell
+                const float b0 = left ? w1.d3.x : w1.d1.w;                         // from my edge cell: cy = 0
+                const float bp = left ? w1.g6.x : w1.g5.w;                         //                   cy = +1
+                const float bm = left ? q1[7].x : q1[8].w;                         //                   cy = -1
+                c.f1 = left ? a0 : b0; c.f3 = left ? b0 : a0;
+                c.f5 = left ? ap : bp; c.f6 = left ? bp : ap;
+                c.f8 = left ? am : bm; c.f7 = left ? bm : am;
+                if (hxi_in) {
+                    const int yg = a.y0 + r2;
+                    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
+                        if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+                        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
+                    }
+                    if (MASK) bounce_cell(c, a.mask[(long long)r2 * a.pitch + hxi_c] != 0);
+                    float rho, ux, uy;
+                    relax_cell(c, a.omega, rho, ux, uy);
+                }
+                h2_new = halo_links(c, left);
+            }
+            uc4 mk2 = {0, 0, 0, 0};
+            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + (long long)r2 * a.pitch + x4);
+            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk2, r4, u4, v4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- step 3 of row r-2 (from window 2), stored ---------------------------------------------
+        if (r >= ya + 2) {
+            int r3, r3m, r3p;
+            (void)step1_rows(a, r - 2, r3, r3m, r3p);
+            f4a t[9];
+            window_gather(w2, q2, hi2, h2_new, lane, t);
+            const long long o = (long long)r3 * a.pitch + x4;
+            uc4 mk3 = {0, 0, 0, 0};
+            if (MASK) mk3 = *reinterpret_cast<const uc4 *>(a.mask + o);
+            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk3, r4, u4, v4);
+            if (store_lane) {
+                float *d = a.dst + o;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
+                if (MACRO) {
+                    store4<false>(a.rho + o, r4);
+                    store4<false>(a.u + o, u4);
+                    store4<false>(a.v + o, v4);
+                }
+            }
+        }
+        // ---- slide the windows -------------------------------------------------------------------------
+        window_push(w1, q1);
+        window_push(w2, q2);
+        halo_push(hi1, hi_new);
+        halo_push(ho1, ho_new);
+        halo_push(hi2, h2_new);
+    }
+}
+
+// Calibration kernel: plain 16-byte-per-lane copy of n4 float4s.  Known byte count in the same
+// access shape as the fused step, used to (a) correct rocprofv3's FETCH_SIZE on gfx950 and
+// (b) measure the streaming ceiling of the device the bench runs on.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy4(const f4a *__restrict__ src, f4a *__restrict__ dst, long long n4)
+{
+    // 8 independent 16-byte loads in flight per lane (the fused step has 9)
+    const long long tile = 8LL * blockDim.x;
+    for (long long base = (long long)blockIdx.x * tile; base < n4; base += (long long)gridDim.x * tile) {
+        f4a v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            if (i < n4) v[j] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            if (i < n4) {
+                if (NT) __builtin_nontemporal_store(v[j], dst + i);
+                else dst[i] = v[j];
+            }
+        }
+    }
+}
+
+}  // namespace

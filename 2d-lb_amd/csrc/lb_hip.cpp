@@ -14,6 +14,8 @@
 // (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -3..-1 and
 // H..H+2 are ghost rows (slab halo, three deep for the three-step kernel / don't-care at walls), so
 // element (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+3)*pitch + x .
+// Source layout (one translation unit): d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2,
+// k_step3), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
 // 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
 #include <hip/hip_runtime.h>
@@ -55,844 +57,13 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                   \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-//  device code
-// ------------------------------------------------------------------------------------------
+}  // namespace
 
-typedef float f4a __attribute__((ext_vector_type(4)));              // 16-byte aligned
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword aligned
-typedef unsigned char uc4 __attribute__((ext_vector_type(4)));
+#include "d2q9_cell.h"
+#include "kernels_fused.h"
+#include "kernels_phases.h"
 
-struct StepArgs {
-    const float *src;      // plane 0, row 0, x 0 of the lattice being read
-    float *dst;            // same element of the lattice being written
-    const uint8_t *mask;   // [H][pitch] or nullptr
-    float *rho, *u, *v;    // [H][pitch]
-    long long plane;       // plane stride, floats
-    int pitch;             // row pitch, floats
-    int nx, ny;            // global grid
-    int y0, h;             // slab origin / height
-    int row_begin, row_step, row_count;  // local rows visited: row_begin + i*row_step, i < row_count
-    int wrap_y;            // periodic in y inside one slab: wrap the source rows locally
-    int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
-    int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
-    int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
-    float omega, rho_in, rho_out, lid_u, rho0;
-};
-
-// One cell's nine populations as named scalars (never an indexable array: the boundary rules
-// below assign different members on different branches, and an array would be demoted to scratch).
-struct Cell {
-    float f0, f1, f2, f3, f4, f5, f6, f7, f8;
-};
-
-// D2Q9.cl:173-261 (move_bcs) for one cell, float arithmetic (the reference's double literals
-// are not mimicked: SURVEY.md Appendix D.1 measured that difference at <= 1e-6 over 5000 steps).
-__device__ __forceinline__ void bc_pipe_cell(Cell &c, int x, int y, int nx, int ny, float rin, float rout)
-{
-    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
-    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
-    if (w && !s && !n) {                                   // inlet :198-203
-        const float uu = -((f0 + f2 + 2.f * f3 + f4 + 2.f * f6 + 2.f * f7 - rin) / rin);
-        const float a = (1.f / 6.f) * uu * rin;
-        c.f1 = f3 + (2.f / 3.f) * rin * uu;
-        c.f5 = -.5f * f2 + .5f * f4 + f7 + a;
-        c.f8 = .5f * f2 - .5f * f4 + f6 + a;
-    }
-    if (e && !s && !n) {                                   // outlet :205-210
-        const float uu = -1.f + (f0 + 2.f * f1 + f2 + f4 + 2.f * f5 + 2.f * f8) / rout;
-        const float a = (1.f / 6.f) * uu * rout;
-        c.f3 = f1 - (2.f / 3.f) * rout * uu;
-        c.f6 = -.5f * f2 + .5f * f4 + f8 - a;
-        c.f7 = .5f * f2 - .5f * f4 + f5 - a;
-    }
-    if (n && !w && !e) {                                   // north wall :213-217
-        c.f4 = f2;
-        c.f8 = .5f * (-f1 + f3 + 2.f * f6);
-        c.f7 = .5f * (f1 - f3 + 2.f * f5);
-    }
-    if (s && !w && !e) {                                   // south wall :219-223
-        c.f2 = f4;
-        c.f6 = .5f * (f1 - f3 + 2.f * f8);
-        c.f5 = .5f * (-f1 + f3 + 2.f * f7);
-    }
-    if (w && s) {                                          // corners :228-259
-        const float t = .5f * (-f0 - 2.f * f3 - 2.f * f4 - 2.f * f7 + rin);
-        c.f1 = f3; c.f2 = f4; c.f5 = f7; c.f6 = t; c.f8 = t;
-    }
-    if (w && n) {
-        const float t = .5f * (-f0 - 2.f * f2 - 2.f * f3 - 2.f * f6 + rin);
-        c.f1 = f3; c.f4 = f2; c.f8 = f6; c.f5 = t; c.f7 = t;
-    }
-    if (e && s) {
-        const float t = .5f * (-f0 - 2.f * f1 - 2.f * f4 - 2.f * f8 + rout);
-        c.f3 = f1; c.f2 = f4; c.f6 = f8; c.f5 = t; c.f7 = t;
-    }
-    if (e && n) {
-        const float t = .5f * (-f0 - 2.f * f1 - 2.f * f2 - 2.f * f5 + rout);
-        c.f3 = f1; c.f4 = f2; c.f7 = f5; c.f6 = t; c.f8 = t;
-    }
-}
-
-// Build-defined lid-driven cavity closure, oracle/d2q9_oracle.c o2_bc_cavity.
-__device__ __forceinline__ void bc_cavity_cell(Cell &c, int x, int y, int nx, int ny, float lid, float rho0)
-{
-    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
-    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
-    if (n && !w && !e) {
-        const float rw = f0 + f1 + f3 + 2.f * (f2 + f5 + f6);
-        c.f4 = f2;
-        c.f7 = 0.5f * (f1 - f3 + 2.f * f5) - 0.5f * rw * lid;
-        c.f8 = 0.5f * (-f1 + f3 + 2.f * f6) + 0.5f * rw * lid;
-    }
-    if (s && !w && !e) {
-        c.f2 = f4;
-        c.f6 = 0.5f * (f1 - f3 + 2.f * f8);
-        c.f5 = 0.5f * (-f1 + f3 + 2.f * f7);
-    }
-    if (w && !s && !n) {
-        c.f1 = f3;
-        c.f5 = 0.5f * (-f2 + f4 + 2.f * f7);
-        c.f8 = 0.5f * (f2 - f4 + 2.f * f6);
-    }
-    if (e && !s && !n) {
-        c.f3 = f1;
-        c.f6 = 0.5f * (-f2 + f4 + 2.f * f8);
-        c.f7 = 0.5f * (f2 - f4 + 2.f * f5);
-    }
-    if (w && s) {
-        const float t = 0.5f * (-f0 - 2.f * f3 - 2.f * f4 - 2.f * f7 + rho0);
-        c.f1 = f3; c.f2 = f4; c.f5 = f7; c.f6 = t; c.f8 = t;
-    }
-    if (w && n) {
-        const float t = 0.5f * (-f0 - 2.f * f2 - 2.f * f3 - 2.f * f6 + rho0);
-        c.f1 = f3; c.f4 = f2; c.f8 = f6; c.f5 = t; c.f7 = t;
-    }
-    if (e && s) {
-        const float t = 0.5f * (-f0 - 2.f * f1 - 2.f * f4 - 2.f * f8 + rho0);
-        c.f3 = f1; c.f2 = f4; c.f6 = f8; c.f5 = t; c.f7 = t;
-    }
-    if (e && n) {
-        const float t = 0.5f * (-f0 - 2.f * f1 - 2.f * f2 - 2.f * f5 + rho0);
-        c.f3 = f1; c.f4 = f2; c.f7 = f5; c.f6 = t; c.f8 = t;
-    }
-}
-
-// D2Q9.cl:398-433 (bounceback_in_obstacle): exchange opposite links on a solid cell.
-__device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
-{
-    const float f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
-    c.f1 = solid ? f3 : f1; c.f3 = solid ? f1 : f3;
-    c.f2 = solid ? f4 : f2; c.f4 = solid ? f2 : f4;
-    c.f5 = solid ? f7 : f5; c.f7 = solid ? f5 : f7;
-    c.f6 = solid ? f8 : f6; c.f8 = solid ? f6 : f8;
-}
-
-// Moments (D2Q9.cl:92-97), equilibrium (:55-60) and BGK relaxation (:119) of one cell.
-// The products keep the reference's structure -- feq_k = (w_k rho) * inner_k with the float32
-// weights, then f (1-omega) + omega feq -- because the rounding of the weights is a *systematic*
-// mass bias (sum_k fl(w_k) = 1 + 7.5e-9); folding omega into the weights would change that bias
-// and make rho drift away from the reference's by ~3e-8 per step in a periodic box.
-__device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
-{
-    rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
-    const float inv = 1.0f / rho;
-    ux = (c.f1 - c.f3 + c.f5 - c.f6 - c.f7 + c.f8) * inv;
-    uy = (c.f5 + c.f2 + c.f6 - c.f7 - c.f4 - c.f8) * inv;
-    const float usq = ux * ux + uy * uy;
-    const float base = 1.f - 1.5f * usq;
-    const float keep = 1.f - omega;
-    const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
-    // inner_k = 1 + 3 cu + 4.5 cu^2 - 1.5 usq
-    c.f0 = c.f0 * keep + omega * (r0 * base);
-    c.f1 = c.f1 * keep + omega * (r1 * (base + 3.f * ux + 4.5f * ux * ux));
-    c.f3 = c.f3 * keep + omega * (r1 * (base - 3.f * ux + 4.5f * ux * ux));
-    c.f2 = c.f2 * keep + omega * (r1 * (base + 3.f * uy + 4.5f * uy * uy));
-    c.f4 = c.f4 * keep + omega * (r1 * (base - 3.f * uy + 4.5f * uy * uy));
-    const float p = ux + uy, m = ux - uy;
-    c.f5 = c.f5 * keep + omega * (r2 * (base + 3.f * p + 4.5f * p * p));
-    c.f7 = c.f7 * keep + omega * (r2 * (base - 3.f * p + 4.5f * p * p));
-    c.f8 = c.f8 * keep + omega * (r2 * (base + 3.f * m + 4.5f * m * m));
-    c.f6 = c.f6 * keep + omega * (r2 * (base - 3.f * m + 4.5f * m * m));
-}
-
-template <bool NT>
-__device__ __forceinline__ f4a load4(const float *p)
-{
-    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4a *>(p));
-    return *reinterpret_cast<const f4a *>(p);
-}
-template <bool NT>
-__device__ __forceinline__ f4a load4u(const float *p)
-{
-    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4u *>(p));
-    return *reinterpret_cast<const f4u *>(p);
-}
-template <bool NT>
-__device__ __forceinline__ void store4(float *p, f4a v)
-{
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4a *>(p));
-    else *reinterpret_cast<f4a *>(p) = v;
-}
-
-// Pull-stream gather for 4 consecutive cells (x4..x4+3) of local row yl: q[k] = f_k at (x - cx_k,
-// y - cy_k) of the source lattice.  ym / yp are the source rows of the cy=+1 / cy=-1 links (already
-// wrapped by the caller where the box is periodic in y within this slab).
-template <int BC, bool MASK, bool NTL>
-__device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk)
-{
-    const long long P = a.pitch, S = a.plane;
-    const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
-    const float *s = a.src;
-#ifdef LB_DIAG
-    if (a.diag & 8) {                      // timing only: all nine planes read aligned (wrong results)
-        q[0] = load4<NTL>(s + o0);          q[1] = load4<NTL>(s + 1 * S + o0);  q[2] = load4<NTL>(s + 2 * S + om);
-        q[3] = load4<NTL>(s + 3 * S + o0);  q[4] = load4<NTL>(s + 4 * S + op);  q[5] = load4<NTL>(s + 5 * S + om);
-        q[6] = load4<NTL>(s + 6 * S + om);  q[7] = load4<NTL>(s + 7 * S + op);  q[8] = load4<NTL>(s + 8 * S + op);
-        mk = uc4{0, 0, 0, 0};
-        return;
-    }
-#endif
-    q[0] = load4<NTL>(s + o0);
-    q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
-    q[2] = load4<NTL>(s + 2 * S + om);
-    q[3] = load4u<NTL>(s + 3 * S + o0 + 1);
-    q[4] = load4<NTL>(s + 4 * S + op);
-    q[5] = load4u<NTL>(s + 5 * S + om - 1);
-    q[6] = load4u<NTL>(s + 6 * S + om + 1);
-    q[7] = load4u<NTL>(s + 7 * S + op + 1);
-    q[8] = load4u<NTL>(s + 8 * S + op - 1);
-    mk = uc4{0, 0, 0, 0};
-    if (MASK) mk = *reinterpret_cast<const uc4 *>(a.mask + o0);
-    if (BC == LB_BC_PERIODIC) {
-        // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
-        // row padding (wave-divergent, one lane per row).
-        if (x4 == 0) {
-            q[1].x = s[1 * S + (long long)yl * P + a.nx - 1];
-            q[5].x = s[5 * S + (long long)ym * P + a.nx - 1];
-            q[8].x = s[8 * S + (long long)yp * P + a.nx - 1];
-        }
-        const int c = a.nx - 1 - x4;
-        if (c >= 0 && c < 4) {
-            const float w3 = s[3 * S + (long long)yl * P], w6 = s[6 * S + (long long)ym * P],
-                        w7 = s[7 * S + (long long)yp * P];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j == c) { q[3][j] = w3; q[6][j] = w6; q[7][j] = w7; }
-        }
-    }
-}
-
-// Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.
-template <int BC, bool MASK>
-__device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
-                                            f4a &u4, f4a &v4)
-{
-    const bool edge = (BC != LB_BC_PERIODIC) &&
-                      (yg == 0 || yg == a.ny - 1 || x4 == 0 || (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-        if (edge) {
-            if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
-        }
-        if (MASK) bounce_cell(c, mk[j] != 0);
-        float rho, ux, uy;
-        relax_cell(c, a.omega, rho, ux, uy);
-        r4[j] = rho; u4[j] = ux; v4[j] = uy;
-        q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
-        q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
-    }
-}
-
-// The hot kernel: one full time step for 4 consecutive cells of one row per lane.
-//   pull-stream (move+copy_buffer) -> boundary rule (move_bcs) -> obstacle swap
-//   (bounceback_in_obstacle) -> moments (update_hydro) -> equilibrium (update_feq) ->
-//   relaxation (collide_particles), then 9 aligned 16-byte stores.
-// Launch: blockDim = (64, RW): a wave covers 256 cells of one row, RW rows per block.
-//
-// XCD-aware tile order (XCD = true): workgroups are dealt round-robin over the 8 XCDs, each with its
-// own L2.  A misaligned 1 KiB wave read touches 9 cache lines, the 9th shared with the wave to its
-// right; if that neighbour runs on another XCD the line is fetched from HBM twice (measured: +8.3 %
-// FETCH_SIZE = 6/9 planes x 1/8).  Remapping the linear workgroup id so that every XCD sweeps its own
-// contiguous band of rows keeps x-neighbours on one L2.  Only speed depends on it, never results.
-template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS, bool XCD>
-__global__ __launch_bounds__(256) void k_step(const StepArgs a)
-{
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD) {
-        const unsigned total = gridDim.x * gridDim.y;
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned per = total >> 3;                 // tiles per XCD (tail handled below)
-        if (lin < (per << 3)) {
-            const unsigned t = (lin & 7u) * per + (lin >> 3);
-            bx = t % gridDim.x;
-            by = t / gridDim.x;
-        }
-    }
-    const int x4 = (bx * blockDim.x + threadIdx.x) * 4;
-    const int ri = by * blockDim.y + threadIdx.y;
-    if (x4 >= a.pitch || ri >= a.row_count) return;
-    const int yl = a.row_begin + ri * a.row_step;
-    const int yg = a.y0 + yl;
-    int ym = yl - 1, yp = yl + 1;          // source rows of the cy=+1 / cy=-1 links
-    if (a.wrap_y) {
-        if (ym < 0) ym = a.h - 1;
-        if (yp >= a.h) yp = 0;
-    }
-    const long long o0 = (long long)yl * a.pitch + x4;
-    f4a q[9], r4, u4, v4;
-    uc4 mk;
-    gather_row<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk);
-#ifdef LB_DIAG
-    if (!(a.diag & 1))
-#endif
-    collide_row<BC, MASK>(a, x4, yg, q, mk, r4, u4, v4);
-
-    const long long S = a.plane;
-    float *d = a.dst + o0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, q[k]);
-    if (MACRO) {
-        store4<false>(a.rho + o0, r4);
-        store4<false>(a.u + o0, u4);
-        store4<false>(a.v + o0, v4);
-    }
-}
-
-// ---- two time steps per pass ------------------------------------------------------------------
-// Temporal blocking without LDS.  A wave owns a strip of 256 cells (64 lanes x 4, 1 KiB-aligned) and
-// marches up a segment of rows.  For every row r it computes step 1 (gather from the source lattice +
-// collide: exactly gather_row/collide_row above) and keeps the result in registers; the second step of
-// row y = r-1 needs, per link k, the step-1 value of ONE row only (cy=-1: row r, just computed; cy=0:
-// row r-1; cy=+1: row r-2), so a register window of 3+6 float4 holds everything, and the x-neighbour
-// a link comes from is one element to the left/right = a 1-lane shuffle.  The two cells just outside
-// the strip (x0-1 and x0+256) are recomputed by the edge lanes 0 and 63 as a fifth, scalar cell, so
-// waves never exchange anything, every strip is a whole number of cache lines and every store is a
-// full aligned 1 KiB.  (A first version used lanes 0/63 as halo lanes and advanced strips by 248
-// cells: simpler, but its 992-byte store segments and 34-instead-of-32 strips cost 10-18 %:
-// tools/ablate.py, profiles/r01_ablation.txt.)  HBM traffic per two updates of a cell: 9 reads +
-// 9 writes (+2 rows per segment), i.e. ~37 B per lattice update instead of 72.
-constexpr int STRIP_W = 256;       // cells per wave-row
-
-// Workgroup -> work item order of the marching kernels.  Workgroups are dealt round-robin over the 8
-// XCDs; transposing every 8x8 block of workgroup ids puts 8 consecutive items (= up to 32 adjacent
-// strips, one segment row at nx = 8192) on ONE XCD, so the cache line a strip shares with its
-// neighbour is fetched into one L2 instead of two (+1.8 % at 8192^2, profiles/r01_ablation.txt).
-// Only speed depends on it.
-__device__ __forceinline__ int xcd_item(int wg, int nwg)
-{
-    const int blk = wg & ~63, i = wg & 63;
-    return (blk + 64 <= nwg) ? blk + (i & 7) * 8 + (i >> 3) : wg;
-}
-
-// value of the cell one to the LEFT of each of my 4 cells (links with cx = +1); lane 0 takes the
-// strip's left halo cell
-__device__ __forceinline__ f4a from_left(f4a v, float halo, int lane)
-{
-    float w = __shfl_up(v.w, 1);                // left lane's last cell
-    if (lane == 0) w = halo;
-    return f4a{w, v.x, v.y, v.z};
-}
-// value of the cell one to the RIGHT of each of my 4 cells (links with cx = -1); lane 63 takes the
-// strip's right halo cell
-__device__ __forceinline__ f4a from_right(f4a v, float halo, int lane)
-{
-    float x = __shfl_down(v.x, 1);              // right lane's first cell
-    if (lane == 63) x = halo;
-    return f4a{v.y, v.z, v.w, x};
-}
-
-// Resolve the rows step 1 of row r reads.  Rows -1 and H are wrapped (whole periodic grid on this
-// GPU), read from the ghost rows (slab with a neighbour on that side: rows -2..H+1 hold valid halo
-// data) or skipped: returns false when the row lies outside a wall (its values are never consumed
-// un-overwritten).
-__device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, int &ym, int &yp)
-{
-    rr = r; ym = r - 1; yp = r + 1;
-    if (a.wrap_y) {
-        rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
-        ym = rr - 1 < 0 ? a.h - 1 : rr - 1;
-        yp = rr + 1 >= a.h ? 0 : rr + 1;
-        return true;
-    }
-    if (r < 0) return a.ghost_s != 0;
-    if (r >= a.h) return a.ghost_n != 0;
-    return true;
-}
-
-// Step 1 of the single cell (hx, row rr): the strip's halo cell, executed by one edge lane.  Same
-// arithmetic as collide_row, so the value equals what the neighbouring strip computes for that cell.
-template <int BC, bool MASK>
-__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c)
-{
-    int xc = hx, xl = hx - 1, xg = hx + 1;
-    if (BC == LB_BC_PERIODIC) {
-        xc = hx < 0 ? hx + a.nx : (hx >= a.nx ? hx - a.nx : hx);
-        xl = xc - 1 < 0 ? a.nx - 1 : xc - 1;
-        xg = xc + 1 >= a.nx ? 0 : xc + 1;
-    } else if (hx < 0 || hx >= a.nx) {
-        c = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // outside the box: don't-care
-        return;
-    }
-    const long long P = a.pitch, S = a.plane;
-    const float *s = a.src;
-    const long long r0 = (long long)rr * P, rm = (long long)ym * P, rp = (long long)yp * P;
-    c.f0 = s[r0 + xc];
-    c.f1 = s[1 * S + r0 + xl];
-    c.f2 = s[2 * S + rm + xc];
-    c.f3 = s[3 * S + r0 + xg];
-    c.f4 = s[4 * S + rp + xc];
-    c.f5 = s[5 * S + rm + xl];
-    c.f6 = s[6 * S + rm + xg];
-    c.f7 = s[7 * S + rp + xg];
-    c.f8 = s[8 * S + rp + xl];
-    const int yg = a.y0 + rr;
-    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
-        if (BC == LB_BC_PIPE) bc_pipe_cell(c, xc, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, xc, yg, a.nx, a.ny, a.lid_u, a.rho0);
-    }
-    if (MASK) bounce_cell(c, a.mask[r0 + xc] != 0);
-    float rho, ux, uy;
-    relax_cell(c, a.omega, rho, ux, uy);
-}
-
-// Segment i of a launch covers output rows [row_begin + i*seg_stride, +seg_rows) clipped to row_end:
-// one contiguous range cut into equal shares (seg_stride == seg_rows), or the two 2-row edge bands
-// of a slab (seg_stride = H-2) that are computed first so their halo can travel early.
-template <int BC, bool MASK, bool MACRO, bool NTS>
-__global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
-{
-    const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
-    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
-    const int sx = item % strips, sy = item / strips;
-    if (sy >= nsegs) return;
-    const int ya = a.row_begin + sy * a.seg_stride;
-    if (ya >= row_end) return;
-    const int yb = min(ya + seg_rows, row_end);
-    const int x0 = sx * STRIP_W;
-    const int xr = x0 + lane * 4;                       // true x of my first cell; may lie beyond nx
-    int x4 = xr;                                        // x used for addressing
-    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;   // duplicates of cells 0.. (nx % 4 == 0)
-    const bool store_lane = xr < a.nx;                  // lanes past the box compute don't-care values
-    const bool edge_lane = (lane == 0) || (lane == 63);
-    const int hx = (lane == 0) ? x0 - 1 : x0 + STRIP_W; // my halo cell (edge lanes only)
-    const long long S = a.plane;
-
-    f4a d0 = {}, d1 = {}, d3 = {};                      // step-1 links 0,1,3 of row r-1
-    f4a e2 = {}, e5 = {}, e6 = {};                      // step-1 links 2,5,6 of row r-1
-    f4a g2 = {}, g5 = {}, g6 = {};                      //                     of row r-2
-    // the same window for the halo cell; lane 0 keeps the links entering from the left (1,5,8),
-    // lane 63 those entering from the right (3,6,7)
-    float hd = 0.f, he = 0.f, hg = 0.f;                 // cy=0 link of row r-1; cy=+1 link of rows r-1, r-2
-    for (int r = ya - 1; r <= yb; ++r) {
-        // ---- step 1 of row r ---------------------------------------------------------------------
-        // (an explicit software prefetch of row r+1 was tried: +36 VGPR, -2 %; removing all
-        // arithmetic does not make the kernel faster either: the memory pipeline is what the waves
-        // wait for -- profiles/r01_ablation.txt)
-        f4a q[9], r4, u4, v4;
-        uc4 mk = {0, 0, 0, 0};
-        int rr, ym, yp;
-        const bool have = step1_rows(a, r, rr, ym, yp);
-        float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f;          // halo cell, row r: cy=0, cy=+1, cy=-1 link
-        if (have) {
-            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
-            if (edge_lane) {
-                Cell hc;
-                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, hc);
-                hq0 = lane == 0 ? hc.f1 : hc.f3;
-                hq1 = lane == 0 ? hc.f5 : hc.f6;
-                hq2 = lane == 0 ? hc.f8 : hc.f7;
-            }
-#ifdef LB_DIAG
-            if (!(a.diag & 1))
-#endif
-            collide_row<BC, MASK>(a, x4, a.y0 + rr, q, mk, r4, u4, v4);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) q[k] = f4a{0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- step 2 of row y = r-1 from the register window ---------------------------------------
-        if (r >= ya + 1) {
-            const int y = r - 1;
-            f4a t[9];
-            t[0] = d0;
-            t[1] = from_left(d1, hd, lane);
-            t[3] = from_right(d3, hd, lane);
-            t[2] = g2;
-            t[5] = from_left(g5, hg, lane);
-            t[6] = from_right(g6, hg, lane);
-            t[4] = q[4];
-            t[7] = from_right(q[7], hq2, lane);
-            t[8] = from_left(q[8], hq2, lane);
-            const long long o = (long long)y * a.pitch + x4;
-            uc4 mk2 = {0, 0, 0, 0};
-            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + o);
-#ifdef LB_DIAG
-            if (!(a.diag & 2))
-#endif
-            collide_row<BC, MASK>(a, x4, a.y0 + y, t, mk2, r4, u4, v4);
-#ifdef LB_DIAG
-            if (a.diag & 4) {              // no stores: keep the values alive instead
-#pragma unroll
-                for (int k = 0; k < 9; ++k) asm volatile("" ::"v"(t[k]));
-            } else
-#endif
-            if (store_lane) {
-                float *d = a.dst + o;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
-                if (MACRO) {
-                    store4<false>(a.rho + o, r4);
-                    store4<false>(a.u + o, u4);
-                    store4<false>(a.v + o, v4);
-                }
-            }
-        }
-        // ---- slide the window -----------------------------------------------------------------------
-        g2 = e2; g5 = e5; g6 = e6;
-        e2 = q[2]; e5 = q[5]; e6 = q[6];
-        d0 = q[0]; d1 = q[1]; d3 = q[3];
-        hg = he; he = hq1; hd = hq0;
-    }
-}
-
-// ---- three time steps per pass ----------------------------------------------------------------
-// The two-step kernel is bound by HBM alone (removing all of its arithmetic does not speed it up), so
-// a third step per pass is free bytes: the same march with one more register window.  Per row r:
-// step 1 of row r (from memory), step 2 of row r-1 (from window 1), step 3 of row r-2 (from window 2,
-// stored).  The edge lanes now recompute two cells beyond the strip for step 1 (x0-2, x0-1 |
-// x0+256, x0+257) and one for step 2 (x0-1 | x0+256), all as scalar cells with the same arithmetic.
-// Whole-grid handles only (a slab would need a 3-deep halo).  ~25 B of HBM traffic per lattice update.
-
-// Post-collision links of one halo cell that later stages can ask for: the centre links (cx = 0) and
-// the three links that point toward the strip (cx = +1 on the left side, -1 on the right side),
-// each indexed by cy = 0, +1, -1.
-struct HaloLinks {
-    float c0, c2, c4;      // links 0, 2 (cy=+1), 4 (cy=-1)
-    float t0, tp, tm;      // toward-strip links with cy = 0, +1, -1: (1,5,8) on the left, (3,6,7) on the right
-};
-
-__device__ __forceinline__ HaloLinks halo_links(const Cell &c, bool left)
-{
-    HaloLinks h;
-    h.c0 = c.f0; h.c2 = c.f2; h.c4 = c.f4;
-    h.t0 = left ? c.f1 : c.f3;
-    h.tp = left ? c.f5 : c.f6;
-    h.tm = left ? c.f8 : c.f7;
-    return h;
-}
-
-// The 4-cell-wide register window one stage hands to the next (see k_step2).
-struct Window {
-    f4a d0, d1, d3;        // links 0,1,3 of the previous row
-    f4a e2, e5, e6;        // links 2,5,6 of the previous row
-    f4a g2, g5, g6;        //                 of the row before that
-};
-__device__ __forceinline__ void window_push(Window &w, const f4a (&q)[9])
-{
-    w.g2 = w.e2; w.g5 = w.e5; w.g6 = w.e6;
-    w.e2 = q[2]; w.e5 = q[5]; w.e6 = q[6];
-    w.d0 = q[0]; w.d1 = q[1]; w.d3 = q[3];
-}
-// The same for one halo cell (scalars): toward links always, centre links when a later stage
-// recomputes this cell.
-struct HaloWindow {
-    float t0_d, tp_e, tp_g;     // toward links: cy=0 of the previous row; cy=+1 of the previous row / the one before
-    float c0_d, c2_e, c2_g;     // centre links, same delays
-};
-__device__ __forceinline__ void halo_push(HaloWindow &w, const HaloLinks &h)
-{
-    w.tp_g = w.tp_e; w.tp_e = h.tp; w.t0_d = h.t0;
-    w.c2_g = w.c2_e; w.c2_e = h.c2; w.c0_d = h.c0;
-}
-
-// Gather for the next stage of row y from the previous stage's window `w`, its newest row `q`
-// (= row y+1) and the inner halo cell's toward links (window hw, newest row hnew).
-__device__ __forceinline__ void window_gather(const Window &w, const f4a (&q)[9], const HaloWindow &hw,
-                                              const HaloLinks &hnew, int lane, f4a (&t)[9])
-{
-    t[0] = w.d0;
-    t[1] = from_left(w.d1, hw.t0_d, lane);
-    t[3] = from_right(w.d3, hw.t0_d, lane);
-    t[2] = w.g2;
-    t[5] = from_left(w.g5, hw.tp_g, lane);
-    t[6] = from_right(w.g6, hw.tp_g, lane);
-    t[4] = q[4];
-    t[7] = from_right(q[7], hnew.tm, lane);
-    t[8] = from_left(q[8], hnew.tm, lane);
-}
-
-template <int BC, bool MASK, bool MACRO, bool NTS>
-__global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
-{
-    const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
-    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
-    const int sx = item % strips, sy = item / strips;
-    if (sy >= nsegs) return;
-    const int ya = a.row_begin + sy * a.seg_stride;
-    if (ya >= row_end) return;
-    const int yb = min(ya + seg_rows, row_end);
-    const int x0 = sx * STRIP_W;
-    const int xr = x0 + lane * 4;
-    int x4 = xr;
-    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;
-    const bool store_lane = xr < a.nx;
-    const bool left = (lane == 0);
-    const bool edge_lane = left || (lane == 63);
-    const int hxi = left ? x0 - 1 : x0 + STRIP_W;       // inner halo cell (adjacent to the strip)
-    const int hxo = left ? x0 - 2 : x0 + STRIP_W + 1;   // outer halo cell
-    int hxi_c = hxi;                                    // inner halo cell, wrapped, for mask / boundary tests
-    if (BC == LB_BC_PERIODIC) hxi_c = hxi < 0 ? hxi + a.nx : (hxi >= a.nx ? hxi - a.nx : hxi);
-    const bool hxi_in = (BC == LB_BC_PERIODIC) || (hxi >= 0 && hxi < a.nx);
-    const long long S = a.plane;
-
-    Window w1 = {}, w2 = {};                            // step-1 / step-2 results of my 4 cells
-    HaloWindow hi1 = {}, ho1 = {}, hi2 = {};            // step 1 of the inner / outer halo cell, step 2 of the inner one
-    for (int r = ya - 2; r <= yb + 1; ++r) {
-        // ---- step 1 of row r (from memory) --------------------------------------------------------
-        f4a q1[9], r4, u4, v4;
-        uc4 mk = {0, 0, 0, 0};
-        int rr, ym, yp;
-        const bool have = step1_rows(a, r, rr, ym, yp);
-        HaloLinks hi_new = {}, ho_new = {};
-        if (have) {
-            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);   // (non-temporal loads: no gain, measured)
-            if (edge_lane) {
-                Cell c;
-                halo_cell_step1<BC, MASK>(a, hxi, rr, ym, yp, c);
-                hi_new = halo_links(c, left);
-                halo_cell_step1<BC, MASK>(a, hxo, rr, ym, yp, c);
-                ho_new = halo_links(c, left);
-            }
-            collide_row<BC, MASK>(a, x4, a.y0 + rr, q1, mk, r4, u4, v4);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) q1[k] = f4a{0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- step 2 of row r-1 (from window 1) ----------------------------------------------------
-        // (skipped while the window is still filling, r < ya: nothing consumes those rows and their
-        //  mask rows r-1 < ya-1 may not exist)
-        f4a q2[9];
-        HaloLinks h2_new = {};
-        if (r >= ya) {
-            int r2, r2m, r2p;
-            (void)step1_rows(a, r - 1, r2, r2m, r2p);   // r2 = local row of r-1 (wrapped when periodic)
-            window_gather(w1, q1, hi1, hi_new, lane, q2);
-            if (edge_lane) {
-                // the inner halo cell, step 2: centre links from itself, toward links from the outer halo
-                // cell, the remaining three from the strip's own edge cell
-                Cell c;
-                c.f0 = hi1.c0_d; c.f2 = hi1.c2_g; c.f4 = hi_new.c4;
-                const float a0 = ho1.t0_d, ap = ho1.tp_g, am = ho_new.tm;          // from the outer cell
-                const float b0 = left ? w1.d3.x : w1.d1.w;                         // from my edge cell: cy = 0
-                const float bp = left ? w1.g6.x : w1.g5.w;                         //                   cy = +1
-                const float bm = left ? q1[7].x : q1[8].w;                         //                   cy = -1
-                c.f1 = left ? a0 : b0; c.f3 = left ? b0 : a0;
-                c.f5 = left ? ap : bp; c.f6 = left ? bp : ap;
-                c.f8 = left ? am : bm; c.f7 = left ? bm : am;
-                if (hxi_in) {
-                    const int yg = a.y0 + r2;
-                    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
-                        if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-                        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
-                    }
-                    if (MASK) bounce_cell(c, a.mask[(long long)r2 * a.pitch + hxi_c] != 0);
-                    float rho, ux, uy;
-                    relax_cell(c, a.omega, rho, ux, uy);
-                }
-                h2_new = halo_links(c, left);
-            }
-            uc4 mk2 = {0, 0, 0, 0};
-            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + (long long)r2 * a.pitch + x4);
-            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk2, r4, u4, v4);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- step 3 of row r-2 (from window 2), stored ---------------------------------------------
-        if (r >= ya + 2) {
-            int r3, r3m, r3p;
-            (void)step1_rows(a, r - 2, r3, r3m, r3p);
-            f4a t[9];
-            window_gather(w2, q2, hi2, h2_new, lane, t);
-            const long long o = (long long)r3 * a.pitch + x4;
-            uc4 mk3 = {0, 0, 0, 0};
-            if (MASK) mk3 = *reinterpret_cast<const uc4 *>(a.mask + o);
-            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk3, r4, u4, v4);
-            if (store_lane) {
-                float *d = a.dst + o;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
-                if (MACRO) {
-                    store4<false>(a.rho + o, r4);
-                    store4<false>(a.u + o, u4);
-                    store4<false>(a.v + o, v4);
-                }
-            }
-        }
-        // ---- slide the windows -------------------------------------------------------------------------
-        window_push(w1, q1);
-        window_push(w2, q2);
-        halo_push(hi1, hi_new);
-        halo_push(ho1, ho_new);
-        halo_push(hi2, h2_new);
-    }
-}
-
-// Calibration kernel: plain 16-byte-per-lane copy of n4 float4s.  Known byte count in the same
-// access shape as the fused step, used to (a) correct rocprofv3's FETCH_SIZE on gfx950 and
-// (b) measure the streaming ceiling of the device the bench runs on.
-template <bool NT>
-__global__ __launch_bounds__(256) void k_copy4(const f4a *__restrict__ src, f4a *__restrict__ dst, long long n4)
-{
-    // 8 independent 16-byte loads in flight per lane (the fused step has 9)
-    const long long tile = 8LL * blockDim.x;
-    for (long long base = (long long)blockIdx.x * tile; base < n4; base += (long long)gridDim.x * tile) {
-        f4a v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
-            if (i < n4) v[j] = NT ? __builtin_nontemporal_load(src + i) : src[i];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
-            if (i < n4) {
-                if (NT) __builtin_nontemporal_store(v[j], dst + i);
-                else dst[i] = v[j];
-            }
-        }
-    }
-}
-
-// ---- un-fused kernels: the reference's phases one by one (API / test parity) ----------------
-struct PhaseArgs {
-    float *f, *fs, *feq;   // plane 0, row 0, x 0
-    float *rho, *u, *v;
-    const uint8_t *mask;
-    long long plane;
-    int pitch, nx, ny, bc;
-    float omega, rho_in, rho_out, lid_u, rho0;
-};
-
-__device__ __constant__ int d_cx[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
-__device__ __constant__ int d_cy[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
-__device__ __constant__ float d_w[9] = {4.f / 9.f,  1.f / 9.f,  1.f / 9.f,  1.f / 9.f, 1.f / 9.f,
-                                        1.f / 36.f, 1.f / 36.f, 1.f / 36.f, 1.f / 36.f};
-
-// D2Q9.cl:139-171 in pull form: a cell whose upstream neighbour is outside the box keeps the
-// stale content of f_streamed, exactly like the reference's dropped push.
-__global__ void k_move(const PhaseArgs a)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
-    if (x >= a.nx) return;
-    int sx = x - d_cx[k], sy = y - d_cy[k];
-    if (a.bc == LB_BC_PERIODIC) {
-        sx = (sx + a.nx) % a.nx;
-        sy = (sy + a.ny) % a.ny;
-    }
-    if (sx < 0 || sx >= a.nx || sy < 0 || sy >= a.ny) return;
-    a.fs[k * a.plane + (long long)y * a.pitch + x] = a.f[k * a.plane + (long long)sy * a.pitch + sx];
-}
-
-__global__ void k_bcs(const PhaseArgs a)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x, S = a.plane;
-    float *f = a.f + o;
-    Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
-    if (x == 0 || x == a.nx - 1 || y == 0 || y == a.ny - 1) {
-        if (a.bc == LB_BC_PIPE) bc_pipe_cell(c, x, y, a.nx, a.ny, a.rho_in, a.rho_out);
-        if (a.bc == LB_BC_CAVITY) bc_cavity_cell(c, x, y, a.nx, a.ny, a.lid_u, a.rho0);
-    }
-    bounce_cell(c, a.mask && a.mask[o]);
-    f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
-    f[5 * S] = c.f5; f[6 * S] = c.f6; f[7 * S] = c.f7; f[8 * S] = c.f8;
-}
-
-__global__ void k_hydro(const PhaseArgs a)   // D2Q9.cl:67-100
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x;
-    float f[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) f[k] = a.f[k * a.plane + o];
-    const float rho = f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + f[8];
-    const float inv = 1.0f / rho;
-    a.rho[o] = rho;
-    a.u[o] = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) * inv;
-    a.v[o] = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
-}
-
-__global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x;
-    const float rho = a.rho[o], ux = a.u[o], uy = a.v[o];
-    const float usq = ux * ux + uy * uy;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const float cu = d_cx[k] * ux + d_cy[k] * uy;
-        a.feq[k * a.plane + o] = d_w[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
-    }
-}
-
-__global__ void k_collide(const PhaseArgs a) // D2Q9.cl:102-121
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
-    if (x >= a.nx) return;
-    const long long o = k * a.plane + (long long)y * a.pitch + x;
-    a.f[o] = a.f[o] * (1.f - a.omega) + a.omega * a.feq[o];
-}
-
-__global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x;
-    if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
-}
-
-// Halo pack / unpack: the 3-deep halo of one edge is 18 row segments scattered over the planes
-// (HaloSeg tables on the host side).  One tiny kernel gathers both edges into two contiguous buffers
-// (so that an exchange is one send + one receive per neighbour instead of eighteen), one scatters the
-// received buffers into the ghost rows.  Table t: 0 north-out, 1 south-out, 2 south-in, 3 north-in;
-// rows of the north tables count from row H.
-__device__ __constant__ int d_halo_k[4][18] = {
-    {2, 5, 6, 0, 1, 3, 2, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 3, 4, 7, 8, 4, 7, 8},
-    {2, 5, 6, 0, 1, 3, 2, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 3, 4, 7, 8, 4, 7, 8}};
-__device__ __constant__ int d_halo_row[4][18] = {
-    {-3, -3, -3, -2, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1},
-    {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2},
-    {-3, -3, -3, -2, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1},
-    {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2}};
-
-__global__ void k_halo_pack(const float *origin, long long plane, int pitch, int h, int nx, float *buf_n, float *buf_s)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
-    if (x >= nx) return;
-    float *buf = north ? buf_n : buf_s;
-    if (!buf) return;
-    const int t = north ? 0 : 1;
-    const long long row = (north ? h : 0) + d_halo_row[t][seg];
-    buf[(long long)seg * nx + x] = origin[d_halo_k[t][seg] * plane + row * pitch + x];
-}
-
-__global__ void k_halo_unpack(float *origin, long long plane, int pitch, int h, int nx, const float *buf_s, const float *buf_n)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
-    if (x >= nx) return;
-    const float *buf = north ? buf_n : buf_s;
-    if (!buf) return;
-    const int t = north ? 3 : 2;
-    const long long row = (north ? h : 0) + d_halo_row[t][seg];
-    origin[d_halo_k[t][seg] * plane + row * pitch + x] = buf[(long long)seg * nx + x];
-}
+namespace {
 
 // ------------------------------------------------------------------------------------------
 //  RCCL, loaded lazily so that single-GPU use never touches librccl
