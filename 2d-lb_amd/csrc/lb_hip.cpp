@@ -136,6 +136,11 @@ struct lb_sim {
     float *halo_buf = nullptr;  // 4 x 9*nx floats: send north, send south, recv south, recv north
     bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
     int variant = -1;           // < 0: automatic (effective_variant)
+    hipGraph_t graph = nullptr;            // GRAPH_STEPS single-step launches, captured for small grids
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_key = -1;                    // state the capture is valid for (cur, mask, variant)
+    hipStream_t graph_stream = nullptr;
+    bool graph_failed = false;
     int diag = 0;
     int64_t bytes = 0;
 
@@ -320,6 +325,55 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
     }
     HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+constexpr int GRAPH_STEPS = 16;
+
+bool small_grid(const lb_sim *s) { return (double)s->p.nx * s->H <= 768.0 * 768.0; }
+
+void drop_graph(lb_sim *s)
+{
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    s->graph_exec = nullptr;
+    s->graph = nullptr;
+    s->graph_key = -1;
+}
+
+// (Re)capture GRAPH_STEPS single-step launches starting from the current lattice.  The capture bakes in
+// the lattice parity, the mask flag, the kernel variant and the stream, so it is redone when any changes.
+// A capture failure is not an error: the caller falls back to eager launches.
+int ensure_graph(lb_sim *s)
+{
+    const int key = (s->cur & 1) | (s->has_mask ? 2 : 0) | (effective_variant(s) << 2);
+    if (s->graph_exec && s->graph_key == key && s->graph_stream == s->stream) return LB_OK;
+    if (s->graph_failed) return LB_OK;
+    drop_graph(s);
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        s->graph_failed = true;
+        return LB_OK;
+    }
+    int rc = LB_OK;
+    const int cur0 = s->cur;
+    for (int i = 0; i < GRAPH_STEPS && !rc; ++i) {
+        rc = launch_step(s, 0, 1, s->H, false);
+        s->cur ^= 1;
+    }
+    s->cur = cur0;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (rc || e != hipSuccess || !g || hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        s->graph_exec = nullptr;
+        s->graph_failed = true;
+        return LB_OK;
+    }
+    s->graph = g;
+    s->graph_key = key;
+    s->graph_stream = s->stream;
     return LB_OK;
 }
 
@@ -565,6 +619,7 @@ int lb_destroy(lb_sim *s)
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
+    drop_graph(s);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf})
         if (p) (void)hipFree(p);
@@ -903,6 +958,15 @@ int lb_run(lb_sim *s, int n_steps)
         const bool three = (v & 64) && step3_applicable(s);
         const bool two = (v & 32) && step2_applicable(s);
         int left = n_steps;
+        // Small grids are launch-bound (a 256^2 step is ~3 us of GPU work against ~5 us of host launch
+        // cost): replay GRAPH_STEPS single-step launches captured once into a hipGraph.
+        if (!three && !two && left > GRAPH_STEPS && small_grid(s)) {
+            if ((rc = ensure_graph(s))) return rc;
+            while (s->graph_exec && left > GRAPH_STEPS) {          // keep >= 1 step for the MACRO launch
+                HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+                left -= GRAPH_STEPS;                                // GRAPH_STEPS is even: cur is unchanged
+            }
+        }
         while (left > 0) {
             const int adv = next_advance(three, two, left);
             const bool macro = (left == adv);

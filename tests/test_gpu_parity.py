@@ -375,3 +375,31 @@ def test_pipe_flow_cylinder_docs_case_vs_oracle(lbhip, oracle):
     assert_fields_close(sim.get_fields(), ref.get_fields(), TOLN)
     phys = sim.get_physical_fields()
     assert np.allclose(phys["u"], sim.get_fields()["u"] * (sim.delta_x / sim.delta_t) * (sim.L / sim.T))
+
+
+@pytest.mark.parametrize("bc", ["pipe", "periodic", "cavity"])
+def test_small_grid_graph_replay_equals_eager_steps(lbhip, bc):
+    """Grids <= 768^2 replay 16 captured single-step launches per hipGraph launch inside run(n);
+    run(1) never does.  Same kernels, so the two must agree bit for bit (also across a mask change,
+    which invalidates the capture)."""
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 200, 150
+    rng = np.random.default_rng(8)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.04
+    mask[0, :] = mask[-1, :] = False
+    mask[:, 0] = mask[:, -1] = False
+    kw = dict(inlet_rho=1.004, lid_u=0.05)
+    a, b = Simulation(nx, ny, 1.4, bc=bc, **kw), Simulation(nx, ny, 1.4, bc=bc, **kw)
+    a.set_f(f0); b.set_f(f0)
+    a.run(101)                                   # 6 graph replays + 5 eager steps
+    for _ in range(101):
+        b.run(1)
+    for k in ("f", "rho", "u", "v"):
+        assert np.array_equal(a.get_fields((k,))[k], b.get_fields((k,))[k]), k
+    a.set_obstacle_mask(mask); b.set_obstacle_mask(mask)
+    a.run(50)
+    for _ in range(50):
+        b.run(1)
+    for k in ("f", "rho", "u", "v"):
+        assert np.array_equal(a.get_fields((k,))[k], b.get_fields((k,))[k]), k
