@@ -35,8 +35,8 @@ namespace {
 
 constexpr int GHOST = 3;   // ghost rows below row 0 and above row H-1 of every plane (3-step kernel on slabs)
 constexpr int MASK_GHOST = 2;   // mask rows kept of each neighbouring slab
-constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (k_step2's edge strips
-                           // read up to 4 cells before a row and 256 cells past its end)
+constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (the marching kernels' last
+                           // strip reads up to 257 cells past a row's end, every kernel 1 cell before its start)
 
 thread_local char g_err[512] = "";
 
