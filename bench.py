@@ -124,7 +124,23 @@ def main():
         sim = Simulation(n, n, args.omega, bc="periodic", device=local_rank)
         eng, y0, h = sim, 0, n
     else:
-        slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=args.transport, device=local_rank)
+        # RCCL halo exchange inside the engine; if any rank cannot set it up, every rank falls back to the
+        # torch.distributed-driven exchange (same halo format, single-step kernel, not overlapped)
+        slab, failed = None, 0
+        try:
+            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=args.transport, device=local_rank)
+        except Exception as exc:                                   # noqa: BLE001 - reported below
+            failed = 1
+            print("rank %d: %s halo transport unavailable (%s)" % (rank, args.transport, exc), file=sys.stderr, flush=True)
+        flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag[0]):
+            if args.transport == "torch":
+                raise SystemExit("bench: no usable halo transport")
+            args.transport = "torch"
+            if slab is not None:
+                slab.engine.close()
+            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport="torch", device=local_rank)
         sim, eng, y0, h = slab, slab.engine, slab.y0, slab.h
     if args.variant is not None:
         eng.set_variant(args.variant)
