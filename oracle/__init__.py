@@ -1,0 +1,1 @@
+"""CPU oracle of the reference hot path: test infrastructure only (see oracle/README.md)."""
