@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("LB_LIB") or os.path.join(_HERE, "liblbhip.so")   # LB
 
 LB_BC_PIPE, LB_BC_PERIODIC, LB_BC_CAVITY = 0, 1, 2
 LB_FLAG_HALO = 1
+LB_SEM_OPENCL, LB_SEM_CYTHON = 0, 1
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY}
 
 ABI_VERSION = 1
@@ -30,7 +31,8 @@ class LbParams(ct.Structure):
     _fields_ = [("nx", ct.c_int32), ("ny", ct.c_int32), ("y0", ct.c_int32), ("local_ny", ct.c_int32),
                 ("bc_mode", ct.c_int32), ("device", ct.c_int32),
                 ("omega", ct.c_float), ("inlet_rho", ct.c_float), ("outlet_rho", ct.c_float),
-                ("lid_u", ct.c_float), ("rho0", ct.c_float), ("flags", ct.c_int32), ("reserved", ct.c_int32 * 4)]
+                ("lid_u", ct.c_float), ("rho0", ct.c_float), ("flags", ct.c_int32), ("semantics", ct.c_int32),
+                ("reserved", ct.c_int32 * 3)]
 
 
 class LbError(RuntimeError):

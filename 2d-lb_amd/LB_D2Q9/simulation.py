@@ -51,7 +51,7 @@ def comm_unique_id():
 
 class Simulation(object):
     def __init__(self, nx, ny, omega, bc="pipe", inlet_rho=1., outlet_rho=1., lid_u=0., rho0=1.,
-                 obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False):
+                 obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False, semantics="opencl"):
         """
         :param nx, ny: global grid size (cells, boundary nodes included).
         :param omega: BGK relaxation rate, 0 < omega < 2.
@@ -60,6 +60,8 @@ class Simulation(object):
         :param obstacle_mask: optional (nx, ny) array, non-zero = solid (bounce-back, D2Q9.cl:398-433).
         :param y0, local_ny: the row slab this object owns (multi-GPU); default = whole grid.
         :param halo: fill the ghost rows through the halo interface even for a whole-grid handle.
+        :param semantics: 'opencl' (D2Q9.cl, fused fast path) or 'cython' (cython_dim.pyx: pipe family,
+               whole grid, un-fused compatibility path); the two reference paths differ at walls and inlets.
         """
         if isinstance(bc, str):
             if bc not in _native.BC_NAMES:
@@ -78,6 +80,10 @@ class Simulation(object):
         p.nx, p.ny, p.y0, p.local_ny = self.nx, self.ny, self.y0, self.local_ny
         p.bc_mode, p.device = bc, self.device
         p.flags = _native.LB_FLAG_HALO if halo else 0
+        if semantics not in ("opencl", "cython"):
+            raise ValueError("semantics must be 'opencl' or 'cython'")
+        p.semantics = _native.LB_SEM_CYTHON if semantics == "cython" else _native.LB_SEM_OPENCL
+        self.semantics = semantics
         self._halo = bool(halo)
         p.omega = np.float32(omega)
         p.inlet_rho, p.outlet_rho = np.float32(inlet_rho), np.float32(outlet_rho)

@@ -96,6 +96,107 @@ __global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
     if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
 }
 
+// ---- the reference's CPU ("Cython") path as GPU kernels -------------------------------------------
+// LB_D2Q9/dimensionless/cython_dim.pyx is a different discretisation of the same pipe flow:
+// boundary rules BEFORE streaming and fed by the stored inlet/outlet velocity of the previous step, plain
+// bounce-back walls, an in-place streaming whose loop bounds leave four tangential links unmoved on one
+// wall row/column each, and overrides in the moment update.  These three kernels restate it phase by
+// phase (one thread per cell, un-fused: a compatibility path, ~15x slower than the fused OpenCL-path
+// kernels and ~2000x faster than the reference's CPU loop); k_feq and k_collide are shared.
+// x = i (0..lx), y = j (0..ly) in the .pyx's notation.
+
+// cython_dim.pyx:204-269 `move_bcs` (+ :468-513 obstacle swap), in place
+__global__ void k1_bcs(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    float *f = a.f + o;
+    const bool edge = (x == 0 || x == lx || y == 0 || y == ly);
+    const bool solid = a.mask && a.mask[o];
+    if (!edge && !solid) return;
+    Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
+    if (x == 0 && y >= 1 && y < ly) {                         // inlet, stored u of the previous update_hydro
+        const float u0 = a.u[o], t = (1.f / 6.f) * u0 * a.rho_in;
+        const float f2 = c.f2, f4 = c.f4;
+        c.f1 = c.f3 + (2.f / 3.f) * a.rho_in * u0;
+        c.f5 = (-.5f * f2 + .5f * f4) + c.f7 + t;
+        c.f8 = (.5f * f2 - .5f * f4) + c.f6 + t;
+    } else if (x == lx && y >= 1 && y < ly) {                 // outlet
+        const float ul = a.u[o], t = (1.f / 6.f) * ul * a.rho_out;
+        const float f2 = c.f2, f4 = c.f4;
+        c.f3 = c.f1 - (2.f / 3.f) * a.rho_out * ul;
+        c.f6 = (-.5f * f2 + .5f * f4) + c.f8 - t;
+        c.f7 = (.5f * f2 - .5f * f4) + c.f5 - t;
+    } else if (y == ly && x >= 1 && x < lx) {                 // north wall: plain bounce-back
+        c.f4 = c.f2; c.f8 = c.f6; c.f7 = c.f5;
+    } else if (y == 0 && x >= 1 && x < lx) {                  // south wall
+        c.f2 = c.f4; c.f6 = c.f8; c.f5 = c.f7;
+    } else if (x == 0 && y == 0) {                            // corners :242-269
+        const float t = .5f * (-c.f0 - 2.f * c.f3 - 2.f * c.f4 - 2.f * c.f7 + a.rho_in);
+        c.f1 = c.f3; c.f2 = c.f4; c.f5 = c.f7; c.f6 = t; c.f8 = t;
+    } else if (x == 0 && y == ly) {
+        const float t = .5f * (-c.f0 - 2.f * c.f2 - 2.f * c.f3 - 2.f * c.f6 + a.rho_in);
+        c.f1 = c.f3; c.f4 = c.f2; c.f5 = t; c.f7 = t; c.f8 = c.f6;
+    } else if (x == lx && y == 0) {
+        const float t = .5f * (-c.f0 - 2.f * c.f1 - 2.f * c.f4 - 2.f * c.f8 + a.rho_out);
+        c.f3 = c.f1; c.f2 = c.f4; c.f6 = c.f8; c.f5 = t; c.f7 = t;
+    } else if (x == lx && y == ly) {
+        const float t = .5f * (-c.f0 - 2.f * c.f1 - 2.f * c.f2 - 2.f * c.f5 + a.rho_out);
+        c.f3 = c.f1; c.f4 = c.f2; c.f6 = t; c.f7 = c.f5; c.f8 = t;
+    }
+    bounce_cell(c, solid);
+    f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
+    f[5 * S] = c.f5; f[6 * S] = c.f6; f[7 * S] = c.f7; f[8 * S] = c.f8;
+}
+
+// cython_dim.pyx:271-299 `move`: the in-place loops read sources before they are overwritten, i.e. they
+// are a simultaneous pull restricted to the loops' index ranges; a link outside its range keeps its value.
+__global__ void k1_move(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= a.nx) return;
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    bool moved = false;
+    switch (k) {
+    case 2: case 6: moved = (y >= 1 && x <= lx - 1); break;     // j = ly..1, i = 0..lx-1
+    case 1: case 5: moved = (y >= 1 && x >= 1); break;          // j = ly..1, i = lx..1
+    case 4: case 8: moved = (y <= ly - 1 && x >= 1); break;     // j = 0..ly-1, i = lx..1
+    case 3: case 7: moved = (y <= ly - 1 && x <= lx - 1); break; // j = 0..ly-1, i = 0..lx-1
+    default: break;                                             // the rest population never moves
+    }
+    const int sx = moved ? x - d_cx[k] : x, sy = moved ? y - d_cy[k] : y;
+    a.fs[k * a.plane + (long long)y * a.pitch + x] = a.f[k * a.plane + (long long)sy * a.pitch + sx];
+}
+
+// cython_dim.pyx:302-333 `update_hydro` (+ :459-466 obstacle zeroing)
+__global__ void k1_hydro(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    const float *f = a.f + o;
+    const float f0 = f[0], f1 = f[S], f2 = f[2 * S], f3 = f[3 * S], f4 = f[4 * S], f5 = f[5 * S], f6 = f[6 * S],
+                f7 = f[7 * S], f8 = f[8 * S];
+    float rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
+    const float inv = 1.0f / rho;
+    float ux = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
+    float uy = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
+    if (y == 0 || y == ly) { ux = 0.f; uy = 0.f; }              // walls
+    if (x == 0) {                                                // pressure inlet: rho pinned, u from the knowns
+        rho = a.rho_in;
+        ux = 1.f - ((f0 + f2 + f4) + 2.f * (f3 + f6 + f7)) / a.rho_in;
+    }
+    if (x == lx) {
+        rho = a.rho_out;
+        ux = -1.f + ((f0 + f2 + f4) + 2.f * (f1 + f5 + f8)) / a.rho_out;
+    }
+    if (a.mask && a.mask[o]) { ux = 0.f; uy = 0.f; }
+    a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+}
+
 // Halo pack / unpack: the 3-deep halo of one edge is 18 row segments scattered over the planes
 // (HaloSeg tables on the host side).  One tiny kernel gathers both edges into two contiguous buffers
 // (so that an exchange is one send + one receive per neighbour instead of eighteen), one scatters the

@@ -546,6 +546,11 @@ int lb_create(const lb_params *p, lb_sim **out)
     for (int r : p->reserved)
         if (r != 0) return fail(LB_ERR_ARG, "reserved fields must be zero");
     if (p->flags & ~LB_FLAG_HALO) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
+    if (p->semantics != LB_SEM_OPENCL && p->semantics != LB_SEM_CYTHON)
+        return fail(LB_ERR_ARG, "unknown semantics %d", p->semantics);
+    if (p->semantics == LB_SEM_CYTHON &&
+        (p->bc_mode != LB_BC_PIPE || p->local_ny != p->ny || (p->flags & LB_FLAG_HALO)))
+        return fail(LB_ERR_ARG, "Cython-path semantics exist for whole-grid pipe-flow handles only");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(LB_ERR_HIP, "no HIP device visible");
@@ -802,6 +807,13 @@ int lb_move(lb_sim *s)
     int rc = need_single_slab(s, "lb_move");
     if (rc) return rc;
     DeviceGuard guard(s->p.device);
+    if (s->p.semantics == LB_SEM_CYTHON) {
+        // every entry of the target is written, so the lattices simply swap
+        hipLaunchKernelGGL(k1_move, cells_grid(s, 9), dim3(256), 0, s->stream, phase_args(s));
+        HIP_TRY(hipGetLastError());
+        s->cur ^= 1;
+        return LB_OK;
+    }
     hipLaunchKernelGGL(k_move, cells_grid(s, 9), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
     // copy_buffer: f = f_streamed (kept as a copy, not a pointer swap, so that the stale
@@ -817,7 +829,10 @@ int lb_move_bcs(lb_sim *s)
     int rc = need_single_slab(s, "lb_move_bcs");
     if (rc) return rc;
     DeviceGuard guard(s->p.device);
-    hipLaunchKernelGGL(k_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    if (s->p.semantics == LB_SEM_CYTHON)
+        hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    else
+        hipLaunchKernelGGL(k_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
@@ -828,7 +843,10 @@ int lb_update_hydro(lb_sim *s)
     int rc = need_single_slab(s, "lb_update_hydro");
     if (rc) return rc;
     DeviceGuard guard(s->p.device);
-    hipLaunchKernelGGL(k_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    if (s->p.semantics == LB_SEM_CYTHON)
+        hipLaunchKernelGGL(k1_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    else
+        hipLaunchKernelGGL(k_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
     return LB_OK;   // feq keeps its previous content, as the reference's feq buffer does
 }
@@ -952,6 +970,15 @@ int lb_run(lb_sim *s, int n_steps)
     if (s->stepping) return fail(LB_ERR_STATE, "lb_run between lb_step_boundary and lb_step_finish");
     DeviceGuard guard(s->p.device);
     int rc;
+    if (s->p.semantics == LB_SEM_CYTHON) {
+        // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles
+        for (int it = 0; it < n_steps; ++it) {
+            if ((rc = lb_move_bcs(s)) || (rc = lb_move(s)) || (rc = lb_update_hydro(s)) || (rc = lb_update_feq(s)) ||
+                (rc = lb_collide_particles(s)))
+                return rc;
+        }
+        return LB_OK;
+    }
     if (!s->multi_slab()) {
         // largest fused kernel first in the remainder: n = 3a + rem (three-step), or 2a + rem (two-step)
         const int v = effective_variant(s);

@@ -50,6 +50,16 @@ typedef enum {
     LB_BC_CAVITY = 2      /* four no-slip walls, north wall moving with lid_u  */
 } lb_bc_mode;
 
+/* Which of the reference's two (numerically different) paths the handle reproduces.
+ * OPENCL: LB_D2Q9/D2Q9.cl driven as opencl_dim.py:372-387 does -- the fused, fast path.
+ * CYTHON: LB_D2Q9/dimensionless/cython_dim.pyx:160-359 -- boundary rules before streaming, bounce-back
+ *         walls, restricted in-place streaming, moment overrides; PIPE family, whole-grid handles,
+ *         un-fused kernels only (a compatibility path for users of the reference's CPU classes). */
+typedef enum {
+    LB_SEM_OPENCL = 0,
+    LB_SEM_CYTHON = 1
+} lb_semantics;
+
 typedef struct {
     int32_t nx, ny;           /* global grid (reference: self.nx, self.ny, opencl_dim.py:191-201) */
     int32_t y0, local_ny;     /* row slab [y0, y0+local_ny) owned by this handle; 0, ny for one GPU */
@@ -61,7 +71,8 @@ typedef struct {
     float lid_u;              /* CAVITY only */
     float rho0;               /* CAVITY corner closure density */
     int32_t flags;            /* LB_FLAG_* */
-    int32_t reserved[4];      /* must be zero */
+    int32_t semantics;        /* lb_semantics; 0 = the OpenCL path */
+    int32_t reserved[3];      /* must be zero */
 } lb_params;
 
 /* Treat the handle as a row slab with ghost rows even when it owns the whole grid: its halo

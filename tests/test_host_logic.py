@@ -176,3 +176,35 @@ def test_frame_dumper_loop_and_png(tmp_path):
                       image_format="npy", run_func=lambda n: sim.run(2 * n))
     d2.on_draw()
     assert sim.steps == 17 and np.load(d2.frames_written[0]).shape == (sim.nx, sim.ny)
+
+
+def test_cython_style_constants_match_reference_prints(oracle):
+    """LB_D2Q9.dimensionless.cython_dim (GPU-backed): the comparison notebook's cylinder case prints
+    L=0.1, T=0.08, Re=1.5625, omega=0.413223140496, inlet rho 1.00368738304 on a 3751x1251 grid
+    (docs/python_cython_opencl_comparison.ipynb cells 10-13); any other input must equal the oracle's
+    restatement of the reference constructor."""
+    from LB_D2Q9.dimensionless import cython_dim as lb
+
+    def dry_c(cls):
+        class Dry(cls):
+            def init_hydro(self):
+                self.inlet_rho, self.outlet_rho = self._boundary_densities()
+
+            def update_feq(self):
+                pass
+
+            def init_pop(self, amplitude=.001):
+                pass
+        return Dry
+
+    c = dry_c(lb.Pipe_Flow_Cylinder)(cylinder_center=[.75, .5], cylinder_radius=.1, diameter=1., rho=1., viscosity=1.,
+                                     pressure_grad=-10., pipe_length=3., N=125, verbose=False)
+    assert c.L == pytest.approx(0.1) and c.T == pytest.approx(0.08) and c.Re == pytest.approx(1.5625)
+    assert c.omega == pytest.approx(0.413223140496, rel=1e-11) and (c.nx, c.ny) == (3751, 1251)
+    assert c.inlet_rho == pytest.approx(1.00368738304, rel=1e-11)
+    assert c.obstacle_mask.dtype == bool and c.obstacle_mask.sum() == len(c.obstacle_pixels[0]) > 40000
+    kw = dict(diameter=0.8, rho=1.3, viscosity=0.21, pressure_grad=-2.5, pipe_length=1.7, N=41, time_prefactor=0.7)
+    s = dry_c(lb.Pipe_Flow)(verbose=False, **kw)
+    p = oracle.cython_pipe_parameters(**kw)
+    for k in ("L", "T", "Re", "delta_x", "delta_t", "lb_viscosity", "omega", "lx", "ly", "nx", "ny", "inlet_rho", "outlet_rho"):
+        assert getattr(s, k) == p[k], k
