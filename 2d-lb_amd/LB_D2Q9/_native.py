@@ -8,10 +8,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LB_LIB") or os.path.join(_HERE, "liblbhip.so")   # LB_LIB: diagnostic builds only
 
-LB_BC_PIPE, LB_BC_PERIODIC, LB_BC_CAVITY = 0, 1, 2
+LB_BC_PIPE, LB_BC_PERIODIC, LB_BC_CAVITY, LB_BC_VELOCITY_INLET = 0, 1, 2, 3
 LB_FLAG_HALO = 1
 LB_SEM_OPENCL, LB_SEM_CYTHON = 0, 1
-BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY}
+BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
+            "velocity_inlet": LB_BC_VELOCITY_INLET}
 
 ABI_VERSION = 1
 
@@ -32,7 +33,7 @@ class LbParams(ct.Structure):
                 ("bc_mode", ct.c_int32), ("device", ct.c_int32),
                 ("omega", ct.c_float), ("inlet_rho", ct.c_float), ("outlet_rho", ct.c_float),
                 ("lid_u", ct.c_float), ("rho0", ct.c_float), ("flags", ct.c_int32), ("semantics", ct.c_int32),
-                ("reserved", ct.c_int32 * 3)]
+                ("inlet_u", ct.c_float), ("outlet_u", ct.c_float), ("reserved", ct.c_int32 * 1)]
 
 
 class LbError(RuntimeError):

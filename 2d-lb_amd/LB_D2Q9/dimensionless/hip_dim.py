@@ -137,13 +137,15 @@ class Pipe_Flow(object):
         self.ly = self.N
         self.nx, self.ny = self.lx + 1, self.ly + 1
 
+    def _engine(self):
+        rin, rout = self._boundary_densities()
+        return Simulation(self.nx, self.ny, self.omega, bc='pipe', inlet_rho=rin, outlet_rho=rout, device=self.device)
+
     def init_hip(self):
         """Replaces init_opencl (:203-242): report the HIP devices and create the engine handle."""
         ndev = _native.device_count()
         self._say('HIP devices visible:', ndev, '- using device', self.device)
-        rin, rout = self._boundary_densities()
-        self._sim = Simulation(self.nx, self.ny, self.omega, bc='pipe', inlet_rho=rin, outlet_rho=rout,
-                               device=self.device)
+        self._sim = self._engine()
 
     init_opencl = init_hip
 
@@ -248,3 +250,28 @@ class Pipe_Flow_Cylinder(Pipe_Flow):
         self._sim.set_obstacle_mask(self.obstacle_mask_host)
         self.obstacle_mask = DeviceField(self, 'mask')
         self._sim.zero_velocity_in_obstacle()
+
+
+class Pipe_Flow_PeriodicBC_VelocityInlet(Pipe_Flow):
+    """The reference's second rule set (kernels ``move_bcs_PeriodicBC_VelocityInlet`` and
+    ``update_hydro_PeriodicBC_VelocityInlet``, D2Q9.cl:263-374): imposed speed ``u_w`` at the inlet and the
+    outlet, north/south rows fed from the opposite wall row.  In the reference only
+    ``LB_D2Q9/OLD/opencl.py:281-327`` drives these kernels (its callers in ``dimensionless`` are commented
+    out); this class puts the same overrides (``move_bcs``, ``init_hydro``: rho=1, u=u_w, v=0,
+    ``update_hydro``) on the dimensionless constructor.  Runs on the un-fused phase kernels."""
+
+    def __init__(self, u_w=0.1, **kwargs):
+        self.u_w = u_w
+        self.u_e = u_w
+        super(Pipe_Flow_PeriodicBC_VelocityInlet, self).__init__(**kwargs)
+
+    def _engine(self):
+        return Simulation(self.nx, self.ny, self.omega, bc='velocity_inlet', inlet_u=self.u_w, outlet_u=self.u_e,
+                          device=self.device)
+
+    def init_hydro(self):
+        self.inlet_rho, self.outlet_rho = self._boundary_densities()     # kept as attributes; unused by this family
+        rho_host = np.ones((self.nx, self.ny), np.float32, order='F')
+        u_host = np.asfortranarray((np.ones((self.nx, self.ny)) * self.u_w).astype(np.float32))
+        v_host = np.zeros((self.nx, self.ny), np.float32, order='F')
+        self._sim.set_fields(rho_host, u_host, v_host)

@@ -51,12 +51,15 @@ def comm_unique_id():
 
 class Simulation(object):
     def __init__(self, nx, ny, omega, bc="pipe", inlet_rho=1., outlet_rho=1., lid_u=0., rho0=1.,
-                 obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False, semantics="opencl"):
+                 obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False, semantics="opencl",
+                 inlet_u=0., outlet_u=None):
         """
         :param nx, ny: global grid size (cells, boundary nodes included).
         :param omega: BGK relaxation rate, 0 < omega < 2.
         :param bc: 'pipe' (the reference's pressure inlet/outlet + no-slip walls, D2Q9.cl:173-261),
                    'periodic' or 'cavity' (lid-driven; build-defined, see oracle/d2q9_oracle.c).
+        :param inlet_u, outlet_u: bc='velocity_inlet' (D2Q9.cl:263-374; un-fused kernels): imposed speed at
+               x=0 / x=nx-1 (outlet_u defaults to inlet_u, as OLD/opencl.py:283-286 sets u_e = u_w).
         :param obstacle_mask: optional (nx, ny) array, non-zero = solid (bounce-back, D2Q9.cl:398-433).
         :param y0, local_ny: the row slab this object owns (multi-GPU); default = whole grid.
         :param halo: fill the ghost rows through the halo interface even for a whole-grid handle.
@@ -88,6 +91,8 @@ class Simulation(object):
         p.omega = np.float32(omega)
         p.inlet_rho, p.outlet_rho = np.float32(inlet_rho), np.float32(outlet_rho)
         p.lid_u, p.rho0 = np.float32(lid_u), np.float32(rho0)
+        self.inlet_u, self.outlet_u = inlet_u, (inlet_u if outlet_u is None else outlet_u)
+        p.inlet_u, p.outlet_u = np.float32(self.inlet_u), np.float32(self.outlet_u)
         self._h = ct.c_void_p()
         check(self._lib.lb_create(ct.byref(p), ct.byref(self._h)))
         self._shape2 = (self.nx, self.local_ny)

@@ -388,6 +388,7 @@ PhaseArgs phase_args(const lb_sim *s)
     a.plane = s->plane; a.pitch = (int)s->pitch; a.nx = s->p.nx; a.ny = s->p.ny; a.bc = s->p.bc_mode;
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
+    a.u_w = s->p.inlet_u; a.u_e = s->p.outlet_u;
     return a;
 }
 
@@ -541,7 +542,12 @@ int lb_create(const lb_params *p, lb_sim **out)
     if (p->nx < 2 || p->ny < 2) return fail(LB_ERR_ARG, "grid must be at least 2x2 (got %dx%d)", p->nx, p->ny);
     if (p->local_ny < 1 || p->y0 < 0 || p->y0 + p->local_ny > p->ny)
         return fail(LB_ERR_ARG, "slab [%d,%d) outside 0..%d", p->y0, p->y0 + p->local_ny, p->ny);
-    if (p->bc_mode < LB_BC_PIPE || p->bc_mode > LB_BC_CAVITY) return fail(LB_ERR_ARG, "unknown bc_mode %d", p->bc_mode);
+    if (p->bc_mode < LB_BC_PIPE || p->bc_mode > LB_BC_VELOCITY_INLET) return fail(LB_ERR_ARG, "unknown bc_mode %d", p->bc_mode);
+    if (p->bc_mode == LB_BC_VELOCITY_INLET &&
+        (p->local_ny != p->ny || (p->flags & LB_FLAG_HALO) || p->semantics != LB_SEM_OPENCL))
+        return fail(LB_ERR_ARG, "the velocity-inlet family exists for whole-grid OpenCL-path handles only");
+    if (p->bc_mode == LB_BC_VELOCITY_INLET && (!(p->inlet_u < 1.f) || !(p->outlet_u > -1.f)))
+        return fail(LB_ERR_ARG, "velocity-inlet speeds must satisfy inlet_u < 1 and outlet_u > -1");
     if (!(p->omega > 0.f && p->omega < 2.f)) return fail(LB_ERR_ARG, "omega must be in (0,2), got %g", p->omega);
     for (int r : p->reserved)
         if (r != 0) return fail(LB_ERR_ARG, "reserved fields must be zero");
@@ -831,6 +837,8 @@ int lb_move_bcs(lb_sim *s)
     DeviceGuard guard(s->p.device);
     if (s->p.semantics == LB_SEM_CYTHON)
         hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    else if (s->p.bc_mode == LB_BC_VELOCITY_INLET)
+        hipLaunchKernelGGL(k_bcs_vel, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     else
         hipLaunchKernelGGL(k_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
@@ -845,6 +853,8 @@ int lb_update_hydro(lb_sim *s)
     DeviceGuard guard(s->p.device);
     if (s->p.semantics == LB_SEM_CYTHON)
         hipLaunchKernelGGL(k1_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    else if (s->p.bc_mode == LB_BC_VELOCITY_INLET)
+        hipLaunchKernelGGL(k_hydro_vel, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     else
         hipLaunchKernelGGL(k_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
@@ -906,6 +916,8 @@ int lb_step_boundary(lb_sim *s, int write_macro)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_step_boundary called twice");
+    if (s->p.bc_mode == LB_BC_VELOCITY_INLET || s->p.semantics == LB_SEM_CYTHON)
+        return fail(LB_ERR_STATE, "no fused kernel for this boundary family / semantics: use lb_run");
     DeviceGuard guard(s->p.device);
     // local rows 0 and H-1 (one row when H == 1)
     int rc = launch_step(s, 0, s->H > 1 ? s->H - 1 : 1, s->H > 1 ? 2 : 1, write_macro != 0);
@@ -970,6 +982,15 @@ int lb_run(lb_sim *s, int n_steps)
     if (s->stepping) return fail(LB_ERR_STATE, "lb_run between lb_step_boundary and lb_step_finish");
     DeviceGuard guard(s->p.device);
     int rc;
+    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) {
+        // un-fused, in the reference's order (opencl_dim.py:380-387 with the overrides of OLD/opencl.py:290-327)
+        for (int it = 0; it < n_steps; ++it) {
+            if ((rc = lb_move(s)) || (rc = lb_move_bcs(s)) || (rc = lb_update_hydro(s)) || (rc = lb_update_feq(s)) ||
+                (rc = lb_collide_particles(s)))
+                return rc;
+        }
+        return LB_OK;
+    }
     if (s->p.semantics == LB_SEM_CYTHON) {
         // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles
         for (int it = 0; it < n_steps; ++it) {

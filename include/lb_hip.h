@@ -43,11 +43,16 @@ typedef enum {
 
 /* Boundary-condition families.  PIPE is the reference's `move_bcs`
  * (D2Q9.cl:173-261); PERIODIC and CAVITY are build-defined (BASELINE configs
- * 2-4) and specified by oracle/d2q9_oracle.c. */
+ * 2-4) and specified by oracle/d2q9_oracle.c; VELOCITY_INLET is the reference's
+ * second rule set of D2Q9.cl. */
 typedef enum {
     LB_BC_PIPE = 0,       /* pressure inlet x=0 / outlet x=nx-1, no-slip y=0,ny-1 */
     LB_BC_PERIODIC = 1,   /* periodic in x and y                               */
-    LB_BC_CAVITY = 2      /* four no-slip walls, north wall moving with lid_u  */
+    LB_BC_CAVITY = 2,     /* four no-slip walls, north wall moving with lid_u  */
+    LB_BC_VELOCITY_INLET = 3  /* D2Q9.cl:263-374: imposed speed inlet_u at x=0 / outlet_u at x=nx-1, north and
+                             south rows copy their missing links from the opposite wall row.  Dead code in
+                             the reference's `dimensionless` package (only OLD/opencl.py:281-327 launches
+                             it); offered through the un-fused phase kernels only, whole-grid handles. */
 } lb_bc_mode;
 
 /* Which of the reference's two (numerically different) paths the handle reproduces.
@@ -72,7 +77,8 @@ typedef struct {
     float rho0;               /* CAVITY corner closure density */
     int32_t flags;            /* LB_FLAG_* */
     int32_t semantics;        /* lb_semantics; 0 = the OpenCL path */
-    int32_t reserved[3];      /* must be zero */
+    float inlet_u, outlet_u;  /* VELOCITY_INLET only: u_w, u_e of OLD/opencl.py:283-286 */
+    int32_t reserved[1];      /* must be zero */
 } lb_params;
 
 /* Treat the handle as a row slab with ghost rows even when it owns the whole grid: its halo

@@ -32,7 +32,7 @@
 static const int   CX[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
 static const int   CY[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
 
-enum { BC_PIPE = 0, BC_PERIODIC = 1, BC_CAVITY = 2 };
+enum { BC_PIPE = 0, BC_PERIODIC = 1, BC_CAVITY = 2, BC_VELOCITY_INLET = 3 };
 
 /* ======================================================================= */
 /*  O2 : OpenCL-path semantics.  idx(k,x,y) = k*nx*ny + y*nx + x            */
@@ -41,6 +41,7 @@ enum { BC_PIPE = 0, BC_PERIODIC = 1, BC_CAVITY = 2 };
 typedef struct {
     int32_t nx, ny, bc_mode, _pad;
     float omega, rho_in, rho_out, lid_u, rho0;
+    float u_w, u_e;                       /* BC_VELOCITY_INLET: imposed inlet / outlet speed */
     float cs2, two_cs2, two_cs4;          /* float32 casts made by the host, opencl_dim.py:305 */
     float *f, *fs, *feq, *rho, *u, *v;
     const int32_t *mask;                  /* NULL when there is no obstacle */
@@ -188,6 +189,71 @@ void o2_bc_cavity(float *f, float lid_u, float rho0, int nx, int ny)
         }
 }
 
+/* D2Q9.cl:263-321 `move_bcs_PeriodicBC_VelocityInlet` (only OLD/opencl.py:290-296 launches it): imposed
+ * x-velocity u_w at x=0 and u_e at x=nx-1 for 1<=y<=ny-2 (Zou-He, double literals), and on the whole
+ * north / south rows a copy of the three links that streaming could not deliver from the same x of
+ * the opposite wall row.  Each work-item first reads its own nine links; the copies read the opposite
+ * row from memory, planes that no other work-item of the launch writes, so the order is immaterial. */
+void o2_bc_velocity_inlet(float *f, float u_w, float u_e, int nx, int ny)
+{
+    const size_t plane = (size_t)nx * ny;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            float *c = f + (size_t)y * nx + x;
+            const float f0 = c[P(0)], f1 = c[P(1)], f2 = c[P(2)], f3 = c[P(3)], f4 = c[P(4)],
+                        f5 = c[P(5)], f6 = c[P(6)], f7 = c[P(7)], f8 = c[P(8)];
+            if (x == 0 && y >= 1 && y < ny - 1) {                                 /* :291-296 */
+                float rho_w = (float)((1. / (1. - u_w)) * (f0 + f2 + f4 + 2 * (f3 + f6 + f7)));
+                c[P(1)] = (float)(f3 + (2. / 3.) * rho_w * u_w);
+                c[P(5)] = (float)(f7 - (1. / 2.) * (f2 - f4) + (1. / 6.) * rho_w * u_w);
+                c[P(8)] = (float)(f6 + (1. / 2.) * (f2 - f4) + (1. / 6.) * rho_w * u_w);
+            }
+            if (x == nx - 1 && y >= 1 && y < ny - 1) {                            /* :298-303 */
+                float rho_e = (float)((1. / (1. + u_e)) * (f0 + f2 + f4 + 2. * (f1 + f5 + f8)));
+                c[P(3)] = (float)(f1 - (2. / 3.) * rho_e * u_e);
+                c[P(6)] = (float)(f5 + (1. / 2.) * (f2 - f4) - (1. / 6.) * rho_e * u_e);
+                c[P(7)] = (float)(f8 - (1. / 2.) * (f2 - f4) - (1. / 6.) * rho_e * u_e);
+            }
+            if (y == ny - 1) {                                                    /* :306-311 */
+                c[P(4)] = f[P(4) + x]; c[P(8)] = f[P(8) + x]; c[P(7)] = f[P(7) + x];
+            }
+            if (y == 0) {                                                         /* :314-318 */
+                const size_t top = (size_t)(ny - 1) * nx + x;
+                c[P(2)] = f[P(2) + top]; c[P(6)] = f[P(6) + top]; c[P(5)] = f[P(5) + top];
+            }
+        }
+}
+
+/* D2Q9.cl:323-374 `update_hydro_PeriodicBC_VelocityInlet`: rho everywhere; u,v only for 0<x<nx-1; at
+ * the inlet / outlet (1<=y<=ny-2) rho from the Zou-He closure and u = u_w / u_e; v there and u,v on
+ * the four corner cells keep whatever they held. */
+void o2_moments_velocity_inlet(const float *f, float *rho, float *u, float *v, float u_w, float u_e, int nx, int ny)
+{
+    const size_t plane = (size_t)nx * ny;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            const size_t i = (size_t)y * nx + x;
+            const float f0 = f[P(0) + i], f1 = f[P(1) + i], f2 = f[P(2) + i], f3 = f[P(3) + i],
+                        f4 = f[P(4) + i], f5 = f[P(5) + i], f6 = f[P(6) + i], f7 = f[P(7) + i],
+                        f8 = f[P(8) + i];
+            float r = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
+            rho[i] = r;
+            float inv = (float)(1. / r);
+            if (x != 0 && x != nx - 1) {
+                u[i] = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
+                v[i] = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
+            }
+            if (x == 0 && y != 0 && y < ny - 1) {
+                rho[i] = (float)((1. / (1. - u_w)) * (f0 + f2 + f4 + 2. * (f3 + f6 + f7)));
+                u[i] = u_w;
+            }
+            if (x == nx - 1 && y != 0 && y < ny - 1) {
+                rho[i] = (float)((1. / (1. + u_e)) * (f0 + f2 + f4 + 2. * (f1 + f5 + f8)));
+                u[i] = u_e;
+            }
+        }
+}
+
 /* D2Q9.cl:398-433 `bounceback_in_obstacle`: on mask==1 exchange opposite links. */
 void o2_bounceback(const int32_t *mask, float *f, int nx, int ny)
 {
@@ -267,6 +333,7 @@ void o2_phase_bcs(o2_state *s)
 {
     if (s->bc_mode == BC_PIPE)   o2_bc_pipe(s->f, s->rho_in, s->rho_out, s->nx, s->ny);
     if (s->bc_mode == BC_CAVITY) o2_bc_cavity(s->f, s->lid_u, s->rho0, s->nx, s->ny);
+    if (s->bc_mode == BC_VELOCITY_INLET) o2_bc_velocity_inlet(s->f, s->u_w, s->u_e, s->nx, s->ny);
     if (s->mask) o2_bounceback(s->mask, s->f, s->nx, s->ny);
 }
 
@@ -275,7 +342,10 @@ void o2_run(o2_state *s, int n)
     for (int it = 0; it < n; ++it) {
         o2_phase_move(s);
         o2_phase_bcs(s);
-        o2_moments(s->f, s->rho, s->u, s->v, s->nx, s->ny);
+        if (s->bc_mode == BC_VELOCITY_INLET)
+            o2_moments_velocity_inlet(s->f, s->rho, s->u, s->v, s->u_w, s->u_e, s->nx, s->ny);
+        else
+            o2_moments(s->f, s->rho, s->u, s->v, s->nx, s->ny);
         o2_feq(s->feq, s->rho, s->u, s->v, s->cs2, s->two_cs2, s->two_cs4, s->nx, s->ny);
         o2_collide(s->f, s->feq, s->omega, s->nx, s->ny);
     }

@@ -94,6 +94,10 @@ void k_move(float *f, float *fs, int nx, int ny)
 { NDRANGE(9, move(f, fs, CXc, CYc, nx, ny)) }
 void k_move_bcs(float *f, float *u, float rin, float rout, int nx, int ny)
 { NDRANGE(1, move_bcs(f, u, rin, rout, nx, ny)) }
+void k_move_bcs_vel(float *f, float *u, float uw, float ue, int nx, int ny)
+{ NDRANGE(1, move_bcs_PeriodicBC_VelocityInlet(f, u, uw, ue, nx, ny)) }
+void k_update_hydro_vel(float *f, float *u, float *v, float *rho, float uw, float ue, int nx, int ny)
+{ NDRANGE(1, update_hydro_PeriodicBC_VelocityInlet(f, u, v, rho, uw, ue, nx, ny)) }
 void k_zero_vel(int *mask, float *u, float *v, int nx, int ny)
 { NDRANGE(1, set_zero_velocity_in_obstacle(mask, u, v, nx, ny)) }
 void k_bounceback(int *mask, float *f, int nx, int ny)
@@ -117,6 +121,8 @@ def build_o2(tmp):
     L.k_move.argtypes = [fp, fp, I, I]
     L.k_move_bcs.argtypes = [fp, fp, F, F, I, I]
     L.k_zero_vel.argtypes = [ip, fp, fp, I, I]
+    L.k_move_bcs_vel.argtypes = [fp, fp, F, F, I, I]
+    L.k_update_hydro_vel.argtypes = [fp, fp, fp, fp, F, F, I, I]
     L.k_bounceback.argtypes = [ip, fp, I, I]
     return L
 
@@ -283,6 +289,39 @@ def gen_o2(L):
     save("o2_cyl_61x31", **out)
 
 
+def gen_o2_velocity_inlet(L):
+    """The two velocity-inlet kernels of D2Q9.cl (:263-374), driven in the order of
+    OLD/opencl.py:281-327 (Pipe_Flow_PeriodicBC_VelocityInlet: rho=1, u=u_w, v=0 at start)."""
+    nx, ny, omega, uw = 45, 23, 1.1, 0.05
+    rng = np.random.default_rng(21)
+    s = RefOpenCL(L, nx, ny, omega, 1.0, 1.0)
+    s.rho[...] = 1.0
+    s.u[...] = uw
+    s.update_feq()
+    f0 = np.asfortranarray((s.feq * (1. + 0.001 * rng.standard_normal((nx, ny, 9)))).astype(np.float32))
+    s.f[...] = f0; s.fs[...] = f0
+    out = {"nx": nx, "ny": ny, "omega": omega, "u_w": uw, "u_e": uw, "f0": f0}
+    # one call of each kernel on the initial state
+    L.k_move_bcs_vel(P(s.f), P(s.u), np.float32(uw), np.float32(uw), nx, ny)
+    out["after_bcs_f"] = s.f.copy(order="F")
+    s.f[...] = f0
+    L.k_update_hydro_vel(P(s.f), P(s.u), P(s.v), P(s.rho), np.float32(uw), np.float32(uw), nx, ny)
+    out.update(hydro_rho=s.rho.copy(order="F"), hydro_u=s.u.copy(order="F"), hydro_v=s.v.copy(order="F"))
+    # runs
+    s.rho[...] = 1.0; s.u[...] = uw; s.v[...] = 0.0
+    done = 0
+    for n in (1, 20, 200):
+        for _ in range(n - done):
+            s.move()
+            L.k_move_bcs_vel(P(s.f), P(s.u), np.float32(uw), np.float32(uw), nx, ny)
+            L.k_update_hydro_vel(P(s.f), P(s.u), P(s.v), P(s.rho), np.float32(uw), np.float32(uw), nx, ny)
+            s.update_feq()
+            s.collide()
+        done = n
+        out.update(flat("s%d" % n, s.snap()))
+    save("o2_velocity_inlet_45x23", **out)
+
+
 # --------------------------------------------------------------------------
 #  O1: cython_dim.pyx compiled and imported
 # --------------------------------------------------------------------------
@@ -376,7 +415,12 @@ def gen_o1(m):
 def main():
     tmp = tempfile.mkdtemp(prefix="lb_golden_", dir="/tmp")
     print("scratch dir", tmp)
-    gen_o2(build_o2(tmp))
+    L = build_o2(tmp)
+    if "--only-velocity-inlet" not in sys.argv:
+        gen_o2(L)
+    gen_o2_velocity_inlet(L)
+    if "--only-velocity-inlet" in sys.argv:
+        return
     gen_o1(build_o1(tmp))
 
 

@@ -32,7 +32,7 @@ CX = np.array([0, 1, 0, -1, 0, 1, -1, -1, 1], dtype=np.int32)
 CY = np.array([0, 0, 1, 0, -1, 1, 1, -1, -1], dtype=np.int32)
 W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4, dtype=np.float32)
 
-BC_PIPE, BC_PERIODIC, BC_CAVITY = 0, 1, 2
+BC_PIPE, BC_PERIODIC, BC_CAVITY, BC_VELOCITY_INLET = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -52,7 +52,7 @@ _bp = ct.POINTER(ct.c_uint8)
 class _O2State(ct.Structure):
     _fields_ = [("nx", ct.c_int32), ("ny", ct.c_int32), ("bc_mode", ct.c_int32), ("_pad", ct.c_int32),
                 ("omega", ct.c_float), ("rho_in", ct.c_float), ("rho_out", ct.c_float),
-                ("lid_u", ct.c_float), ("rho0", ct.c_float),
+                ("lid_u", ct.c_float), ("rho0", ct.c_float), ("u_w", ct.c_float), ("u_e", ct.c_float),
                 ("cs2", ct.c_float), ("two_cs2", ct.c_float), ("two_cs4", ct.c_float),
                 ("f", _fp), ("fs", _fp), ("feq", _fp), ("rho", _fp), ("u", _fp), ("v", _fp),
                 ("mask", _ip)]
@@ -81,6 +81,8 @@ def lib():
         L.o2_copy.argtypes = [_fp, _fp, ct.c_int, ct.c_int]
         L.o2_bc_pipe.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
         L.o2_bc_cavity.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
+        L.o2_bc_velocity_inlet.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
+        L.o2_moments_velocity_inlet.argtypes = [_fp, _fp, _fp, _fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
         L.o2_bounceback.argtypes = [_ip, _fp, ct.c_int, ct.c_int]
         L.o2_zero_velocity.argtypes = [_ip, _fp, _fp, ct.c_int, ct.c_int]
         L.o2_moments.argtypes = [_fp, _fp, _fp, _fp, ct.c_int, ct.c_int]
@@ -176,7 +178,8 @@ class O2Sim(object):
     == the reference's F-ordered (nx, ny, 9) / (nx, ny) buffers."""
 
     def __init__(self, nx, ny, omega, bc_mode=BC_PIPE, inlet_rho=1., outlet_rho=1.,
-                 lid_u=0., rho0=1., mask=None):
+                 lid_u=0., rho0=1., mask=None, u_w=0., u_e=None):
+        self.u_w, self.u_e = u_w, (u_w if u_e is None else u_e)
         self.nx, self.ny = int(nx), int(ny)
         self.omega = omega
         self.bc_mode = bc_mode
@@ -216,6 +219,7 @@ class O2Sim(object):
         s.omega = np.float32(self.omega)
         s.rho_in, s.rho_out = np.float32(self.inlet_rho), np.float32(self.outlet_rho)
         s.lid_u, s.rho0 = np.float32(self.lid_u), np.float32(self.rho0)
+        s.u_w, s.u_e = np.float32(self.u_w), np.float32(self.u_e)
         s.cs2, s.two_cs2, s.two_cs4 = np.float32(cs2), np.float32(cs22), np.float32(two_cs4)
         s.f, s.fs, s.feq = _f(self.f), _f(self.fs), _f(self.feq)
         s.rho, s.u, s.v = _f(self.rho), _f(self.u), _f(self.v)
@@ -230,7 +234,11 @@ class O2Sim(object):
         lib().o2_phase_bcs(ct.byref(self._state()))
 
     def update_hydro(self):
-        lib().o2_moments(_f(self.f), _f(self.rho), _f(self.u), _f(self.v), self.nx, self.ny)
+        if self.bc_mode == BC_VELOCITY_INLET:
+            lib().o2_moments_velocity_inlet(_f(self.f), _f(self.rho), _f(self.u), _f(self.v),
+                                            np.float32(self.u_w), np.float32(self.u_e), self.nx, self.ny)
+        else:
+            lib().o2_moments(_f(self.f), _f(self.rho), _f(self.u), _f(self.v), self.nx, self.ny)
 
     def update_feq(self):
         lib().o2_feq(_f(self.feq), _f(self.rho), _f(self.u), _f(self.v),

@@ -403,3 +403,40 @@ def test_small_grid_graph_replay_equals_eager_steps(lbhip, bc):
         b.run(1)
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(a.get_fields((k,))[k], b.get_fields((k,))[k]), k
+
+
+def test_velocity_inlet_family_vs_reference_kernels(lbhip, oracle):
+    """The reference's velocity-inlet rule set (D2Q9.cl:263-374) on the GPU, phase by phase and over 200
+    steps, against the fixture produced by executing those kernels, then through the class."""
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.dimensionless import opencl_dim as lb
+    d = golden("o2_velocity_inlet_45x23")
+    nx, ny, uw = int(d["nx"]), int(d["ny"]), float(d["u_w"])
+    sim = Simulation(nx, ny, float(d["omega"]), bc="velocity_inlet", inlet_u=uw)
+    sim.set_f(d["f0"])
+    sim.move_bcs()
+    assert maxdiff(sim.get_fields(("f",))["f"], d["after_bcs_f"]) <= 2.5e-7
+    sim.set_f(d["f0"])
+    sim.set_fields(np.ones((nx, ny)), np.full((nx, ny), uw), np.zeros((nx, ny)))
+    sim.update_hydro()
+    g = sim.get_fields(("rho", "u", "v"))
+    assert maxdiff(g["rho"], d["hydro_rho"]) <= 5e-7 and maxdiff(g["u"], d["hydro_u"]) <= 1e-6
+    assert maxdiff(g["v"], d["hydro_v"]) <= 1e-6
+    sim.set_fields(np.ones((nx, ny)), np.full((nx, ny), uw), np.zeros((nx, ny)))
+    done = 0
+    for n in (1, 20, 200):
+        sim.run(n - done)
+        done = n
+        assert_fields_close(sim.get_fields(), d, TOL1 if n == 1 else TOLN, "s%d_" % n)
+    # the class: same overrides as OLD/opencl.py:281-327 on the dimensionless constructor
+    np.random.seed(3)
+    c = lb.Pipe_Flow_PeriodicBC_VelocityInlet(u_w=0.04, diameter=1., rho=1., viscosity=0.1, pressure_grad=-1.,
+                                              pipe_length=2., N=24, verbose=False)
+    np.random.seed(3)
+    perturb = 1. + .001 * np.random.randn(c.nx, c.ny, 9)
+    o = oracle.O2Sim(c.nx, c.ny, c.omega, oracle.BC_VELOCITY_INLET, u_w=0.04)
+    o.set_macro(np.ones((c.nx, c.ny)), np.full((c.nx, c.ny), 0.04), np.zeros((c.nx, c.ny)))
+    o.update_feq(); o.init_pop(perturb)
+    assert maxdiff(c.get_fields()["f"], o.get_fields()["f"]) <= 2.5e-7
+    c.run(100); o.run(100)
+    assert_fields_close(c.get_fields(), o.get_fields(), TOLN)

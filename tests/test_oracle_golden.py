@@ -190,3 +190,27 @@ def test_o1_and_o2_agree_in_the_interior_on_the_first_step(oracle):
     inner = (slice(3, -3), slice(3, -3))
     assert np.abs(g["rho"][inner] - o1.rho[inner]).max() <= 1e-6
     assert np.abs(g["u"][inner] - o1.u[inner]).max() <= 1e-6
+
+
+def test_o2_velocity_inlet_kernels_bit_exact(oracle):
+    """D2Q9.cl:263-374 (`move_bcs_PeriodicBC_VelocityInlet`, `update_hydro_PeriodicBC_VelocityInlet`), executed
+    through the same C shim as the other kernels, driven as OLD/opencl.py:281-327 drives them."""
+    O = oracle
+    d = golden("o2_velocity_inlet_45x23")
+    nx, ny, uw = int(d["nx"]), int(d["ny"]), float(d["u_w"])
+    s = O.O2Sim(nx, ny, float(d["omega"]), O.BC_VELOCITY_INLET, u_w=uw)
+    s.set_f(d["f0"])
+    O.lib().o2_bc_velocity_inlet(O._f(s.f), np.float32(uw), np.float32(uw), nx, ny)
+    assert exact(s.f.transpose(2, 1, 0), d["after_bcs_f"])
+    s.set_f(d["f0"])
+    s.set_macro(np.ones((nx, ny)), np.full((nx, ny), uw), np.zeros((nx, ny)))
+    s.update_hydro()
+    assert exact(s.rho.T, d["hydro_rho"]) and exact(s.u.T, d["hydro_u"]) and exact(s.v.T, d["hydro_v"])
+    s.set_macro(np.ones((nx, ny)), np.full((nx, ny), uw), np.zeros((nx, ny)))
+    done = 0
+    for n in (1, 20, 200):
+        s.run(n - done)
+        done = n
+        g = s.get_fields()
+        for k in ("f", "feq", "rho", "u", "v"):
+            assert exact(g[k], d["s%d_%s" % (n, k)]), (n, k)
