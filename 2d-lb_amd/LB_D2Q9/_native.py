@@ -24,7 +24,7 @@ EXPORTS = (
     "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_run",
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group",
-    "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch",
+    "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
 )
 
 
@@ -57,7 +57,7 @@ def lib():
     L.lb_create.argtypes = [ct.POINTER(LbParams), ct.POINTER(h)]
     for name in ("lb_destroy", "lb_sync", "lb_move", "lb_move_bcs", "lb_update_hydro", "lb_update_feq",
                  "lb_collide_particles", "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_step_finish",
-                 "lb_timer_start", "lb_steps_per_launch"):
+                 "lb_timer_start", "lb_steps_per_launch", "lb_autotune"):
         getattr(L, name).argtypes = [h]
     L.lb_set_stream.argtypes = [h, vp]
     L.lb_set_macro.argtypes = [h, vp, vp, vp]

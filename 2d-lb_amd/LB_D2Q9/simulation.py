@@ -320,6 +320,14 @@ class Simulation(object):
     def set_variant(self, variant):
         check(self._lib.lb_set_variant(self._h, int(variant)))
 
+    def autotune(self):
+        """Time the candidate fused-kernel configurations on a few live steps and keep the fastest for this
+        grid (bitwise-equivalent candidates).  Returns the number of time steps the simulation advanced."""
+        n = self._lib.lb_autotune(self._h)
+        if n < 0:
+            check(n)
+        return n
+
     def steps_per_launch(self):
         """2 when run() uses the two-steps-per-pass kernel for this grid/variant, else 1."""
         n = self._lib.lb_steps_per_launch(self._h)

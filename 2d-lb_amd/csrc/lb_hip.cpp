@@ -142,6 +142,8 @@ struct lb_sim {
     hipStream_t graph_stream = nullptr;
     bool graph_failed = false;
     int diag = 0;
+    int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1, 2, 3) chosen by lb_autotune
+    int tuned_wpc = 0;          // and its waves per CU for the marching kernels
     int64_t bytes = 0;
 
     float *origin(int which) const { return lat[which] + GUARD + GHOST * pitch; }   // plane 0, row 0, x 0
@@ -305,8 +307,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     } else {
         // as many wave-items as the chip holds at once (waves per CU from the kernel's register
         // budget; tunable), each marching an equal share of the rows
-        int waves_per_cu = 8;
-        if (const char *e = getenv("LB_STEP2_WAVES_PER_CU")) waves_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+        int waves_per_cu = s->tuned_wpc > 0 ? s->tuned_wpc : 8;
+        if (const char *e = getenv("LB_STEP2_WAVES_PER_CU")) waves_per_cu = atoi(e) > 0 ? atoi(e) : waves_per_cu;
         const int capacity = s->cu_count * waves_per_cu - reserve;
         const int rows = row_end - row_begin;
         segs = capacity / strips;
@@ -517,6 +519,88 @@ int slab_step_join(lb_sim *s)
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
     return LB_OK;
+}
+
+// n time steps on a whole-grid handle: largest fused kernel first in the remainder (n = 3a + rem with
+// the three-step kernel, 2a + rem with the two-step kernel), hipGraph replay for small grids.
+int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
+{
+    int rc;
+    const int v = effective_variant(s);
+    bool three = (v & 64) && step3_applicable(s);
+    bool two = (v & 32) && step2_applicable(s);
+    if (s->variant < 0 && s->tuned_steps) {            // lb_autotune's choice overrides the size heuristic
+        three = three && s->tuned_steps == 3;
+        two = two && s->tuned_steps >= 2;
+    }
+    int left = n_steps;
+    // Small grids are launch-bound (a 256^2 step is ~3 us of GPU work against ~5 us of host launch
+    // cost): replay GRAPH_STEPS single-step launches captured once into a hipGraph.
+    if (!three && !two && left > GRAPH_STEPS && small_grid(s)) {
+        if ((rc = ensure_graph(s))) return rc;
+        while (s->graph_exec && left > GRAPH_STEPS) {          // keep >= 1 step for the MACRO launch
+            HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+            left -= GRAPH_STEPS;                                // GRAPH_STEPS is even: cur is unchanged
+        }
+    }
+    while (left > 0) {
+        const int adv = next_advance(three, two, left);
+        const bool macro = final_macro && (left == adv);
+        if (adv == 3) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, true);
+        else if (adv == 2) rc = launch_step2(s, s->stream, 0, s->H, macro);
+        else rc = launch_step(s, 0, 1, s->H, macro);
+        if (rc) return rc;
+        s->cur ^= 1;
+        left -= adv;
+    }
+    if (n_steps) s->feq_valid = false;
+    return LB_OK;
+}
+
+// Time the candidate configurations of the fused kernels on LIVE steps (every configuration produces
+// bitwise identical results, so tuning advances the simulation like any other steps): three- and
+// two-step marching kernels at 8 and 4 waves per CU, and the single-step kernel.  Which one wins depends
+// on the grid's aspect ratio, the mask and the boundary family (wide, short pipes favour fewer, longer
+// segments: +20 % at 3751 x 1251).  Returns the number of steps advanced, or a negative status.
+int autotune_whole_grid(lb_sim *s, int rounds)
+{
+    struct Cand { int steps, wpc; };
+    const Cand cands[] = {{3, 8}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};
+    const int per = 6;                                 // steps per timed sample: 2 x 3 = 3 x 2 = 6 x 1
+    int used = 0, best = -1;
+    float best_ms = 0.f;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (size_t c = 0; c < sizeof(cands) / sizeof(cands[0]); ++c) {
+        if (cands[c].steps == 3 && !step3_applicable(s)) continue;
+        if (cands[c].steps == 2 && !step2_applicable(s)) continue;
+        s->tuned_steps = cands[c].steps;
+        s->tuned_wpc = cands[c].wpc;
+        float ms_min = 0.f;
+        for (int r = 0; r <= rounds; ++r) {            // round 0 warms the configuration up
+            HIP_TRY(hipEventRecord(e0, s->stream));
+            int rc = run_whole_grid(s, per, false);     // no rho,u,v epilogue: it would weigh on the short samples
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(e1, s->stream));
+            HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            used += per;
+            if (r >= 1 && (r == 1 || ms < ms_min)) ms_min = ms;
+        }
+        if (best < 0 || ms_min < best_ms) { best = (int)c; best_ms = ms_min; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    s->tuned_steps = cands[best].steps;
+    s->tuned_wpc = cands[best].wpc;
+    // one more step that stores rho,u,v so that the observable state is consistent again
+    int rc = launch_step(s, 0, 1, s->H, true);
+    if (rc) return rc;
+    s->cur ^= 1;
+    s->feq_valid = false;
+    return used + 1;
 }
 
 }  // namespace
@@ -1001,32 +1085,14 @@ int lb_run(lb_sim *s, int n_steps)
         return LB_OK;
     }
     if (!s->multi_slab()) {
-        // largest fused kernel first in the remainder: n = 3a + rem (three-step), or 2a + rem (two-step)
-        const int v = effective_variant(s);
-        const bool three = (v & 64) && step3_applicable(s);
-        const bool two = (v & 32) && step2_applicable(s);
-        int left = n_steps;
-        // Small grids are launch-bound (a 256^2 step is ~3 us of GPU work against ~5 us of host launch
-        // cost): replay GRAPH_STEPS single-step launches captured once into a hipGraph.
-        if (!three && !two && left > GRAPH_STEPS && small_grid(s)) {
-            if ((rc = ensure_graph(s))) return rc;
-            while (s->graph_exec && left > GRAPH_STEPS) {          // keep >= 1 step for the MACRO launch
-                HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
-                left -= GRAPH_STEPS;                                // GRAPH_STEPS is even: cur is unchanged
-            }
+        // Long first run with the automatic variant: time the candidate kernel configurations on the
+        // first steps of this very run (they are bitwise equivalent) and keep the fastest.
+        if (s->variant < 0 && !s->tuned_steps && n_steps >= 120 && (step2_applicable(s) || step3_applicable(s))) {
+            const int used = autotune_whole_grid(s, 2);   // <= 5 candidates x 3 samples x 6 steps + 1 = 91 steps
+            if (used < 0) return used;
+            n_steps -= used;
         }
-        while (left > 0) {
-            const int adv = next_advance(three, two, left);
-            const bool macro = (left == adv);
-            if (adv == 3) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, true);
-            else if (adv == 2) rc = launch_step2(s, s->stream, 0, s->H, macro);
-            else rc = launch_step(s, 0, 1, s->H, macro);
-            if (rc) return rc;
-            s->cur ^= 1;
-            left -= adv;
-        }
-        if (n_steps) s->feq_valid = false;
-        return LB_OK;
+        return run_whole_grid(s, n_steps);
     }
     if (!s->comm)
         return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
@@ -1184,8 +1250,22 @@ int lb_steps_per_launch(lb_sim *s)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
     const int v = effective_variant(s);
-    if ((v & 64) && step3_applicable(s)) return 3;
-    return ((v & 32) && step2_applicable(s)) ? 2 : 1;
+    int n = 1;
+    if ((v & 64) && step3_applicable(s)) n = 3;
+    else if ((v & 32) && step2_applicable(s)) n = 2;
+    if (s->variant < 0 && s->tuned_steps && !s->multi_slab() && s->tuned_steps < n) n = s->tuned_steps;
+    return n;
+}
+
+int lb_autotune(lb_sim *s)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune inside a split step");
+    if (s->multi_slab() || s->p.semantics != LB_SEM_OPENCL || s->p.bc_mode == LB_BC_VELOCITY_INLET ||
+        !(step2_applicable(s) || step3_applicable(s)))
+        return 0;                                      // nothing to choose between
+    DeviceGuard guard(s->p.device);
+    return autotune_whole_grid(s, 6);
 }
 
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)

@@ -156,6 +156,8 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
+    if dist is None:
+        eng.autotune()                         # picks the fused-kernel configuration for this grid (untimed)
     copy_gbs = None
     if args.calibrate:
         copy_gbs = {"plain": round(eng.copy_calibration(args.calibrate, False)[0], 1),

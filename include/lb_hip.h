@@ -176,6 +176,11 @@ int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_a
 /* Time steps advanced by one launch of the hot kernel in lb_run with the current variant:
  * 3 / 2 when the three- / two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch with it). */
 int lb_steps_per_launch(lb_sim *s);
+/* Pick the fastest configuration of the fused kernels for THIS grid by timing each candidate on a few
+ * live time steps (all candidates give bitwise identical results, so this simply advances the
+ * simulation): returns the number of steps advanced (0 when there is nothing to choose), <0 on error.
+ * lb_run does it by itself at the start of the first run of >= 120 steps with the automatic variant. */
+int lb_autotune(lb_sim *s);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
  * (which is scratch between steps).  *bytes_moved = bytes read + written.  Known traffic in the
  * fused kernel's access shape: corrects rocprofv3 FETCH_SIZE on gfx950 and gives the device's

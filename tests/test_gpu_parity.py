@@ -440,3 +440,34 @@ def test_velocity_inlet_family_vs_reference_kernels(lbhip, oracle):
     assert maxdiff(c.get_fields()["f"], o.get_fields()["f"]) <= 2.5e-7
     c.run(100); o.run(100)
     assert_fields_close(c.get_fields(), o.get_fields(), TOLN)
+
+
+def test_autotune_is_transparent(lbhip, oracle):
+    """lb_autotune times the candidate fused-kernel configurations on live steps; whatever it picks, the
+    trajectory is the one the single-step kernel produces (bitwise), also when a long run triggers it."""
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 1500, 300
+    rng = np.random.default_rng(12)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.02
+    mask[0, :] = mask[-1, :] = False
+    mask[:, 0] = mask[:, -1] = False
+    ref = Simulation(nx, ny, 1.3, bc="pipe", inlet_rho=1.002, obstacle_mask=mask)
+    ref.set_variant(0)
+    ref.set_f(f0)
+    a = Simulation(nx, ny, 1.3, bc="pipe", inlet_rho=1.002, obstacle_mask=mask)
+    a.set_f(f0)
+    used = a.autotune()
+    assert used > 0 and a.steps_per_launch() in (1, 2, 3)
+    ref.run(used)
+    for k in ("f", "rho", "u", "v"):
+        assert np.array_equal(a.get_fields((k,))[k], ref.get_fields((k,))[k]), k
+    a.run(31); ref.run(31)
+    assert np.array_equal(a.get_fields(("f",))["f"], ref.get_fields(("f",))["f"])
+    b = Simulation(nx, ny, 1.3, bc="pipe", inlet_rho=1.002, obstacle_mask=mask)
+    b.set_f(f0)
+    b.run(150)                                    # long first run: tunes itself on the way
+    ref2 = Simulation(nx, ny, 1.3, bc="pipe", inlet_rho=1.002, obstacle_mask=mask)
+    ref2.set_variant(0); ref2.set_f(f0); ref2.run(150)
+    for k in ("f", "rho", "u", "v"):
+        assert np.array_equal(b.get_fields((k,))[k], ref2.get_fields((k,))[k]), k
