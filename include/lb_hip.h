@@ -119,15 +119,16 @@ int lb_collide_particles(lb_sim *s);    /* kernels.collide_particles, :364-370 *
 int lb_zero_velocity_in_obstacle(lb_sim *s); /* kernels.set_zero_velocity_in_obstacle, :506-508 */
 int lb_init_pop(lb_sim *s);             /* f = f_streamed = feq (device side of init_pop, :308-327) */
 
-/* ---- the hot path: n fused time steps (replaces the body of
- *      Pipe_Flow.run, opencl_dim.py:372-387: move -> move_bcs(+obstacle) ->
- *      update_hydro -> update_feq -> collide_particles, 6-8 launches and as
- *      many host waits per step, by ONE launch per step and no host wait).
- *      rho,u,v of the LAST step are stored (they are only observable through
- *      get_fields); feq is rebuilt from them on demand.
- *      Multi-slab handles exchange their halo rows inside lb_run when a
- *      communicator is attached (lb_comm_init), otherwise the caller drives
- *      lb_step_boundary / lb_halo_export / lb_halo_import / lb_step_interior. */
+/* ---- the hot path: n time steps (replaces the body of Pipe_Flow.run, opencl_dim.py:372-387:
+ *      move -> move_bcs(+obstacle) -> update_hydro -> update_feq -> collide_particles, 6-8 launches and
+ *      as many host waits per step) by fused launches that advance one, two or three time steps each
+ *      (k_step, k_step2, k_step3; results bitwise independent of which) and no host wait.
+ *      rho,u,v of the LAST step are stored (they are only observable through get_fields); feq is
+ *      rebuilt from them on demand.  Handles with LB_SEM_CYTHON or LB_BC_VELOCITY_INLET run the
+ *      un-fused phase kernels in their reference order instead.
+ *      Multi-slab handles exchange their halo rows inside lb_run when a communicator is attached
+ *      (lb_comm_init), otherwise the caller drives lb_step_boundary / lb_halo_export /
+ *      lb_halo_import / lb_step_interior. */
 int lb_run(lb_sim *s, int n_steps);
 
 /* ---- row-slab decomposition (new: the reference is single-device) -------- */
