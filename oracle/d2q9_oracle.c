@@ -437,22 +437,33 @@ void o1_move(o1_state *s)
     const int nx = s->nx, ny = s->ny, lx = nx - 1, ly = ny - 1;
     const size_t plane = (size_t)nx * ny;
     float *f = s->f;
-    for (int j = ly; j > 0; --j)
-        for (int i = 0; i < lx; ++i) { F(2, i, j) = F(2, i, j - 1); F(6, i, j) = F(6, i + 1, j - 1); }
-    for (int j = ly; j > 0; --j)
-        for (int i = lx; i > 0; --i) { F(1, i, j) = F(1, i - 1, j); F(5, i, j) = F(5, i - 1, j - 1); }
-    for (int j = 0; j < ly; ++j)
-        for (int i = lx; i > 0; --i) { F(4, i, j) = F(4, i, j + 1); F(8, i, j) = F(8, i - 1, j + 1); }
-    for (int j = 0; j < ly; ++j)
-        for (int i = 0; i < lx; ++i) { F(3, i, j) = F(3, i + 1, j); F(7, i, j) = F(7, i + 1, j + 1); }
+    /* four loop nests over disjoint link pairs: independent of each other, sequential inside */
+#pragma omp parallel sections
+    {
+#pragma omp section
+        for (int j = ly; j > 0; --j)
+            for (int i = 0; i < lx; ++i) { F(2, i, j) = F(2, i, j - 1); F(6, i, j) = F(6, i + 1, j - 1); }
+#pragma omp section
+        for (int j = ly; j > 0; --j)
+            for (int i = lx; i > 0; --i) { F(1, i, j) = F(1, i - 1, j); F(5, i, j) = F(5, i - 1, j - 1); }
+#pragma omp section
+        for (int j = 0; j < ly; ++j)
+            for (int i = lx; i > 0; --i) { F(4, i, j) = F(4, i, j + 1); F(8, i, j) = F(8, i - 1, j + 1); }
+#pragma omp section
+        for (int j = 0; j < ly; ++j)
+            for (int i = 0; i < lx; ++i) { F(3, i, j) = F(3, i + 1, j); F(7, i, j) = F(7, i + 1, j + 1); }
+    }
 }
 
 /* cython_dim.pyx:302-333 `update_hydro` (+ :459-466 obstacle zeroing) */
 void o1_update_hydro(o1_state *s)
 {
+    /* the omp pragmas of the o1_* phases only take effect in the -fopenmp build used for the
+     * "all host cores" CPU baseline; every cell is independent, so results do not change */
     const int nx = s->nx, ny = s->ny, lx = nx - 1, ly = ny - 1;
     const size_t plane = (size_t)nx * ny;
     const float *f = s->f;
+#pragma omp parallel for schedule(static)
     for (size_t c = 0; c < plane; ++c) {
         /* np.sum(f, axis=0): plane-by-plane float32 accumulation */
         float r = f[c];
@@ -496,6 +507,7 @@ void o1_update_feq(o1_state *s)
     const double cs2 = cs * cs, cs22 = 2 * cs2, cssq = 2.0 / 9.0;
     const float w0 = (float)(4. / 9.), w1 = (float)(1. / 9.), w2 = (float)(1. / 36.);
     float *feq = s->feq;
+#pragma omp parallel for schedule(static)
     for (size_t c = 0; c < plane; ++c) {
         const double u = s->u[c], v = s->v[c];
         const float rho = s->rho[c];
@@ -525,9 +537,11 @@ void o1_collide(o1_state *s)
     const float *feq = s->feq;
     if (s->numpy2) {
         const double om = s->omega, om1 = 1. - s->omega;
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i) f[i] = (float)((double)f[i] * om1 + om * (double)feq[i]);
     } else {
         const float om = (float)s->omega, om1 = (float)(1. - s->omega);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i) f[i] = f[i] * om1 + om * feq[i];
     }
 }

@@ -22,6 +22,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libd2q9_oracle.so")
+_LIB_OMP_PATH = os.path.join(_HERE, "_build", "libd2q9_oracle_omp.so")   # same source, -fopenmp (CPU baseline only)
 
 # D2Q9 constants exactly as the reference forms them (opencl_dim.py:22-36)
 cs = 1.0 / np.sqrt(3)
@@ -38,7 +39,8 @@ BC_PIPE, BC_PERIODIC, BC_CAVITY, BC_VELOCITY_INLET = 0, 1, 2, 3
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "d2q9_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    stale = lambda p: not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src)
+    if force or stale(_LIB_PATH) or stale(_LIB_OMP_PATH):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
@@ -65,6 +67,20 @@ class _O1State(ct.Structure):
 
 
 _lib = None
+_lib_omp = None
+
+
+def lib_omp():
+    """The -fopenmp build of the same source: only the o1_* phase entry points, only for timing the
+    Cython-path port on all host cores (bench.py cpu_baseline)."""
+    global _lib_omp
+    if _lib_omp is None:
+        build()
+        L = ct.CDLL(_LIB_OMP_PATH)
+        L.o1_run.argtypes = [ct.POINTER(_O1State), ct.c_int]
+        L.o1_run.restype = None
+        _lib_omp = L
+    return _lib_omp
 
 
 def lib():
@@ -328,8 +344,8 @@ class O1Sim(object):
     def collide_particles(self):
         lib().o1_collide(ct.byref(self._state()))
 
-    def run(self, n):
-        lib().o1_run(ct.byref(self._state()), int(n))
+    def run(self, n, openmp=False):
+        (lib_omp() if openmp else lib()).o1_run(ct.byref(self._state()), int(n))
 
     def init_pop(self, perturb_xy=None):
         """f = feq * perturb, perturb (nx,ny) shared by the 9 links (cython_dim.pyx:191-202)."""
