@@ -26,7 +26,7 @@ def test_cpu_baseline_leg_reports_the_contract_keys():
     import bench
     r = bench.cpu_baseline(budget_s=0.5, n=128, all_cores_budget_s=0.3)
     assert set(r) == {"value", "unit", "cores", "kind", "sample", "all_cores"}
-    assert r["all_cores"]["cores"] >= 1 and r["all_cores"]["value"] > 0.1
+    assert r["all_cores"]["cores"] >= 1 and r["all_cores"]["value"] > 0
     assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "MLUPS" and r["value"] > 0.1
 
 
