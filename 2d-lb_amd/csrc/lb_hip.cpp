@@ -840,7 +840,7 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     if (!mask) {
-        s->has_mask = false;
+        s->has_mask = false;      // (takes effect with the next launch; nothing to upload)
         return LB_OK;
     }
     const size_t n = (size_t)s->pitch * s->H;
@@ -853,6 +853,10 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
             tmp[(size_t)y * s->pitch + x] = m;
             any |= m;
         }
+    // kernels of an un-waited run() may still be reading the mask: the handle's streams are
+    // non-blocking, so order the upload behind them explicitly
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamSynchronize(s->edge_stream);
     hipError_t e = hipMemcpy(s->mask, tmp, n, hipMemcpyHostToDevice);
     free(tmp);
     if (e != hipSuccess) return fail(LB_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
@@ -870,6 +874,8 @@ int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_
     uint8_t *tmp = (uint8_t *)calloc((size_t)s->pitch * MASK_GHOST, 1);
     if (!tmp) return fail(LB_ERR_ARG, "out of host memory");
     // south_rows = global rows y0-2, y0-1; north_rows = rows y0+H, y0+H+1 (each [2][nx], nearest last / first)
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamSynchronize(s->edge_stream);
     const int32_t *rows[2] = {south_rows, north_rows};
     uint8_t *dst[2] = {s->mask - (size_t)MASK_GHOST * s->pitch, s->mask + (size_t)s->H * s->pitch};
     for (int side = 0; side < 2; ++side) {
