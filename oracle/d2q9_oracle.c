@@ -45,6 +45,7 @@ typedef struct {
     float cs2, two_cs2, two_cs4;          /* float32 casts made by the host, opencl_dim.py:305 */
     float *f, *fs, *feq, *rho, *u, *v;
     const int32_t *mask;                  /* NULL when there is no obstacle */
+    int32_t d2q9i, _pad2;                 /* 1: the kernels of LB_D2Q9/D2Q9i.cl ("incompressible" fork) */
 } o2_state;
 
 #define P(k) ((size_t)(k) * plane)
@@ -320,6 +321,87 @@ void o2_collide(float *f, const float *feq, float omega, int nx, int ny)
         f[i] = f[i] * (1 - omega) + omega * feq[i];
 }
 
+/* ---- LB_D2Q9/D2Q9i.cl: the "incompressible" fork.  Identical to D2Q9.cl except for the three routines
+ * below (and an unused local in the wall rules); host: dimensionless/opencl_dim_D2Q9i.py. ---------- */
+
+/* D2Q9i.cl:190-205: inlet / outlet of `move_bcs`; walls and corners as in D2Q9.cl */
+void o2i_bc_pipe(float *f, float rho_in, float rho_out, int nx, int ny)
+{
+    const size_t plane = (size_t)nx * ny;
+    /* the inlet / outlet columns get the fork's formulas ... */
+    for (int y = 1; y < ny - 1; ++y) {
+        float *c = f + (size_t)y * nx;
+        {
+            const float f0 = c[P(0)], f2 = c[P(2)], f3 = c[P(3)], f4 = c[P(4)], f6 = c[P(6)], f7 = c[P(7)];
+            float uu = -f0 - f2 - 2 * f3 - f4 - 2 * f6 - 2 * f7 + rho_in;
+            c[P(1)] = (float)((1. / 3.) * (3 * f3 + 2 * uu));
+            c[P(5)] = (float)((1. / 6.) * (-3 * f2 + 3 * f4 + 6 * f7 + uu));
+            c[P(8)] = (float)((1. / 6.) * (3 * f2 - 3 * f4 + 6 * f6 + uu));
+        }
+        c += nx - 1;
+        {
+            const float f0 = c[P(0)], f1 = c[P(1)], f2 = c[P(2)], f4 = c[P(4)], f5 = c[P(5)], f8 = c[P(8)];
+            float uu = f0 + 2 * f1 + f2 + f4 + 2 * f5 + 2 * f8 - rho_out;
+            c[P(3)] = (float)((1. / 3.) * (3 * f1 - 2 * uu));
+            c[P(6)] = (float)((1. / 6.) * (-3 * f2 + 3 * f4 + 6 * f8 - uu));
+            c[P(7)] = (float)((1. / 6.) * (3 * f2 - 3 * f4 + 6 * f5 - uu));
+        }
+    }
+    /* ... walls and corners the common ones: run the D2Q9 rule on rows 0 and ny-1 only */
+    for (int y = 0; y < ny; y += (ny - 1)) {
+        float *row = f + (size_t)y * nx;
+        /* build a 1-row view by calling the shared routine on a temporary with the same edge logic */
+        for (int x = 0; x < nx; ++x) {
+            float *c = row + x;
+            const int on_w = (x == 0), on_e = (x == nx - 1), on_s = (y == 0), on_n = (y == ny - 1);
+            const float f0 = c[P(0)], f1 = c[P(1)], f2 = c[P(2)], f3 = c[P(3)], f4 = c[P(4)],
+                        f5 = c[P(5)], f6 = c[P(6)], f7 = c[P(7)], f8 = c[P(8)];
+            if (on_n && !on_w && !on_e) { c[P(4)] = f2; c[P(8)] = (float)(.5 * (-f1 + f3 + 2 * f6)); c[P(7)] = (float)(.5 * (f1 - f3 + 2 * f5)); }
+            if (on_s && !on_w && !on_e) { c[P(2)] = f4; c[P(6)] = (float)(.5 * (f1 - f3 + 2 * f8)); c[P(5)] = (float)(.5 * (-f1 + f3 + 2 * f7)); }
+            if (on_w && on_s) { float t = (float)(.5 * (-f0 - 2 * f3 - 2 * f4 - 2 * f7 + rho_in));
+                                c[P(1)] = f3; c[P(2)] = f4; c[P(5)] = f7; c[P(6)] = t; c[P(8)] = t; }
+            if (on_w && on_n) { float t = (float)(.5 * (-f0 - 2 * f2 - 2 * f3 - 2 * f6 + rho_in));
+                                c[P(1)] = f3; c[P(4)] = f2; c[P(8)] = f6; c[P(5)] = t; c[P(7)] = t; }
+            if (on_e && on_s) { float t = (float)(.5 * (-f0 - 2 * f1 - 2 * f4 - 2 * f8 + rho_out));
+                                c[P(3)] = f1; c[P(2)] = f4; c[P(6)] = f8; c[P(5)] = t; c[P(7)] = t; }
+            if (on_e && on_n) { float t = (float)(.5 * (-f0 - 2 * f1 - 2 * f2 - 2 * f5 + rho_out));
+                                c[P(3)] = f1; c[P(4)] = f2; c[P(7)] = f5; c[P(6)] = t; c[P(8)] = t; }
+        }
+        if (ny == 1) break;
+    }
+}
+
+/* D2Q9i.cl:88-94 `update_hydro`: momentum, not velocity (no division by rho) */
+void o2i_moments(const float *f, float *rho, float *u, float *v, int nx, int ny)
+{
+    const size_t plane = (size_t)nx * ny;
+    for (size_t i = 0; i < plane; ++i) {
+        const float f0 = f[P(0) + i], f1 = f[P(1) + i], f2 = f[P(2) + i], f3 = f[P(3) + i],
+                    f4 = f[P(4) + i], f5 = f[P(5) + i], f6 = f[P(6) + i], f7 = f[P(7) + i],
+                    f8 = f[P(8) + i];
+        rho[i] = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
+        u[i] = (f1 + f5 + f8 - f6 - f3 - f7);
+        v[i] = (f6 + f2 + f5 - f7 - f4 - f8);
+    }
+}
+
+/* D2Q9i.cl:55-62 `update_feq`: inner = rho + 3 cu + 4.5 cu^2 - 1.5 usq formed in double (the literals
+ * 3., 9./2., 3./2. are double), rounded to float, then w*rho*inner in float */
+void o2i_feq(float *feq, const float *rho, const float *u, const float *v, int nx, int ny)
+{
+    static const float W[9] = {(float)(4. / 9.), (float)(1. / 9.), (float)(1. / 9.),
+                               (float)(1. / 9.), (float)(1. / 9.), (float)(1. / 36.),
+                               (float)(1. / 36.), (float)(1. / 36.), (float)(1. / 36.)};
+    const size_t plane = (size_t)nx * ny;
+    for (int k = 0; k < 9; ++k)
+        for (size_t i = 0; i < plane; ++i) {
+            float cu = CX[k] * u[i] + CY[k] * v[i];
+            float usq = u[i] * u[i] + v[i] * v[i];
+            float inner = (float)(rho[i] + 3. * cu + (9. / 2.) * (cu * cu) - (3. / 2.) * usq);
+            feq[P(k) + i] = W[k] * rho[i] * inner;
+        }
+}
+
 /* Individual phases in the order of opencl_dim.py:380-387 (Pipe_Flow.run) with
  * the obstacle hook of Pipe_Flow_Cylinder.move_bcs (:510-518). */
 void o2_phase_move(o2_state *s)
@@ -331,7 +413,8 @@ void o2_phase_move(o2_state *s)
 
 void o2_phase_bcs(o2_state *s)
 {
-    if (s->bc_mode == BC_PIPE)   o2_bc_pipe(s->f, s->rho_in, s->rho_out, s->nx, s->ny);
+    if (s->bc_mode == BC_PIPE && s->d2q9i) o2i_bc_pipe(s->f, s->rho_in, s->rho_out, s->nx, s->ny);
+    else if (s->bc_mode == BC_PIPE) o2_bc_pipe(s->f, s->rho_in, s->rho_out, s->nx, s->ny);
     if (s->bc_mode == BC_CAVITY) o2_bc_cavity(s->f, s->lid_u, s->rho0, s->nx, s->ny);
     if (s->bc_mode == BC_VELOCITY_INLET) o2_bc_velocity_inlet(s->f, s->u_w, s->u_e, s->nx, s->ny);
     if (s->mask) o2_bounceback(s->mask, s->f, s->nx, s->ny);
@@ -344,9 +427,16 @@ void o2_run(o2_state *s, int n)
         o2_phase_bcs(s);
         if (s->bc_mode == BC_VELOCITY_INLET)
             o2_moments_velocity_inlet(s->f, s->rho, s->u, s->v, s->u_w, s->u_e, s->nx, s->ny);
+        else if (s->d2q9i)
+            o2i_moments(s->f, s->rho, s->u, s->v, s->nx, s->ny);
         else
             o2_moments(s->f, s->rho, s->u, s->v, s->nx, s->ny);
-        o2_feq(s->feq, s->rho, s->u, s->v, s->cs2, s->two_cs2, s->two_cs4, s->nx, s->ny);
+        if (s->d2q9i) {
+            /* opencl_dim_D2Q9i.py:494-503: the cylinder class re-zeroes u,v in the obstacle every step */
+            if (s->mask) o2_zero_velocity(s->mask, s->u, s->v, s->nx, s->ny);
+            o2i_feq(s->feq, s->rho, s->u, s->v, s->nx, s->ny);
+        } else
+            o2_feq(s->feq, s->rho, s->u, s->v, s->cs2, s->two_cs2, s->two_cs4, s->nx, s->ny);
         o2_collide(s->f, s->feq, s->omega, s->nx, s->ny);
     }
 }

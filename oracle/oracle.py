@@ -57,7 +57,7 @@ class _O2State(ct.Structure):
                 ("lid_u", ct.c_float), ("rho0", ct.c_float), ("u_w", ct.c_float), ("u_e", ct.c_float),
                 ("cs2", ct.c_float), ("two_cs2", ct.c_float), ("two_cs4", ct.c_float),
                 ("f", _fp), ("fs", _fp), ("feq", _fp), ("rho", _fp), ("u", _fp), ("v", _fp),
-                ("mask", _ip)]
+                ("mask", _ip), ("d2q9i", ct.c_int32), ("_pad2", ct.c_int32)]
 
 
 class _O1State(ct.Structure):
@@ -97,6 +97,9 @@ def lib():
         L.o2_copy.argtypes = [_fp, _fp, ct.c_int, ct.c_int]
         L.o2_bc_pipe.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
         L.o2_bc_cavity.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
+        L.o2i_bc_pipe.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
+        L.o2i_moments.argtypes = [_fp, _fp, _fp, _fp, ct.c_int, ct.c_int]
+        L.o2i_feq.argtypes = [_fp, _fp, _fp, _fp, ct.c_int, ct.c_int]
         L.o2_bc_velocity_inlet.argtypes = [_fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
         L.o2_moments_velocity_inlet.argtypes = [_fp, _fp, _fp, _fp, ct.c_float, ct.c_float, ct.c_int, ct.c_int]
         L.o2_bounceback.argtypes = [_ip, _fp, ct.c_int, ct.c_int]
@@ -194,8 +197,9 @@ class O2Sim(object):
     == the reference's F-ordered (nx, ny, 9) / (nx, ny) buffers."""
 
     def __init__(self, nx, ny, omega, bc_mode=BC_PIPE, inlet_rho=1., outlet_rho=1.,
-                 lid_u=0., rho0=1., mask=None, u_w=0., u_e=None):
+                 lid_u=0., rho0=1., mask=None, u_w=0., u_e=None, d2q9i=False):
         self.u_w, self.u_e = u_w, (u_w if u_e is None else u_e)
+        self.d2q9i = bool(d2q9i)         # the kernels of D2Q9i.cl instead of D2Q9.cl
         self.nx, self.ny = int(nx), int(ny)
         self.omega = omega
         self.bc_mode = bc_mode
@@ -240,6 +244,7 @@ class O2Sim(object):
         s.f, s.fs, s.feq = _f(self.f), _f(self.fs), _f(self.feq)
         s.rho, s.u, s.v = _f(self.rho), _f(self.u), _f(self.v)
         s.mask = self.mask.ctypes.data_as(_ip) if self.mask is not None else None
+        s.d2q9i = int(self.d2q9i)
         return s
 
     # -- the reference's methods ----------------------------------------
@@ -253,10 +258,16 @@ class O2Sim(object):
         if self.bc_mode == BC_VELOCITY_INLET:
             lib().o2_moments_velocity_inlet(_f(self.f), _f(self.rho), _f(self.u), _f(self.v),
                                             np.float32(self.u_w), np.float32(self.u_e), self.nx, self.ny)
+        elif self.d2q9i:
+            lib().o2i_moments(_f(self.f), _f(self.rho), _f(self.u), _f(self.v), self.nx, self.ny)
+            self.zero_velocity_in_obstacle()
         else:
             lib().o2_moments(_f(self.f), _f(self.rho), _f(self.u), _f(self.v), self.nx, self.ny)
 
     def update_feq(self):
+        if self.d2q9i:
+            lib().o2i_feq(_f(self.feq), _f(self.rho), _f(self.u), _f(self.v), self.nx, self.ny)
+            return
         lib().o2_feq(_f(self.feq), _f(self.rho), _f(self.u), _f(self.v),
                      np.float32(cs2), np.float32(cs22), np.float32(two_cs4), self.nx, self.ny)
 

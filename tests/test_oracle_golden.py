@@ -214,3 +214,36 @@ def test_o2_velocity_inlet_kernels_bit_exact(oracle):
         g = s.get_fields()
         for k in ("f", "feq", "rho", "u", "v"):
             assert exact(g[k], d["s%d_%s" % (n, k)]), (n, k)
+
+
+def test_o2_d2q9i_fork_bit_exact_and_unstable(oracle):
+    """LB_D2Q9/D2Q9i.cl (SURVEY: experimental fork, used by no notebook).  The oracle restates its three
+    differing routines bit-exactly - and the executed reference itself diverges: |u| grows ~10x in ten
+    steps from a 2e-4 density drop and is NaN by step 60.  That is why the engine does not offer it."""
+    O = oracle
+    d = golden("o2_d2q9i_53x27")
+    nx, ny = int(d["nx"]), int(d["ny"])
+
+    def fresh():
+        s = O.O2Sim(nx, ny, float(d["omega"]), O.BC_PIPE, float(d["inlet_rho"]), float(d["outlet_rho"]),
+                    mask=d["mask"], d2q9i=True)
+        s.set_f(d["f0"])
+        return s
+
+    s = fresh()
+    O.lib().o2i_bc_pipe(O._f(s.f), np.float32(s.inlet_rho), np.float32(s.outlet_rho), nx, ny)
+    assert exact(s.f.transpose(2, 1, 0), d["after_bcs_f"])
+    s = fresh()
+    O.lib().o2i_moments(O._f(s.f), O._f(s.rho), O._f(s.u), O._f(s.v), nx, ny)
+    assert exact(s.rho.T, d["hydro_rho"]) and exact(s.u.T, d["hydro_u"]) and exact(s.v.T, d["hydro_v"])
+    s.update_feq()
+    assert exact(s.feq.transpose(2, 1, 0), d["feq1"])
+    s = fresh()
+    s.run(1)
+    for k in ("f", "feq", "rho", "u", "v"):
+        assert exact(s.get_fields()[k], d["s1_" + k]), k
+    s.run(9)
+    for k in ("f", "rho", "u", "v"):
+        assert exact(s.get_fields()[k], d["s10_" + k]), k
+    assert np.abs(d["s10_u"]).max() > 10 * np.abs(d["s1_u"]).max()        # already running away
+    assert np.isnan(d["s60_u"]).any()                                     # the reference execution blew up
