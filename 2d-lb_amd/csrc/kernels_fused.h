@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
                 halo_cell_step1<BC, MASK>(a, hxo, rr, ym, yp, c);
                 ho_new = halo_links(c, left);
             }
+#ifdef LB_DIAG
+            if (!(a.diag & 1))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + rr, q1, mk, r4, u4, v4);
         } else {
 #pragma unroll
@@ -494,6 +497,9 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
             }
             uc4 mk2 = {0, 0, 0, 0};
             if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + (long long)r2 * a.pitch + x4);
+#ifdef LB_DIAG
+            if (!(a.diag & 2))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk2, r4, u4, v4);
         } else {
 #pragma unroll
@@ -508,6 +514,9 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
             const long long o = (long long)r3 * a.pitch + x4;
             uc4 mk3 = {0, 0, 0, 0};
             if (MASK) mk3 = *reinterpret_cast<const uc4 *>(a.mask + o);
+#ifdef LB_DIAG
+            if (!(a.diag & 4))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk3, r4, u4, v4);
             if (store_lane) {
                 float *d = a.dst + o;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timing of the fused kernels (diagnostic build, wrong results by design, timing only).
-LB_DIAG bits: 1 = skip step-1 collide, 2 = skip step-2 collide, 4 = no stores, 8 = all loads aligned.
+LB_DIAG bits: 1 = skip step-1 collide, 2 = skip step-2 collide, 4 = no stores (k_step2) / skip step-3 collide
+(k_step3), 8 = all loads aligned.
 Each configuration runs in its own process (the switches are read at lb_create)."""
 import os
 import subprocess
@@ -32,11 +33,11 @@ def main():
                            (4, "no stores"), (8, "aligned loads"), (11, "no collide, aligned loads"),
                            (7, "loads only"), (16, "aligned 256-cell strips"), (19, "aligned strips, no collide"),
                            (17, "aligned strips, no step-1 collide")) + \
-                (((32, "NT loads"), (64, "segment row per XCD"), (96, "NT loads + segment row per XCD"), (0, "full again"))
+                (((7, "no collide at all (3 steps)"), (0, "full again"))
                  if name == "k_step3" else ()):
             if name == "k_step" and diag in (2, 3, 4, 7, 11, 16, 19, 17):
                 continue
-            if name == "k_step3" and diag not in (0, 1, 32, 64, 96):
+            if name == "k_step3" and diag not in (0, 1, 7):
                 continue
             env = dict(os.environ, LB_LIB=lib, LB_DIAG=str(diag))
             out = subprocess.run([sys.executable, "-c", CHILD, str(n), str(variant)], env=env, capture_output=True, text=True)
