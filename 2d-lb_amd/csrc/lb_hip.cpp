@@ -444,7 +444,7 @@ float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
     return s->origin(which) + h.k * s->plane + row * s->pitch;
 }
 
-int exchange_rccl(lb_sim *s, int which)
+int exchange_rccl(lb_sim *s, int which, hipStream_t q)
 {
     // neighbours: south = rank-1, north = rank+1; PERIODIC wraps, walls have none
     const bool wrap = (s->p.bc_mode == LB_BC_PERIODIC);
@@ -453,19 +453,19 @@ int exchange_rccl(lb_sim *s, int which)
     const size_t n = (size_t)HALO_SEGS * s->p.nx;
     float *send_n = s->halo_buf, *send_s = s->halo_buf + n, *recv_s = s->halo_buf + 2 * n, *recv_n = s->halo_buf + 3 * n;
     const dim3 grid((s->p.nx + 255) / 256, HALO_SEGS, 2);
-    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, s->comm_stream, s->origin(which), s->plane, (int)s->pitch,
+    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch,
                        s->H, s->p.nx, north >= 0 ? send_n : nullptr, south >= 0 ? send_s : nullptr);
     HIP_TRY(hipGetLastError());
     // One send and one receive per neighbour.  Posting order matters when both neighbours are the same
     // rank (2 ranks, or 1 rank talking to itself, in a periodic box): sends go north-then-south,
     // receives south-then-north, so the n-th send to a peer meets the n-th receive it posted for us.
     NCCL_TRY(g_rccl.GroupStart());
-    if (north >= 0) NCCL_TRY(g_rccl.Send(send_n, n, ncclFloat, north, s->comm, s->comm_stream));
-    if (south >= 0) NCCL_TRY(g_rccl.Send(send_s, n, ncclFloat, south, s->comm, s->comm_stream));
-    if (south >= 0) NCCL_TRY(g_rccl.Recv(recv_s, n, ncclFloat, south, s->comm, s->comm_stream));
-    if (north >= 0) NCCL_TRY(g_rccl.Recv(recv_n, n, ncclFloat, north, s->comm, s->comm_stream));
+    if (north >= 0) NCCL_TRY(g_rccl.Send(send_n, n, ncclFloat, north, s->comm, q));
+    if (south >= 0) NCCL_TRY(g_rccl.Send(send_s, n, ncclFloat, south, s->comm, q));
+    if (south >= 0) NCCL_TRY(g_rccl.Recv(recv_s, n, ncclFloat, south, s->comm, q));
+    if (north >= 0) NCCL_TRY(g_rccl.Recv(recv_n, n, ncclFloat, north, s->comm, q));
     NCCL_TRY(g_rccl.GroupEnd());
-    hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, s->comm_stream, s->origin(which), s->plane, (int)s->pitch,
+    hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch,
                        s->H, s->p.nx, south >= 0 ? recv_s : nullptr, north >= 0 ? recv_n : nullptr);
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -680,9 +680,10 @@ int lb_create(const lb_params *p, lb_sim **out)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, hi));
     }
-    CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming));
+    const unsigned ev_flags = hipEventDisableTiming;
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, ev_flags));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_halo, ev_flags));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_interior, ev_flags));
     CREATE_TRY(hipEventCreate(&s->ev_t0));
     CREATE_TRY(hipEventCreate(&s->ev_t1));
     const size_t lat_bytes = sizeof(float) * s->lat_floats;
@@ -1104,16 +1105,18 @@ int lb_run(lb_sim *s, int n_steps)
         return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
     if (n_steps == 0) return LB_OK;
     if (s->H < 6) return fail(LB_ERR_ARG, "a slab needs at least 6 rows (has %d)", s->H);
-    // everything enqueued so far on the compute stream happens before the first edge launch
+    // Two queues.  The edge stream (high priority) carries the dependency chain of the slab as it is:
+    // edge rows of step t -> pack -> RCCL send/recv -> unpack -> edge rows of step t+1, in order, no
+    // events in between.  The compute stream carries the interior rows.  Across the two, per launch:
+    // the edge kernel waits for the previous interior kernel (it reads 3 rows past the band), the
+    // interior kernel for the previous edge kernel (it reads rows 0..H-1, never the ghost rows, so it
+    // does not wait for the exchange).  Every cross-queue wait costs ~2 us per step on this part even
+    // when long satisfied (profiles/r01_slab_timeline.txt), hence as few as the data flow allows.
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     if (!s->ghosts_valid) {
         // ghost rows of the current lattice: exchange once before the first step
-        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_interior, 0));
-        if ((rc = exchange_rccl(s, s->cur))) return rc;
-        HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
-        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
-        HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
+        if ((rc = exchange_rccl(s, s->cur, s->edge_stream))) return rc;
     }
     const bool two = (effective_variant(s) & 32) && step2_applicable(s);
     const bool three = (effective_variant(s) & 64) && step3_applicable(s);
@@ -1121,16 +1124,18 @@ int lb_run(lb_sim *s, int n_steps)
         const int adv = next_advance(three, two, left);
         // 1. edge rows (edge stream) and interior rows (compute stream) of the new lattice, concurrently
         if ((rc = slab_step_launch(s, adv, left == adv))) return rc;
-        // 2. halo of the lattice just written, on the communication stream (RCCL over xGMI), as soon as
-        //    the edge rows are done and while the interior is still being computed
-        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
-        if ((rc = exchange_rccl(s, s->cur ^ 1))) return rc;
-        HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
-        // 3. the next step reads the new lattice: both compute streams wait for kernels and halo
-        if ((rc = slab_step_join(s))) return rc;
+        // 2. halo of the lattice just written, behind the edge kernel on its stream (RCCL over xGMI),
+        //    while the interior is still being computed
+        if ((rc = exchange_rccl(s, s->cur ^ 1, s->edge_stream))) return rc;
+        // 3. the next launches read the new lattice
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+        HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
         s->cur ^= 1;
         left -= adv;
     }
+    // the caller's stream sees the whole state, ghost rows included
+    HIP_TRY(hipEventRecord(s->ev_halo, s->edge_stream));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
     s->ghosts_valid = true;
     s->feq_valid = false;
     return LB_OK;
