@@ -128,7 +128,8 @@ class Simulation(object):
         check(self._lib.lb_set_mask(self._h, m.ctypes.data))
         if self._halo and self.local_ny == self.ny and self.bc_mode == _native.LB_BC_PERIODIC:
             # a whole periodic grid run through the halo path is its own neighbour
-            self.set_obstacle_mask_halo(m[:, [-2, -1]].T, m[:, [0, 1]].T)
+            rows = np.arange(self.MASK_HALO_ROWS)
+            self.set_obstacle_mask_halo(m[:, (rows - self.MASK_HALO_ROWS) % self.ny].T, m[:, rows % self.ny].T)
 
     def set_fields(self, rho, u, v):
         """Upload the macroscopic fields (what init_hydro does, opencl_dim.py:291-293)."""
@@ -278,13 +279,15 @@ class Simulation(object):
         """Length of one halo buffer in floats (18 row segments of nx, three rows deep)."""
         return self.HALO_SEGMENTS * self.nx
 
+    MASK_HALO_ROWS = _native.LB_MASK_HALO_ROWS
+
     def set_obstacle_mask_halo(self, south_rows=None, north_rows=None):
-        """Mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-2, y0-1,
-        north_rows = rows y0+H, y0+H+1, each (2, nx), non-zero = solid; None = no solid cells."""
+        """Mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-5 .. y0-1,
+        north_rows = rows y0+H .. y0+H+4, each (MASK_HALO_ROWS, nx), non-zero = solid; None = no solid cells."""
         rows = []
         for r in (south_rows, north_rows):
-            if r is not None and np.asarray(r).shape != (2, self.nx):
-                raise ValueError("mask halo must have shape (2, nx)")
+            if r is not None and np.asarray(r).shape != (self.MASK_HALO_ROWS, self.nx):
+                raise ValueError("mask halo must have shape (%d, nx)" % self.MASK_HALO_ROWS)
             rows.append(None if r is None else np.ascontiguousarray((np.asarray(r) != 0).astype(np.int32)))
         ptr = lambda a: None if a is None else a.ctypes.data
         check(self._lib.lb_set_mask_halo(self._h, ptr(rows[0]), ptr(rows[1])))

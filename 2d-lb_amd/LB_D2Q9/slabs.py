@@ -22,6 +22,7 @@ import numpy as np
 from . import _native
 
 SOUTH, NORTH = 0, 1
+MASK_HALO_ROWS = _native.LB_MASK_HALO_ROWS
 
 
 def partition_rows(ny, nparts):
@@ -62,20 +63,21 @@ class _SlabSet(object):
 
     @staticmethod
     def _mask_halo_rows(mask, y0, h, ny, periodic):
-        """The two mask rows below / above the slab [y0, y0+h), each (2, nx) (None at a wall; rows that
-        fall outside a non-periodic box are empty)."""
+        """The MASK_HALO_ROWS mask rows below / above the slab [y0, y0+h), each (rows, nx) (None at a wall;
+        rows that fall outside a non-periodic box are empty)."""
         m = np.asarray(mask) != 0
+        d = MASK_HALO_ROWS
 
         def rows(ys):
-            out = np.zeros((2, m.shape[0]), bool)
+            out = np.zeros((d, m.shape[0]), bool)
             for i, y in enumerate(ys):
                 if periodic:
                     out[i] = m[:, y % ny]
                 elif 0 <= y < ny:
                     out[i] = m[:, y]
             return out
-        south = rows((y0 - 2, y0 - 1)) if (periodic or y0 > 0) else None
-        north = rows((y0 + h, y0 + h + 1)) if (periodic or y0 + h < ny) else None
+        south = rows(range(y0 - d, y0)) if (periodic or y0 > 0) else None
+        north = rows(range(y0 + h, y0 + h + d)) if (periodic or y0 + h < ny) else None
         return south, north
 
 

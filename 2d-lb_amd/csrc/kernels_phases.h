@@ -263,40 +263,38 @@ __global__ void k1_hydro(const PhaseArgs a)
     a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
 }
 
-// Halo pack / unpack: the 3-deep halo of one edge is 18 row segments scattered over the planes
-// (HaloSeg tables on the host side).  One tiny kernel gathers both edges into two contiguous buffers
-// (so that an exchange is one send + one receive per neighbour instead of eighteen), one scatters the
-// received buffers into the ghost rows.  Table t: 0 north-out, 1 south-out, 2 south-in, 3 north-in;
-// rows of the north tables count from row H.
-__device__ __constant__ int d_halo_k[4][18] = {
-    {2, 5, 6, 0, 1, 3, 2, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 3, 4, 7, 8, 4, 7, 8},
-    {2, 5, 6, 0, 1, 3, 2, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 3, 4, 7, 8, 4, 7, 8}};
-__device__ __constant__ int d_halo_row[4][18] = {
-    {-3, -3, -3, -2, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1},
-    {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2},
-    {-3, -3, -3, -2, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1},
-    {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2}};
+// Halo pack / unpack: the halo of one edge is 18 (3 rows deep) or 45 (6 rows deep) row segments scattered
+// over the planes (HaloTables on the host side).  One tiny kernel gathers both edges into two contiguous
+// buffers (so that an exchange is one send + one receive per neighbour), one scatters the received
+// buffers into the ghost rows.  `neg` lists rows -D..-1 (leaves north, counted from row H / arrives
+// south, counted from row 0), `pos` rows 0..D-1 (leaves south / arrives north).
+struct HaloTable {
+    signed char k[45], row[45];
+    int n;
+};
 
-__global__ void k_halo_pack(const float *origin, long long plane, int pitch, int h, int nx, float *buf_n, float *buf_s)
+__global__ void k_halo_pack(const float *origin, long long plane, int pitch, int h, int nx, float *buf_n, float *buf_s,
+                            const HaloTable neg, const HaloTable pos)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
     if (x >= nx) return;
     float *buf = north ? buf_n : buf_s;
     if (!buf) return;
-    const int t = north ? 0 : 1;
-    const long long row = (north ? h : 0) + d_halo_row[t][seg];
-    buf[(long long)seg * nx + x] = origin[d_halo_k[t][seg] * plane + row * pitch + x];
+    const int k = north ? neg.k[seg] : pos.k[seg];
+    const long long row = north ? h + neg.row[seg] : pos.row[seg];
+    buf[(long long)seg * nx + x] = origin[k * plane + row * pitch + x];
 }
 
-__global__ void k_halo_unpack(float *origin, long long plane, int pitch, int h, int nx, const float *buf_s, const float *buf_n)
+__global__ void k_halo_unpack(float *origin, long long plane, int pitch, int h, int nx, const float *buf_s,
+                              const float *buf_n, const HaloTable neg, const HaloTable pos)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
     if (x >= nx) return;
     const float *buf = north ? buf_n : buf_s;
     if (!buf) return;
-    const int t = north ? 3 : 2;
-    const long long row = (north ? h : 0) + d_halo_row[t][seg];
-    origin[d_halo_k[t][seg] * plane + row * pitch + x] = buf[(long long)seg * nx + x];
+    const int k = north ? pos.k[seg] : neg.k[seg];
+    const long long row = north ? h + pos.row[seg] : neg.row[seg];
+    origin[k * plane + row * pitch + x] = buf[(long long)seg * nx + x];
 }
 
 }  // namespace

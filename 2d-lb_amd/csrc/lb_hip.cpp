@@ -22,6 +22,8 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
 #include <initializer_list>
 #include <stdarg.h>
 #include <stdint.h>
@@ -33,8 +35,9 @@
 
 namespace {
 
-constexpr int GHOST = 3;   // ghost rows below row 0 and above row H-1 of every plane (3-step kernel on slabs)
-constexpr int MASK_GHOST = 2;   // mask rows kept of each neighbouring slab
+constexpr int GHOST = 6;   // ghost rows below row 0 and above row H-1 of every plane: a slab runs two three-step
+                           // launches per halo exchange, the first one recomputing 3 of the neighbour's rows
+constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -5)
 constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (the marching kernels' last
                            // strip reads up to 257 cells past a row's end, every kernel 1 cell before its start)
 
@@ -77,6 +80,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 
@@ -98,6 +102,7 @@ int rccl_load()
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(Send, "ncclSend");
     SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.lib = h;
@@ -130,11 +135,12 @@ struct lb_sim {
     int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
     hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr, edge_stream = nullptr;
-    hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_packed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
-    float *halo_buf = nullptr;  // 4 x 9*nx floats: send north, send south, recv south, recv north
-    bool ghosts_valid = false;  // ghost rows of lat[cur] hold the neighbours' edge rows
+    int min_h = 0;              // smallest slab height over the ranks (every rank must pick the same schedule)
+    float *halo_buf = nullptr;  // 4 x 45*nx floats: send north, send south, recv south, recv north
+    int ghost_depth = 0;        // ghost rows of lat[cur] hold this many of the neighbours' edge rows (0, 3 or 6)
     int variant = -1;           // < 0: automatic (effective_variant)
     hipGraph_t graph = nullptr;            // GRAPH_STEPS single-step launches, captured for small grids
     hipGraphExec_t graph_exec = nullptr;
@@ -222,7 +228,7 @@ int effective_variant(const lb_sim *s)
 {
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
-    const double cells = (double)s->p.nx * s->H;
+    const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
     int v = pair_bytes >= 1.0e9 ? 9 : 16;
     if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32 | 64;
     return v;
@@ -274,17 +280,20 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, dim3 gr
 #undef LB_LAUNCH2
 }
 
-bool step3_applicable(const lb_sim *s)
+// (h: the height the decision is taken on -- a slab's own, or the smallest of the slabs that must agree)
+bool step3_applicable(const lb_sim *s, int h = -1)
 {
-    if (s->p.nx < 512 || s->H < (s->multi_slab() ? 32 : 128)) return false;
+    if (h < 0) h = s->H;
+    if (s->p.nx < 512 || h < (s->multi_slab() ? 32 : 128)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
 }
 
-bool step2_applicable(const lb_sim *s)
+bool step2_applicable(const lb_sim *s, int h = -1)
 {
+    if (h < 0) h = s->H;
     if (s->p.nx < 512) return false;
-    if (s->H < (s->multi_slab() ? 16 : 64)) return false;
+    if (h < (s->multi_slab() ? 16 : 64)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
 }
@@ -424,19 +433,56 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
     return LB_OK;
 }
 
-// Halo of a slab edge: 18 contiguous nx-float row segments ("plane-rows"), three rows deep: what the
-// three-step kernel needs to recompute steps 1 and 2 of the neighbour's edge rows (row -3: the links
-// step 1 of row -2 pulls upward; row -2: those plus its cy=0 links; row -1: everything), and a
-// superset of what the two- and single-step kernels read.  Entry i of the OUT table of one slab pairs
-// with entry i of the IN table of its neighbour.  Rows are relative: north tables count from row H.
+// Halo of a slab edge, D rows deep: contiguous nx-float row segments ("plane-rows") of the D rows next
+// to the edge -- everything a chain of D fused time steps needs to recompute the neighbour's edge rows
+// on the way: of the farthest row only the three links that point toward the receiver, of the next one
+// those plus its cy=0 links, of the others all nine.
+//   D = 3 (18 segments): one three-step launch per exchange; also the format of lb_halo_export/import.
+//   D = 6 (45 segments): two three-step launches per exchange (lb_run's six-step cycle).
+// "neg" tables hold rows -D..-1 (what leaves through a north edge, counted from row H; what a south
+// ghost zone receives, counted from row 0), "pos" tables rows 0..D-1 (leaves south / received north).
+// Entry i of an OUT table of one slab pairs with entry i of the IN table of its neighbour.
 struct HaloSeg { int k, row; };
-constexpr int HALO_SEGS = 18;
-const HaloSeg NORTH_OUT[HALO_SEGS] = {{2, -3}, {5, -3}, {6, -3}, {0, -2}, {1, -2}, {3, -2}, {2, -2}, {5, -2}, {6, -2},
-                                      {0, -1}, {1, -1}, {2, -1}, {3, -1}, {4, -1}, {5, -1}, {6, -1}, {7, -1}, {8, -1}};  // + H
-const HaloSeg *const SOUTH_IN = NORTH_OUT;                                                                        // + 0
-const HaloSeg SOUTH_OUT[HALO_SEGS] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}, {5, 0}, {6, 0}, {7, 0}, {8, 0},
-                                      {0, 1}, {1, 1}, {3, 1}, {4, 1}, {7, 1}, {8, 1}, {4, 2}, {7, 2}, {8, 2}};
-const HaloSeg *const NORTH_IN = SOUTH_OUT;                                                                        // + H
+constexpr int HALO_SEGS = 18;          // D = 3
+constexpr int HALO_SEGS_DEEP = 45;     // D = 6
+
+struct HaloTables {
+    HaloSeg neg[HALO_SEGS_DEEP], pos[HALO_SEGS_DEEP];
+    int n = 0;
+    explicit HaloTables(int depth)
+    {
+        static const int up[3] = {2, 5, 6}, down[3] = {4, 7, 8}, flat[3] = {0, 1, 3};
+        int i = 0;
+        for (int r = -depth; r < 0; ++r) {          // toward the receiver = upward (cy = +1)
+            if (r == -depth) { for (int k : up) neg[i++] = {k, r}; }
+            else if (r == -depth + 1) { for (int k : flat) neg[i++] = {k, r}; for (int k : up) neg[i++] = {k, r}; }
+            else for (int k = 0; k < 9; ++k) neg[i++] = {k, r};
+        }
+        n = i;
+        i = 0;
+        for (int r = 0; r < depth; ++r) {           // toward the receiver = downward (cy = -1)
+            if (r == depth - 1) { for (int k : down) pos[i++] = {k, r}; }
+            else if (r == depth - 2) { for (int k : flat) pos[i++] = {k, r}; for (int k : down) pos[i++] = {k, r}; }
+            else for (int k = 0; k < 9; ++k) pos[i++] = {k, r};
+        }
+    }
+    // the same for the pack / unpack kernels (passed by value)
+    HaloTable device(bool negative) const
+    {
+        HaloTable t;
+        t.n = n;
+        for (int i = 0; i < n; ++i) {
+            t.k[i] = (signed char)(negative ? neg[i].k : pos[i].k);
+            t.row[i] = (signed char)(negative ? neg[i].row : pos[i].row);
+        }
+        return t;
+    }
+};
+const HaloTables HALO3(3), HALO6(6);
+const HaloSeg *const NORTH_OUT = HALO3.neg;   // + H
+const HaloSeg *const SOUTH_IN = HALO3.neg;    // + 0
+const HaloSeg *const SOUTH_OUT = HALO3.pos;   // + 0
+const HaloSeg *const NORTH_IN = HALO3.pos;    // + H
 
 float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
 {
@@ -444,18 +490,37 @@ float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
     return s->origin(which) + h.k * s->plane + row * s->pitch;
 }
 
-int exchange_rccl(lb_sim *s, int which, hipStream_t q)
+// Pack both edges of lattice `which` into the send buffers / scatter the receive buffers into its
+// ghost rows, on stream q.
+int halo_pack(lb_sim *s, int which, hipStream_t q, const HaloTables &T, bool to_north, bool to_south)
+{
+    const size_t n = (size_t)T.n * s->p.nx;
+    const dim3 grid((s->p.nx + 255) / 256, T.n, 2);
+    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->pitch,
+                       s->H, s->p.nx, to_north ? s->halo_buf : nullptr, to_south ? s->halo_buf + n : nullptr,
+                       T.device(true), T.device(false));
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+int halo_unpack(lb_sim *s, int which, hipStream_t q, const HaloTables &T, const float *from_south, const float *from_north)
+{
+    const dim3 grid((s->p.nx + 255) / 256, T.n, 2);
+    hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch, s->H, s->p.nx,
+                       from_south, from_north, T.device(true), T.device(false));
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+int exchange_rccl(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
 {
     // neighbours: south = rank-1, north = rank+1; PERIODIC wraps, walls have none
     const bool wrap = (s->p.bc_mode == LB_BC_PERIODIC);
     const int south = (s->rank > 0) ? s->rank - 1 : (wrap ? s->nranks - 1 : -1);
     const int north = (s->rank < s->nranks - 1) ? s->rank + 1 : (wrap ? 0 : -1);
-    const size_t n = (size_t)HALO_SEGS * s->p.nx;
+    const size_t n = (size_t)T.n * s->p.nx;
     float *send_n = s->halo_buf, *send_s = s->halo_buf + n, *recv_s = s->halo_buf + 2 * n, *recv_n = s->halo_buf + 3 * n;
-    const dim3 grid((s->p.nx + 255) / 256, HALO_SEGS, 2);
-    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch,
-                       s->H, s->p.nx, north >= 0 ? send_n : nullptr, south >= 0 ? send_s : nullptr);
-    HIP_TRY(hipGetLastError());
+    int rc = halo_pack(s, which, q, T, north >= 0, south >= 0);
+    if (rc) return rc;
     // One send and one receive per neighbour.  Posting order matters when both neighbours are the same
     // rank (2 ranks, or 1 rank talking to itself, in a periodic box): sends go north-then-south,
     // receives south-then-north, so the n-th send to a peer meets the n-th receive it posted for us.
@@ -465,10 +530,7 @@ int exchange_rccl(lb_sim *s, int which, hipStream_t q)
     if (south >= 0) NCCL_TRY(g_rccl.Recv(recv_s, n, ncclFloat, south, s->comm, q));
     if (north >= 0) NCCL_TRY(g_rccl.Recv(recv_n, n, ncclFloat, north, s->comm, q));
     NCCL_TRY(g_rccl.GroupEnd());
-    hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch,
-                       s->H, s->p.nx, south >= 0 ? recv_s : nullptr, north >= 0 ? recv_n : nullptr);
-    HIP_TRY(hipGetLastError());
-    return LB_OK;
+    return halo_unpack(s, which, q, T, south >= 0 ? recv_s : nullptr, north >= 0 ? recv_n : nullptr);
 }
 
 // adv (1, 2 or 3) time steps of a slab, edge rows first.  Enqueues on the edge stream (the three
@@ -519,6 +581,55 @@ int slab_step_join(lb_sim *s)
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
     return LB_OK;
+}
+
+// ---- six-step halo cycle of a slab --------------------------------------------------------------
+// Two three-step launches per halo exchange, ghost zone six rows deep (lattice A = cur at the start):
+//   edge stream     E1: A rows [-6,6) and [H-6,H+6)  ->  B rows [-3,3) and [H-3,H+3)   (3 ghost rows recomputed)
+//   compute stream  C1: A rows [0,H)                 ->  B rows [3,H-3)
+//   edge stream     E2: B rows [-3,9) and [H-9,H+3)  ->  A rows [0,6) and [H-6,H)      waits for C1
+//   compute stream  C2: B rows [3,H-3)               ->  A rows [6,H-6)                waits for nothing
+//   edge stream     pack A's six edge rows -> send/recv -> unpack into A's ghost rows
+// and the next C1 waits for E2.  One cross-queue wait per queue and six steps (each costs the waiting
+// queue ~6 us, profiles/r01_slab_timeline.txt), and the exchange has until the middle of the NEXT
+// cycle to arrive instead of the end of the current launch.
+bool cycle_applicable(const lb_sim *s, int h)
+{
+    const int v = effective_variant(s);
+    return (v & 64) && !(v & 128) && step3_applicable(s, h) && h >= 32;
+}
+
+// bands of output rows [lo_s, hi_s) and [lo_n, hi_n): one wave per strip and band
+int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi_n, bool macro)
+{
+    if (hi_s - lo_s == hi_n - lo_n)
+        return launch_step2(s, st, lo_s, hi_n, macro, 2, hi_s - lo_s, lo_n - lo_s, 0, true);
+    int rc = launch_step2(s, st, lo_s, hi_s, macro, 1, hi_s - lo_s, 0, 0, true);
+    if (!rc) rc = launch_step2(s, st, lo_n, hi_n, macro, 1, hi_n - lo_n, 0, 0, true);
+    return rc;
+}
+
+// E1 + C1 (the caller flips cur afterwards)
+int slab_cycle_first(lb_sim *s)
+{
+    const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
+    const StepArgs probe = step_args(s, 0, 1, 1);
+    int rc = launch_bands(s, s->edge_stream, probe.ghost_s ? -3 : 0, 3, H - 3, probe.ghost_n ? H + 3 : H, false);
+    if (rc) return rc;
+    if ((rc = launch_step2(s, s->stream, 3, H - 3, false, 0, 0, 0, 2 * strips, true))) return rc;
+    HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
+    return LB_OK;
+}
+
+// E2 + C2 (the caller flips cur afterwards); ev_boundary = the six edge rows of the new lattice are complete
+int slab_cycle_second(lb_sim *s, bool macro)
+{
+    const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
+    HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
+    int rc = launch_bands(s, s->edge_stream, 0, 6, H - 6, H, macro);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
+    return launch_step2(s, s->stream, 6, H - 6, macro, 0, 0, 0, 2 * strips, true);
 }
 
 // n time steps on a whole-grid handle: largest fused kernel first in the remainder (n = 3a + rem with
@@ -684,6 +795,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, ev_flags));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_halo, ev_flags));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_interior, ev_flags));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_packed, ev_flags));
     CREATE_TRY(hipEventCreate(&s->ev_t0));
     CREATE_TRY(hipEventCreate(&s->ev_t1));
     const size_t lat_bytes = sizeof(float) * s->lat_floats;
@@ -720,7 +832,7 @@ int lb_destroy(lb_sim *s)
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
-    for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_t0, s->ev_t1})
+    for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_t0, s->ev_t1})
         if (e) (void)hipEventDestroy(e);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
@@ -803,7 +915,7 @@ int lb_set_f(lb_sim *s, const float *f)
     HIP_TRY(hipMemcpyAsync(s->lat[s->cur ^ 1], s->lat[s->cur], sizeof(float) * s->lat_floats,
                            hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    s->ghosts_valid = false;
+    s->ghost_depth = 0;
     return LB_OK;
 }
 
@@ -998,7 +1110,7 @@ int lb_init_pop(lb_sim *s)
     for (int i = 0; i < 2; ++i)
         HIP_TRY(hipMemcpyAsync(s->lat[i], s->feq, sizeof(float) * s->lat_floats, hipMemcpyDeviceToDevice,
                                s->stream));
-    s->ghosts_valid = false;
+    s->ghost_depth = 0;
     return LB_OK;
 }
 
@@ -1032,7 +1144,7 @@ int lb_step_finish(lb_sim *s)
     s->cur ^= 1;
     s->stepping = 0;
     s->feq_valid = false;
-    s->ghosts_valid = false;   // the caller imports the new ghosts (lb_run manages its own)
+    s->ghost_depth = 0;   // the caller imports the new ghosts (lb_run manages its own)
     return LB_OK;
 }
 
@@ -1114,19 +1226,35 @@ int lb_run(lb_sim *s, int n_steps)
     // when long satisfied (profiles/r01_slab_timeline.txt), hence as few as the data flow allows.
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
-    if (!s->ghosts_valid) {
-        // ghost rows of the current lattice: exchange once before the first step
-        if ((rc = exchange_rccl(s, s->cur, s->edge_stream))) return rc;
+    int left = n_steps;
+    const int hmin = s->min_h > 0 ? s->min_h : s->H;     // all ranks decide on the same height
+    if (cycle_applicable(s, hmin) && left >= 6) {
+        // six-step cycles (see slab_cycle_first); whatever is left over runs launch by launch below
+        if (s->ghost_depth < 6 && (rc = exchange_rccl(s, s->cur, s->edge_stream, HALO6))) return rc;
+        for (; left >= 6; left -= 6) {
+            if ((rc = slab_cycle_first(s))) return rc;
+            s->cur ^= 1;
+            if ((rc = slab_cycle_second(s, left == 6))) return rc;
+            s->cur ^= 1;
+            if ((rc = exchange_rccl(s, s->cur, s->edge_stream, HALO6))) return rc;
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+        }
+        s->ghost_depth = 6;
     }
-    const bool two = (effective_variant(s) & 32) && step2_applicable(s);
-    const bool three = (effective_variant(s) & 64) && step3_applicable(s);
-    for (int left = n_steps; left > 0;) {
+    if (left > 0 && s->ghost_depth < 3) {
+        // ghost rows of the current lattice: exchange once before the first step
+        if ((rc = exchange_rccl(s, s->cur, s->edge_stream, HALO3))) return rc;
+    }
+    const bool two = (effective_variant(s) & 32) && step2_applicable(s, hmin);
+    const bool three = (effective_variant(s) & 64) && step3_applicable(s, hmin);
+    const bool stepped = left > 0;
+    while (left > 0) {
         const int adv = next_advance(three, two, left);
         // 1. edge rows (edge stream) and interior rows (compute stream) of the new lattice, concurrently
         if ((rc = slab_step_launch(s, adv, left == adv))) return rc;
         // 2. halo of the lattice just written, behind the edge kernel on its stream (RCCL over xGMI),
         //    while the interior is still being computed
-        if ((rc = exchange_rccl(s, s->cur ^ 1, s->edge_stream))) return rc;
+        if ((rc = exchange_rccl(s, s->cur ^ 1, s->edge_stream, HALO3))) return rc;
         // 3. the next launches read the new lattice
         HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
         HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
@@ -1136,7 +1264,7 @@ int lb_run(lb_sim *s, int n_steps)
     // the caller's stream sees the whole state, ghost rows included
     HIP_TRY(hipEventRecord(s->ev_halo, s->edge_stream));
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
-    s->ghosts_valid = true;
+    if (stepped) s->ghost_depth = 3;
     s->feq_valid = false;
     return LB_OK;
 }
@@ -1187,17 +1315,80 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         HIP_TRY(hipEventRecord(sims[i]->ev_interior, sims[i]->stream));
         HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_interior, 0));
     }
+    int hmin = sims[0]->H;
+    for (int i = 1; i < count; ++i) hmin = std::min(hmin, sims[i]->H);
+    bool two = true, three = true, cycle = true;
+    for (int i = 0; i < count; ++i) {
+        two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i], hmin);
+        three = three && (effective_variant(sims[i]) & 64) && step3_applicable(sims[i], hmin);
+        cycle = cycle && cycle_applicable(sims[i], hmin);
+    }
+    int left = n_steps;
+    if (cycle && left >= 6) {
+        // The six-step cycle of lb_run with the transport replaced: every member packs its edges on its
+        // edge stream, the receivers unpack straight from the senders' buffers.
+        for (int i = 0; i < count; ++i)
+            if (!sims[i]->halo_buf) {
+                HIP_TRY(hipMalloc(&sims[i]->halo_buf, sizeof(float) * 4 * HALO_SEGS_DEEP * sims[i]->p.nx));
+                sims[i]->bytes += sizeof(float) * 4 * HALO_SEGS_DEEP * sims[i]->p.nx;
+            }
+        const size_t n = (size_t)HALO6.n * sims[0]->p.nx;
+        auto south_of = [&](int i) { return i > 0 ? i - 1 : (wrap ? count - 1 : -1); };
+        auto north_of = [&](int i) { return i < count - 1 ? i + 1 : (wrap ? 0 : -1); };
+        auto exchange_deep = [&]() -> int {
+            for (int i = 0; i < count; ++i) {
+                lb_sim *me = sims[i];
+                // my send buffers are free again once both neighbours have unpacked the previous halo
+                for (int nb : {south_of(i), north_of(i)})
+                    if (nb >= 0) HIP_TRY(hipStreamWaitEvent(me->edge_stream, sims[nb]->ev_halo, 0));
+                if ((rc = halo_pack(me, me->cur, me->edge_stream, HALO6, north_of(i) >= 0, south_of(i) >= 0))) return rc;
+                HIP_TRY(hipEventRecord(me->ev_packed, me->edge_stream));
+            }
+            for (int i = 0; i < count; ++i) {
+                lb_sim *me = sims[i];
+                const int so = south_of(i), no = north_of(i);
+                for (int nb : {so, no})
+                    if (nb >= 0) HIP_TRY(hipStreamWaitEvent(me->edge_stream, sims[nb]->ev_packed, 0));
+                // my south ghost rows <- what the southern neighbour sent north, and vice versa
+                if ((rc = halo_unpack(me, me->cur, me->edge_stream, HALO6, so >= 0 ? sims[so]->halo_buf : nullptr,
+                                      no >= 0 ? sims[no]->halo_buf + n : nullptr)))
+                    return rc;
+                HIP_TRY(hipEventRecord(me->ev_halo, me->edge_stream));
+            }
+            return LB_OK;
+        };
+        if ((rc = exchange_deep())) return rc;
+        for (; left >= 6; left -= 6) {
+            for (int i = 0; i < count; ++i) {
+                if ((rc = slab_cycle_first(sims[i]))) return rc;
+                sims[i]->cur ^= 1;
+            }
+            for (int i = 0; i < count; ++i) {
+                if ((rc = slab_cycle_second(sims[i], left == 6))) return rc;
+                sims[i]->cur ^= 1;
+            }
+            if ((rc = exchange_deep())) return rc;
+            for (int i = 0; i < count; ++i) HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_boundary, 0));
+        }
+        // (verification path: a plain join before whatever follows)
+        for (int i = 0; i < count; ++i) {
+            HIP_TRY(hipStreamSynchronize(sims[i]->edge_stream));
+            HIP_TRY(hipStreamSynchronize(sims[i]->stream));
+            sims[i]->ghost_depth = 6;
+            sims[i]->feq_valid = false;
+        }
+        if (left == 0) return LB_OK;
+        for (int i = 0; i < count; ++i) {
+            HIP_TRY(hipEventRecord(sims[i]->ev_interior, sims[i]->stream));
+            HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_interior, 0));
+        }
+    }
     if ((rc = exchange(0, false))) return rc;
     for (int i = 0; i < count; ++i) {
         HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_halo, 0));
         HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_halo, 0));
     }
-    bool two = true, three = true;
-    for (int i = 0; i < count; ++i) {
-        two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i]);
-        three = three && (effective_variant(sims[i]) & 64) && step3_applicable(sims[i]);
-    }
-    for (int left = n_steps; left > 0;) {
+    while (left > 0) {
         const int adv = next_advance(three, two, left);
         for (int i = 0; i < count; ++i)
             if ((rc = slab_step_launch(sims[i], adv, left == adv))) return rc;
@@ -1218,7 +1409,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         left -= adv;
     }
     for (int i = 0; i < count; ++i) {
-        sims[i]->ghosts_valid = true;
+        sims[i]->ghost_depth = 3;
         sims[i]->feq_valid = false;
     }
     return LB_OK;
@@ -1246,13 +1437,22 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
     ncclUniqueId id;
     memcpy(&id, unique_id_128, sizeof(id));
     if (!s->halo_buf) {
-        HIP_TRY(hipMalloc(&s->halo_buf, sizeof(float) * 4 * HALO_SEGS * s->p.nx));
-        s->bytes += sizeof(float) * 4 * HALO_SEGS * s->p.nx;
+        HIP_TRY(hipMalloc(&s->halo_buf, sizeof(float) * 4 * HALO_SEGS_DEEP * s->p.nx));
+        s->bytes += sizeof(float) * 4 * HALO_SEGS_DEEP * s->p.nx;
     }
     NCCL_TRY(g_rccl.CommInitRank(&s->comm, nranks, id, rank));
     s->rank = rank;
     s->nranks = nranks;
-    s->ghosts_valid = false;
+    // Which fused kernels a slab can run depends on its height; neighbours must exchange in the same
+    // rhythm, so the ranks agree on the smallest height once, here.
+    {
+        int *d = reinterpret_cast<int *>(s->halo_buf);
+        HIP_TRY(hipMemcpyAsync(d, &s->H, sizeof(int), hipMemcpyHostToDevice, s->edge_stream));
+        NCCL_TRY(g_rccl.AllReduce(d, d + 1, 1, ncclInt32, ncclMin, s->comm, s->edge_stream));
+        HIP_TRY(hipMemcpyAsync(&s->min_h, d + 1, sizeof(int), hipMemcpyDeviceToHost, s->edge_stream));
+        HIP_TRY(hipStreamSynchronize(s->edge_stream));
+    }
+    s->ghost_depth = 0;
     return LB_OK;
 }
 
@@ -1262,8 +1462,9 @@ int lb_steps_per_launch(lb_sim *s)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     const int v = effective_variant(s);
     int n = 1;
-    if ((v & 64) && step3_applicable(s)) n = 3;
-    else if ((v & 32) && step2_applicable(s)) n = 2;
+    const int h = s->min_h > 0 ? s->min_h : s->H;
+    if ((v & 64) && step3_applicable(s, h)) n = 3;
+    else if ((v & 32) && step2_applicable(s, h)) n = 2;
     if (s->variant < 0 && s->tuned_steps && !s->multi_slab() && s->tuned_steps < n) n = s->tuned_steps;
     return n;
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 1
+#define LB_ABI_VERSION 2
 
 typedef enum {
     LB_OK = 0,
@@ -85,6 +85,10 @@ typedef struct {
  * is then filled by lb_halo_import / the RCCL exchange (a 1-rank periodic ring sends to
  * itself).  Lets the multi-GPU code path run, and be tested, on a single GPU. */
 #define LB_FLAG_HALO 1
+
+/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the six-step halo cycle
+ * recomputes three of the neighbour's rows and reads the mask two rows beyond them. */
+#define LB_MASK_HALO_ROWS 5
 
 typedef struct lb_sim lb_sim; /* opaque: device buffers, streams, events, RCCL communicator */
 
@@ -152,9 +156,10 @@ int lb_step_finish(lb_sim *s);
 int lb_halo_floats(lb_sim *s);
 int lb_halo_export(lb_sim *s, int side, void *buf);
 int lb_halo_import(lb_sim *s, int side, const void *buf);
-/* Obstacle-mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-2, y0-1,
- * north_rows = rows y0+H, y0+H+1 (each [2][nx] int32, NULL = no solid cells).  The multi-step kernels
- * recompute the neighbours' edge rows and need their masks. */
+/* Obstacle-mask rows of the neighbouring slabs next to this one: south_rows = global rows
+ * y0-LB_MASK_HALO_ROWS .. y0-1 (nearest last), north_rows = rows y0+H .. y0+H+LB_MASK_HALO_ROWS-1 (nearest
+ * first), each [LB_MASK_HALO_ROWS][nx] int32, NULL = no solid cells.  The multi-step kernels recompute
+ * the neighbours' edge rows and need their masks. */
 int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_rows);
 /* Advance `count` slab handles that tile one grid on ONE device in lock step, moving halos with
  * device-to-device copies: the multi-GPU schedule and kernels without a second GPU (verification). */
@@ -190,7 +195,8 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
 /* Kernel variant selector for tuning experiments: -1 = automatic (default); otherwise bit 0
  * non-temporal stores, bit 1 non-temporal loads, bits 2-3 rows per workgroup (0: 4, 1: 1, 2: 2),
  * bit 4 XCD-aware tile order, bit 5 two time steps per pass where applicable (nx >= 512), bit 6 three
- * time steps per pass (whole-grid handles).  Results never depend on it (bitwise). */
+ * time steps per pass, bit 7 slabs exchange their halo after every launch instead of every two (no
+ * six-step cycle).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);
 
 #ifdef __cplusplus

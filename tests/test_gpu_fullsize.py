@@ -89,12 +89,12 @@ def test_config4_shear_layer_8192_properties(lbhip):
 
 
 def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
-    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, two-step kernel, 2-deep halo)
+    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, three-step kernel, 6-deep halo)
     executed as in-library virtual slabs on one device: bitwise equal to the undivided run."""
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing, partition_rows
     import bench
-    n, steps = 8192, 7
+    n, steps = 8192, 14                           # 2 six-step halo cycles + 2 steps
     one = Simulation(n, n, 1.7, bc="periodic")
     one.init_equilibrium(*bench.shear_layer(n, n, 0, n))
     one.run(steps)

@@ -222,8 +222,9 @@ def test_virtual_slabs_equal_single_slab_bitwise(lbhip, bc, nslabs):
 @pytest.mark.parametrize("nslabs", [2, 3])
 def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs):
     """lb_run_group = the multi-GPU schedule (edge bands on a priority stream, interior on the compute
-    stream, 2-deep halo copies on the communication stream, k_step2 on slabs) with device-to-device
-    copies instead of RCCL.  Must equal the undivided run bit for bit, for odd and even step counts."""
+    stream, six-step halo cycles with the 6-deep halo, launch-by-launch exchange of the 3-deep halo for
+    the remainder) with device-to-device copies instead of RCCL.  Must equal the undivided run bit for
+    bit, for step counts that are and are not multiples of six, three and two."""
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing
     nx, ny = 1000, 137
@@ -237,21 +238,24 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
     one = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, **kw)
     one.set_variant(0)
     one.set_f(f0)
-    for variant in (97, 33, 1):                   # three-step / two-step / single-step kernels on slabs
+    # six-step cycles / three-step launches without the cycle / two-step / single-step kernels on slabs
+    for variant in (97, 97 | 128, 33, 1):
         ring = LocalSlabRing(nx, ny, 1.55, nslabs, bc=bc, obstacle_mask=mask, **kw)
         ring.set_variant(variant)
         ring.set_f(f0)
-        ring.run_in_library(7)
+        ring.run_in_library(20)                   # 3 cycles + 2 steps
+        ring.run_in_library(7)                    # 1 cycle + 1 step
         ring.run_in_library(4)
         if variant == 97:
-            one.run(11)
+            one.run(31)
         a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
         for k in a:
             assert np.array_equal(a[k], b[k]), (variant, k)
 
 
-def test_rccl_self_ring_two_step_with_mask(lbhip):
-    """1-rank periodic ring over RCCL with the two-step slab kernel and an obstacle mask."""
+def test_rccl_self_ring_cycles_with_mask(lbhip):
+    """1-rank periodic ring over RCCL inside lb_run, obstacle mask, every transition between the six-step
+    cycle and the launch-by-launch schedule."""
     from LB_D2Q9.simulation import Simulation, comm_unique_id
     nx, ny = 1024, 160
     rng = np.random.default_rng(23)
@@ -260,16 +264,21 @@ def test_rccl_self_ring_two_step_with_mask(lbhip):
     one = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask)
     one.set_variant(0)
     one.set_f(f0)
-    one.run(9)
-    two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
-    two.set_variant(97)
-    two.comm_init(comm_unique_id(), 0, 1)
-    two.set_f(f0)
-    two.run(5)
-    two.run(4)
-    a, b = one.get_fields(("f", "rho", "u", "v")), two.get_fields(("f", "rho", "u", "v"))
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
+    one.run(41)
+    for variant in (97, 97 | 128):                # with and without the six-step halo cycle
+        two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
+        two.set_variant(variant)
+        two.comm_init(comm_unique_id(), 0, 1)
+        two.set_f(f0)
+        two.run(5)                                # launch by launch: 3 + 2
+        two.run(14)                               # 2 cycles + 2 steps (3-deep ghosts -> deep exchange first)
+        two.run(6)                                # 1 cycle
+        two.run(12)                               # 2 cycles on valid 6-deep ghosts
+        two.run(4)
+        a, b = one.get_fields(("f", "rho", "u", "v")), two.get_fields(("f", "rho", "u", "v"))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (variant, k)
+        two.close()
 
 
 def test_rccl_self_exchange_single_rank(lbhip):
