@@ -168,7 +168,11 @@ int lb_run_group(lb_sim **sims, int count, int n_steps);
 /* RCCL point-to-point halo exchange over xGMI, one rank per GPU.  Rank r owns
  * slab r; neighbours are r-1 (south) and r+1 (north), wrapping for PERIODIC.
  * unique_id is the 128-byte ncclUniqueId: rank 0 obtains it with
- * lb_comm_unique_id and the caller broadcasts it (torch.distributed). */
+ * lb_comm_unique_id and the caller broadcasts it (torch.distributed).
+ * lb_comm_init is collective (every rank of the communicator calls it: the ranks agree on the smallest
+ * slab height there, which decides the kernels and the exchange rhythm).  Afterwards lb_run on a slab
+ * handle exchanges halos itself: six-rows-deep ghost zones, two three-step launches per exchange on
+ * slabs of >= 32 rows and nx >= 512, otherwise one exchange of the 3-deep halo per launch. */
 int lb_comm_unique_id(void *unique_id_128);
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
 
