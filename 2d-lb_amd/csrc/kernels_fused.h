@@ -76,12 +76,25 @@ template <int BC, bool MASK>
 __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
                                             f4a &u4, f4a &v4)
 {
-    const bool edge = (BC != LB_BC_PERIODIC) &&
-                      (yg == 0 || yg == a.ny - 1 || x4 == 0 || (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4));
+    // The boundary rule runs for the cells ON the boundary only: all four in the wall rows y = 0, ny-1
+    // (wave-uniform), otherwise the one cell of the one lane that holds x = 0 or x = nx-1.  (Running it
+    // for all four cells of those lanes made the two wall-column strips the stragglers of every launch:
+    // -11 % at 8192^2, profiles/r01_ablation.txt.)
+    bool wall_row = false, first = false, last = false;
+    int jl = 0;
+    if (BC != LB_BC_PERIODIC) {
+        wall_row = (yg == 0 || yg == a.ny - 1);
+        first = (x4 == 0);
+        last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
+        jl = (a.nx - 1) & 3;
+#ifdef LB_DIAG
+        if (a.diag & 512) wall_row = first = last = false;    // timing only: no boundary rule
+#endif
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-        if (edge) {
+        if (BC != LB_BC_PERIODIC && (wall_row || (first && j == 0) || (last && j == jl))) {
             if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
             if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
         }
@@ -213,8 +226,10 @@ __device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, in
 // Step 1 of the single cell (hx, row rr): the strip's halo cell, executed by one edge lane.  Same
 // arithmetic as collide_row, so the value equals what the neighbouring strip computes for that cell.
 template <int BC, bool MASK>
-__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c)
+__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c,
+                                                bool &solid)
 {
+    solid = false;
     int xc = hx, xl = hx - 1, xg = hx + 1;
     if (BC == LB_BC_PERIODIC) {
         xc = hx < 0 ? hx + a.nx : (hx >= a.nx ? hx - a.nx : hx);
@@ -241,7 +256,10 @@ __device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int r
         if (BC == LB_BC_PIPE) bc_pipe_cell(c, xc, yg, a.nx, a.ny, a.rho_in, a.rho_out);
         if (BC == LB_BC_CAVITY) bc_cavity_cell(c, xc, yg, a.nx, a.ny, a.lid_u, a.rho0);
     }
-    if (MASK) bounce_cell(c, a.mask[r0 + xc] != 0);
+    if (MASK) {
+        solid = a.mask[r0 + xc] != 0;
+        bounce_cell(c, solid);
+    }
     float rho, ux, uy;
     relax_cell(c, a.omega, rho, ux, uy);
 }
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
     // the same window for the halo cell; lane 0 keeps the links entering from the left (1,5,8),
     // lane 63 those entering from the right (3,6,7)
     float hd = 0.f, he = 0.f, hg = 0.f;                 // cy=0 link of row r-1; cy=+1 link of rows r-1, r-2
+    uc4 mk_prev = {0, 0, 0, 0};                         // obstacle mask of row r-1: loaded once, with that row's populations
     for (int r = ya - 1; r <= yb; ++r) {
         // ---- step 1 of row r ---------------------------------------------------------------------
         // (an explicit software prefetch of row r+1 was tried: +36 VGPR, -2 %; removing all
@@ -288,7 +307,8 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
             gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q, mk);
             if (edge_lane) {
                 Cell hc;
-                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, hc);
+                bool hsolid;
+                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, hc, hsolid);
                 hq0 = lane == 0 ? hc.f1 : hc.f3;
                 hq1 = lane == 0 ? hc.f5 : hc.f6;
                 hq2 = lane == 0 ? hc.f8 : hc.f7;
@@ -315,12 +335,10 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
             t[7] = from_right(q[7], hq2, lane);
             t[8] = from_left(q[8], hq2, lane);
             const long long o = (long long)y * a.pitch + x4;
-            uc4 mk2 = {0, 0, 0, 0};
-            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + o);
 #ifdef LB_DIAG
             if (!(a.diag & 2))
 #endif
-            collide_row<BC, MASK>(a, x4, a.y0 + y, t, mk2, r4, u4, v4);
+            collide_row<BC, MASK>(a, x4, a.y0 + y, t, mk_prev, r4, u4, v4);
 #ifdef LB_DIAG
             if (a.diag & 4) {              // no stores: keep the values alive instead
 #pragma unroll
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
         e2 = q[2]; e5 = q[5]; e6 = q[6];
         d0 = q[0]; d1 = q[1]; d3 = q[3];
         hg = he; he = hq1; hd = hq0;
+        mk_prev = mk;
     }
 }
 
@@ -438,6 +457,11 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
 
     Window w1 = {}, w2 = {};                            // step-1 / step-2 results of my 4 cells
     HaloWindow hi1 = {}, ho1 = {}, hi2 = {};            // step 1 of the inner / outer halo cell, step 2 of the inner one
+    // obstacle mask of rows r-1 and r-2 (and of the inner halo cell in row r-1): loaded once, together with
+    // that row's populations, and handed down like the windows -- a load at the point of use stalls the wave
+    // for a memory round trip in steps 2 and 3 of every row (-18 % with a mask at 8192^2)
+    uc4 mk_p1 = {0, 0, 0, 0}, mk_p2 = {0, 0, 0, 0};
+    bool hsolid_p1 = false;
     for (int r = ya - 2; r <= yb + 1; ++r) {
         // ---- step 1 of row r (from memory) --------------------------------------------------------
         f4a q1[9], r4, u4, v4;
@@ -445,13 +469,15 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
         int rr, ym, yp;
         const bool have = step1_rows(a, r, rr, ym, yp);
         HaloLinks hi_new = {}, ho_new = {};
+        bool hsolid = false;
         if (have) {
             gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);   // (non-temporal loads: no gain, measured)
             if (edge_lane) {
                 Cell c;
-                halo_cell_step1<BC, MASK>(a, hxi, rr, ym, yp, c);
+                bool osolid;
+                halo_cell_step1<BC, MASK>(a, hxi, rr, ym, yp, c, hsolid);
                 hi_new = halo_links(c, left);
-                halo_cell_step1<BC, MASK>(a, hxo, rr, ym, yp, c);
+                halo_cell_step1<BC, MASK>(a, hxo, rr, ym, yp, c, osolid);
                 ho_new = halo_links(c, left);
             }
 #ifdef LB_DIAG
@@ -489,18 +515,16 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
                         if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
                         if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
                     }
-                    if (MASK) bounce_cell(c, a.mask[(long long)r2 * a.pitch + hxi_c] != 0);
+                    if (MASK) bounce_cell(c, hsolid_p1);
                     float rho, ux, uy;
                     relax_cell(c, a.omega, rho, ux, uy);
                 }
                 h2_new = halo_links(c, left);
             }
-            uc4 mk2 = {0, 0, 0, 0};
-            if (MASK) mk2 = *reinterpret_cast<const uc4 *>(a.mask + (long long)r2 * a.pitch + x4);
 #ifdef LB_DIAG
             if (!(a.diag & 2))
 #endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk2, r4, u4, v4);
+            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk_p1, r4, u4, v4);
         } else {
 #pragma unroll
             for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
@@ -512,12 +536,10 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
             f4a t[9];
             window_gather(w2, q2, hi2, h2_new, lane, t);
             const long long o = (long long)r3 * a.pitch + x4;
-            uc4 mk3 = {0, 0, 0, 0};
-            if (MASK) mk3 = *reinterpret_cast<const uc4 *>(a.mask + o);
 #ifdef LB_DIAG
             if (!(a.diag & 4))
 #endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk3, r4, u4, v4);
+            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk_p2, r4, u4, v4);
             if (store_lane) {
                 float *d = a.dst + o;
 #pragma unroll
@@ -535,6 +557,8 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
         halo_push(hi1, hi_new);
         halo_push(ho1, ho_new);
         halo_push(hi2, h2_new);
+        mk_p2 = mk_p1; mk_p1 = mk;
+        hsolid_p1 = hsolid;
     }
 }
 
