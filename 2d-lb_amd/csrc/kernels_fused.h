@@ -2,6 +2,7 @@
 // time steps per launch: wave-private strips marching in y with register windows) and the float4
 // copy used for calibration.  Included by lb_hip.cpp only.
 #pragma once
+#include <type_traits>
 #include "d2q9_cell.h"
 
 namespace {
@@ -26,32 +27,44 @@ struct StepArgs {
 // Pull-stream gather for 4 consecutive cells (x4..x4+3) of local row yl: q[k] = f_k at (x - cx_k,
 // y - cy_k) of the source lattice.  ym / yp are the source rows of the cy=+1 / cy=-1 links (already
 // wrapped by the caller where the box is periodic in y within this slab).
+// Element x (per lane, >= 0) of a row whose start is the same in all lanes: written as uniform pointer +
+// 32-bit byte offset so that the access takes the scalar-base form (global_load v, v_off, s[base:base+1])
+// instead of a 64-bit address computed per lane -- one offset register serves all nine planes.
+template <typename T>
+__device__ __forceinline__ T *lane_ptr(T *row, int x)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    return reinterpret_cast<T *>(reinterpret_cast<B *>(row) + (unsigned)x * (unsigned)sizeof(T));
+}
+
 template <int BC, bool MASK, bool NTL>
 __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk)
 {
     const long long P = a.pitch, S = a.plane;
-    const long long o0 = (long long)yl * P + x4, om = (long long)ym * P + x4, op = (long long)yp * P + x4;
     const float *s = a.src;
+    const float *r0 = s + (long long)yl * P, *rm = s + (long long)ym * P, *rp = s + (long long)yp * P;   // uniform
 #ifdef LB_DIAG
     if (a.diag & 8) {                      // timing only: all nine planes read aligned (wrong results)
-        q[0] = load4<NTL>(s + o0);          q[1] = load4<NTL>(s + 1 * S + o0);  q[2] = load4<NTL>(s + 2 * S + om);
-        q[3] = load4<NTL>(s + 3 * S + o0);  q[4] = load4<NTL>(s + 4 * S + op);  q[5] = load4<NTL>(s + 5 * S + om);
-        q[6] = load4<NTL>(s + 6 * S + om);  q[7] = load4<NTL>(s + 7 * S + op);  q[8] = load4<NTL>(s + 8 * S + op);
+        q[0] = load4<NTL>(lane_ptr(r0, x4));          q[1] = load4<NTL>(lane_ptr(r0 + 1 * S, x4));
+        q[2] = load4<NTL>(lane_ptr(rm + 2 * S, x4));  q[3] = load4<NTL>(lane_ptr(r0 + 3 * S, x4));
+        q[4] = load4<NTL>(lane_ptr(rp + 4 * S, x4));  q[5] = load4<NTL>(lane_ptr(rm + 5 * S, x4));
+        q[6] = load4<NTL>(lane_ptr(rm + 6 * S, x4));  q[7] = load4<NTL>(lane_ptr(rp + 7 * S, x4));
+        q[8] = load4<NTL>(lane_ptr(rp + 8 * S, x4));
         mk = uc4{0, 0, 0, 0};
         return;
     }
 #endif
-    q[0] = load4<NTL>(s + o0);
-    q[1] = load4u<NTL>(s + 1 * S + o0 - 1);
-    q[2] = load4<NTL>(s + 2 * S + om);
-    q[3] = load4u<NTL>(s + 3 * S + o0 + 1);
-    q[4] = load4<NTL>(s + 4 * S + op);
-    q[5] = load4u<NTL>(s + 5 * S + om - 1);
-    q[6] = load4u<NTL>(s + 6 * S + om + 1);
-    q[7] = load4u<NTL>(s + 7 * S + op + 1);
-    q[8] = load4u<NTL>(s + 8 * S + op - 1);
+    q[0] = load4<NTL>(lane_ptr(r0, x4));
+    q[1] = load4u<NTL>(lane_ptr(r0 + 1 * S - 1, x4));
+    q[2] = load4<NTL>(lane_ptr(rm + 2 * S, x4));
+    q[3] = load4u<NTL>(lane_ptr(r0 + 3 * S + 1, x4));
+    q[4] = load4<NTL>(lane_ptr(rp + 4 * S, x4));
+    q[5] = load4u<NTL>(lane_ptr(rm + 5 * S - 1, x4));
+    q[6] = load4u<NTL>(lane_ptr(rm + 6 * S + 1, x4));
+    q[7] = load4u<NTL>(lane_ptr(rp + 7 * S + 1, x4));
+    q[8] = load4u<NTL>(lane_ptr(rp + 8 * S - 1, x4));
     mk = uc4{0, 0, 0, 0};
-    if (MASK) mk = *reinterpret_cast<const uc4 *>(a.mask + o0);
+    if (MASK) mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)yl * P, x4));
     if (BC == LB_BC_PERIODIC) {
         // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
         // row padding (wave-divergent, one lane per row).
@@ -76,28 +89,38 @@ template <int BC, bool MASK>
 __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
                                             f4a &u4, f4a &v4)
 {
-    // The boundary rule runs for the cells ON the boundary only: all four in the wall rows y = 0, ny-1
-    // (wave-uniform), otherwise the one cell of the one lane that holds x = 0 or x = nx-1.  (Running it
-    // for all four cells of those lanes made the two wall-column strips the stragglers of every launch:
-    // -11 % at 8192^2, profiles/r01_ablation.txt.)
-    bool wall_row = false, first = false, last = false;
-    int jl = 0;
+    // Phase 1, branchy and rare: the boundary rule, for the cells ON the boundary only -- all four in the
+    // wall rows y = 0, ny-1 (wave-uniform), otherwise the one cell of the one lane that holds x = 0 or
+    // x = nx-1.  (Running it for all four cells of those lanes made the two wall-column strips the
+    // stragglers of every launch: -11 % at 8192^2, profiles/r01_ablation.txt.)
     if (BC != LB_BC_PERIODIC) {
-        wall_row = (yg == 0 || yg == a.ny - 1);
-        first = (x4 == 0);
-        last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
-        jl = (a.nx - 1) & 3;
+        bool wall_row = (yg == 0 || yg == a.ny - 1);
+        bool first = (x4 == 0);
+        bool last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
+        const int jl = (a.nx - 1) & 3;
 #ifdef LB_DIAG
         if (a.diag & 512) wall_row = first = last = false;    // timing only: no boundary rule
 #endif
+        if (wall_row || first || last) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (wall_row || (first && j == 0) || (last && j == jl)) {
+                    Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+                    if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
+                    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
+                    q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
+                    q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+                }
+            }
+        }
     }
+    // Phase 2, straight-line: obstacle swap (selects), moments, equilibrium, relaxation of the four cells.
+    // Kept free of control flow so that the compiler pairs the cells into packed fp32 instructions
+    // (v_pk_fma/mul/add_f32: 523 packed ops in the periodic kernel against 105 when the boundary branches
+    // sat inside this loop -- the wall families ran 7 % slower for that alone).
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-        if (BC != LB_BC_PERIODIC && (wall_row || (first && j == 0) || (last && j == jl))) {
-            if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
-        }
         if (MASK) bounce_cell(c, mk[j] != 0);
         float rho, ux, uy;
         relax_cell(c, a.omega, rho, ux, uy);
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
         }
     }
     const int x4 = (bx * blockDim.x + threadIdx.x) * 4;
-    const int ri = by * blockDim.y + threadIdx.y;
+    const int ri = by * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);   // uniform: blockDim.x % 64 == 0
     if (x4 >= a.pitch || ri >= a.row_count) return;
     const int yl = a.row_begin + ri * a.row_step;
     const int yg = a.y0 + yl;
@@ -142,7 +165,7 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
         if (ym < 0) ym = a.h - 1;
         if (yp >= a.h) yp = 0;
     }
-    const long long o0 = (long long)yl * a.pitch + x4;
+    const long long o0 = (long long)yl * a.pitch;       // row start, uniform
     f4a q[9], r4, u4, v4;
     uc4 mk;
     gather_row<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk);
@@ -154,11 +177,11 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
     const long long S = a.plane;
     float *d = a.dst + o0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, q[k]);
+    for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), q[k]);
     if (MACRO) {
-        store4<false>(a.rho + o0, r4);
-        store4<false>(a.u + o0, u4);
-        store4<false>(a.v + o0, v4);
+        store4<false>(lane_ptr(a.rho + o0, x4), r4);
+        store4<false>(lane_ptr(a.u + o0, x4), u4);
+        store4<false>(lane_ptr(a.v + o0, x4), v4);
     }
 }
 
@@ -241,23 +264,23 @@ __device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int r
     }
     const long long P = a.pitch, S = a.plane;
     const float *s = a.src;
-    const long long r0 = (long long)rr * P, rm = (long long)ym * P, rp = (long long)yp * P;
-    c.f0 = s[r0 + xc];
-    c.f1 = s[1 * S + r0 + xl];
-    c.f2 = s[2 * S + rm + xc];
-    c.f3 = s[3 * S + r0 + xg];
-    c.f4 = s[4 * S + rp + xc];
-    c.f5 = s[5 * S + rm + xl];
-    c.f6 = s[6 * S + rm + xg];
-    c.f7 = s[7 * S + rp + xg];
-    c.f8 = s[8 * S + rp + xl];
+    const float *r0 = s + (long long)rr * P, *rm = s + (long long)ym * P, *rp = s + (long long)yp * P;   // uniform
+    c.f0 = *lane_ptr(r0, xc);
+    c.f1 = *lane_ptr(r0 + 1 * S, xl);
+    c.f2 = *lane_ptr(rm + 2 * S, xc);
+    c.f3 = *lane_ptr(r0 + 3 * S, xg);
+    c.f4 = *lane_ptr(rp + 4 * S, xc);
+    c.f5 = *lane_ptr(rm + 5 * S, xl);
+    c.f6 = *lane_ptr(rm + 6 * S, xg);
+    c.f7 = *lane_ptr(rp + 7 * S, xg);
+    c.f8 = *lane_ptr(rp + 8 * S, xl);
     const int yg = a.y0 + rr;
     if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
         if (BC == LB_BC_PIPE) bc_pipe_cell(c, xc, yg, a.nx, a.ny, a.rho_in, a.rho_out);
         if (BC == LB_BC_CAVITY) bc_cavity_cell(c, xc, yg, a.nx, a.ny, a.lid_u, a.rho0);
     }
     if (MASK) {
-        solid = a.mask[r0 + xc] != 0;
+        solid = *lane_ptr(a.mask + (long long)rr * P, xc) != 0;
         bounce_cell(c, solid);
     }
     float rho, ux, uy;
@@ -268,10 +291,12 @@ __device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int r
 // one contiguous range cut into equal shares (seg_stride == seg_rows), or the two 2-row edge bands
 // of a slab (seg_stride = H-2) that are computed first so their halo can travel early.
 template <int BC, bool MASK, bool MACRO, bool NTS>
-__global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+__global__ __launch_bounds__(256, 2) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
-    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
+    // (threadIdx.y is the same in all 64 lanes of a wave, but the compiler does not know: without the
+    //  readfirstlane the segment, the row loop and every row address would live in vector registers)
+    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int sx = item % strips, sy = item / strips;
     if (sy >= nsegs) return;
     const int ya = a.row_begin + sy * a.seg_stride;
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
             t[4] = q[4];
             t[7] = from_right(q[7], hq2, lane);
             t[8] = from_left(q[8], hq2, lane);
-            const long long o = (long long)y * a.pitch + x4;
+            const long long o = (long long)y * a.pitch;         // row start, uniform
 #ifdef LB_DIAG
             if (!(a.diag & 2))
 #endif
@@ -348,11 +373,11 @@ __global__ __launch_bounds__(256) void k_step2(const StepArgs a, int strips, int
             if (store_lane) {
                 float *d = a.dst + o;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
+                for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
                 if (MACRO) {
-                    store4<false>(a.rho + o, r4);
-                    store4<false>(a.u + o, u4);
-                    store4<false>(a.v + o, v4);
+                    store4<false>(lane_ptr(a.rho + o, x4), r4);
+                    store4<false>(lane_ptr(a.u + o, x4), u4);
+                    store4<false>(lane_ptr(a.v + o, x4), v4);
                 }
             }
         }
@@ -431,11 +456,25 @@ __device__ __forceinline__ void window_gather(const Window &w, const f4a (&q)[9]
     t[8] = from_left(q[8], hnew.tm, lane);
 }
 
+// obstacle-mask history of the three-step kernel (see mhist there)
+__device__ __forceinline__ unsigned mask_word(uc4 m)
+{
+    return (m.x ? 1u : 0u) | (m.y ? 0x100u : 0u) | (m.z ? 0x10000u : 0u) | (m.w ? 0x1000000u : 0u);
+}
+__device__ __forceinline__ uc4 mask_bits(unsigned hist, int age)
+{
+    const unsigned b = (hist >> age) & 0x01010101u;
+    return uc4{(unsigned char)(b & 0xff), (unsigned char)((b >> 8) & 0xff), (unsigned char)((b >> 16) & 0xff),
+               (unsigned char)(b >> 24)};
+}
+
 template <int BC, bool MASK, bool MACRO, bool NTS>
-__global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+__global__ __launch_bounds__(256, 2) void k_step3(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     const int lane = threadIdx.x;                       // blockDim = (64, 4): four independent waves
-    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.y;
+    // (threadIdx.y is the same in all 64 lanes of a wave, but the compiler does not know: without the
+    //  readfirstlane the segment, the row loop and every row address would live in vector registers)
+    const int item = xcd_item(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int sx = item % strips, sy = item / strips;
     if (sy >= nsegs) return;
     const int ya = a.row_begin + sy * a.seg_stride;
@@ -460,8 +499,9 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
     // obstacle mask of rows r-1 and r-2 (and of the inner halo cell in row r-1): loaded once, together with
     // that row's populations, and handed down like the windows -- a load at the point of use stalls the wave
     // for a memory round trip in steps 2 and 3 of every row (-18 % with a mask at 8192^2)
-    uc4 mk_p1 = {0, 0, 0, 0}, mk_p2 = {0, 0, 0, 0};
-    bool hsolid_p1 = false;
+    // (one register: in every byte bit 1 = my cell in row r-1, bit 2 = in row r-2; bit 6 of byte 0 = the inner
+    //  halo cell in row r-1 -- the wall + obstacle instantiations sit at the 256-register limit)
+    unsigned mhist = 0;
     for (int r = ya - 2; r <= yb + 1; ++r) {
         // ---- step 1 of row r (from memory) --------------------------------------------------------
         f4a q1[9], r4, u4, v4;
@@ -515,7 +555,7 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
                         if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
                         if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
                     }
-                    if (MASK) bounce_cell(c, hsolid_p1);
+                    if (MASK) bounce_cell(c, (mhist & 0x40u) != 0);
                     float rho, ux, uy;
                     relax_cell(c, a.omega, rho, ux, uy);
                 }
@@ -524,7 +564,7 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
 #ifdef LB_DIAG
             if (!(a.diag & 2))
 #endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mk_p1, r4, u4, v4);
+            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(mhist, 1), r4, u4, v4);
         } else {
 #pragma unroll
             for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
@@ -535,19 +575,19 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
             (void)step1_rows(a, r - 2, r3, r3m, r3p);
             f4a t[9];
             window_gather(w2, q2, hi2, h2_new, lane, t);
-            const long long o = (long long)r3 * a.pitch + x4;
+            const long long o = (long long)r3 * a.pitch;        // row start, uniform
 #ifdef LB_DIAG
             if (!(a.diag & 4))
 #endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mk_p2, r4, u4, v4);
+            collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mask_bits(mhist, 2), r4, u4, v4);
             if (store_lane) {
                 float *d = a.dst + o;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(d + k * S, t[k]);
+                for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
                 if (MACRO) {
-                    store4<false>(a.rho + o, r4);
-                    store4<false>(a.u + o, u4);
-                    store4<false>(a.v + o, v4);
+                    store4<false>(lane_ptr(a.rho + o, x4), r4);
+                    store4<false>(lane_ptr(a.u + o, x4), u4);
+                    store4<false>(lane_ptr(a.v + o, x4), v4);
                 }
             }
         }
@@ -557,8 +597,7 @@ __global__ __launch_bounds__(256) void k_step3(const StepArgs a, int strips, int
         halo_push(hi1, hi_new);
         halo_push(ho1, ho_new);
         halo_push(hi2, h2_new);
-        mk_p2 = mk_p1; mk_p1 = mk;
-        hsolid_p1 = hsolid;
+        if (MASK) mhist = ((mhist | mask_word(mk) | (hsolid ? 0x20u : 0u)) << 1) & 0x06060646u;
     }
 }
 
