@@ -21,9 +21,9 @@ struct Cell {
 
 // D2Q9.cl:173-261 (move_bcs) for one cell, float arithmetic (the reference's double literals
 // are not mimicked: SURVEY.md Appendix D.1 measured that difference at <= 1e-6 over 5000 steps).
-__device__ __forceinline__ void bc_pipe_cell(Cell &c, int x, int y, int nx, int ny, float rin, float rout)
+// (w, e, s, n: the cell lies in column 0 / nx-1, row 0 / ny-1)
+__device__ __forceinline__ void bc_pipe_cell(Cell &c, bool w, bool e, bool s, bool n, float rin, float rout)
 {
-    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
     const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
     if (w && !s && !n) {                                   // inlet :198-203
         const float uu = -((f0 + f2 + 2.f * f3 + f4 + 2.f * f6 + 2.f * f7 - rin) / rin);
@@ -68,9 +68,8 @@ __device__ __forceinline__ void bc_pipe_cell(Cell &c, int x, int y, int nx, int 
 }
 
 // Build-defined lid-driven cavity closure, oracle/d2q9_oracle.c o2_bc_cavity.
-__device__ __forceinline__ void bc_cavity_cell(Cell &c, int x, int y, int nx, int ny, float lid, float rho0)
+__device__ __forceinline__ void bc_cavity_cell(Cell &c, bool w, bool e, bool s, bool n, float lid, float rho0)
 {
-    const bool w = (x == 0), e = (x == nx - 1), s = (y == 0), n = (y == ny - 1);
     const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
     if (n && !w && !e) {
         const float rw = f0 + f1 + f3 + 2.f * (f2 + f5 + f6);

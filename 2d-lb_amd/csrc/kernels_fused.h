@@ -94,7 +94,8 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     // x = nx-1.  (Running it for all four cells of those lanes made the two wall-column strips the
     // stragglers of every launch: -11 % at 8192^2, profiles/r01_ablation.txt.)
     if (BC != LB_BC_PERIODIC) {
-        bool wall_row = (yg == 0 || yg == a.ny - 1);
+        const bool south = (yg == 0), north = (yg == a.ny - 1);
+        bool wall_row = south || north;
         bool first = (x4 == 0);
         bool last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
         const int jl = (a.nx - 1) & 3;
@@ -106,8 +107,9 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
             for (int j = 0; j < 4; ++j) {
                 if (wall_row || (first && j == 0) || (last && j == jl)) {
                     Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-                    if (BC == LB_BC_PIPE) bc_pipe_cell(c, x4 + j, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-                    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, x4 + j, yg, a.nx, a.ny, a.lid_u, a.rho0);
+                    const bool w = first && j == 0, e = last && j == jl;
+                    if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, south, north, a.rho_in, a.rho_out);
+                    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, south, north, a.lid_u, a.rho0);
                     q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
                     q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
                 }
@@ -276,8 +278,9 @@ __device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int r
     c.f8 = *lane_ptr(rp + 8 * S, xl);
     const int yg = a.y0 + rr;
     if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
-        if (BC == LB_BC_PIPE) bc_pipe_cell(c, xc, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, xc, yg, a.nx, a.ny, a.lid_u, a.rho0);
+        const bool w = (xc == 0), e = (xc == a.nx - 1), so = (yg == 0), no = (yg == a.ny - 1);
+        if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
+        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
     }
     if (MASK) {
         solid = *lane_ptr(a.mask + (long long)rr * P, xc) != 0;
@@ -552,8 +555,9 @@ __global__ __launch_bounds__(256, 2) void k_step3(const StepArgs a, int strips, 
                 if (hxi_in) {
                     const int yg = a.y0 + r2;
                     if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
-                        if (BC == LB_BC_PIPE) bc_pipe_cell(c, hxi_c, yg, a.nx, a.ny, a.rho_in, a.rho_out);
-                        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, hxi_c, yg, a.nx, a.ny, a.lid_u, a.rho0);
+                        const bool w = (hxi_c == 0), e = (hxi_c == a.nx - 1), so = (yg == 0), no = (yg == a.ny - 1);
+                        if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
+                        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
                     }
                     if (MASK) bounce_cell(c, (mhist & 0x40u) != 0);
                     float rho, ux, uy;

@@ -44,8 +44,9 @@ __global__ void k_bcs(const PhaseArgs a)
     float *f = a.f + o;
     Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
     if (x == 0 || x == a.nx - 1 || y == 0 || y == a.ny - 1) {
-        if (a.bc == LB_BC_PIPE) bc_pipe_cell(c, x, y, a.nx, a.ny, a.rho_in, a.rho_out);
-        if (a.bc == LB_BC_CAVITY) bc_cavity_cell(c, x, y, a.nx, a.ny, a.lid_u, a.rho0);
+        const bool w = (x == 0), e = (x == a.nx - 1), so = (y == 0), no = (y == a.ny - 1);
+        if (a.bc == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
+        if (a.bc == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
     }
     bounce_cell(c, a.mask && a.mask[o]);
     f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
