@@ -15,7 +15,7 @@
 // H..H+2 are ghost rows (slab halo, three deep for the three-step kernel / don't-care at walls), so
 // element (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+3)*pitch + x .
 // Source layout (one translation unit): d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2,
-// k_step3), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
+// k_step3), kernels_step4.h (k_step4), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
 // 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
 #include <hip/hip_runtime.h>
@@ -64,6 +64,7 @@ int fail(int code, const char *fmt, ...)
 
 #include "d2q9_cell.h"
 #include "kernels_fused.h"
+#include "kernels_step4.h"
 #include "kernels_phases.h"
 
 namespace {
@@ -148,7 +149,7 @@ struct lb_sim {
     hipStream_t graph_stream = nullptr;
     bool graph_failed = false;
     int diag = 0;
-    int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1, 2, 3) chosen by lb_autotune
+    int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1..4) chosen by lb_autotune
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
     int64_t bytes = 0;
 
@@ -257,13 +258,17 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 
 // Two fused time steps in one pass (k_step2).
 template <int BC>
-void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, dim3 grid, int strips, int seg_rows,
-                     int nsegs, int row_end, bool macro, bool nts, bool three)
+void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows,
+                     int nsegs, int row_end, bool macro, bool nts, int depth)
 {
-    const dim3 block(64, 4);
+    const int waves = (depth == 4) ? STEP4_WAVES : 4;      // wave-items per workgroup
+    const dim3 block(64, waves), grid((items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
-        if (three)                                                                                               \
+        if (depth == 4)                                                                                          \
+            hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
+                               row_end);                                                                         \
+        else if (depth == 3)                                                                                     \
             hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
                                row_end);                                                                         \
         else                                                                                                     \
@@ -289,6 +294,14 @@ bool step3_applicable(const lb_sim *s, int h = -1)
     return true;
 }
 
+// four steps per pass: whole-grid handles only (a slab would need a 4-deep halo per launch)
+bool step4_applicable(const lb_sim *s)
+{
+    if (s->multi_slab() || s->p.nx < 512 || s->H < 128) return false;
+    if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
+    return true;
+}
+
 bool step2_applicable(const lb_sim *s, int h = -1)
 {
     if (h < 0) h = s->H;
@@ -302,7 +315,7 @@ bool step2_applicable(const lb_sim *s, int h = -1)
 // apart (edge bands), or -- nsegs_fixed == 0 -- cut into equal shares so that the launch is one
 // balanced round of resident waves (reserve = wave slots left to a concurrent edge launch).
 int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool macro, int nsegs_fixed = 0,
-                 int seg_rows_fixed = 0, int seg_stride = 0, int reserve = 0, bool three = false)
+                 int seg_rows_fixed = 0, int seg_stride = 0, int reserve = 0, int depth = 2)
 {
     if (row_end <= row_begin) return LB_OK;
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
@@ -328,12 +341,11 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         a.seg_stride = seg_rows;
     }
     const int items = strips * segs;
-    const dim3 grid((items + 3) / 4);
     const bool nts = (variant & 1) != 0;
     switch (s->p.bc_mode) {
-    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
-    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
-    default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, grid, strips, seg_rows, segs, row_end, macro, nts, three); break;
+    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
+    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
+    default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -545,9 +557,9 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
         const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
         const bool three = (adv == 3);
         // edge bands: output rows [0,3) and [H-3,H), one wave per strip and band
-        if ((rc = launch_step2(s, s->edge_stream, 0, H, macro, 2, 3, H - 3, 0, three))) return rc;
+        if ((rc = launch_step2(s, s->edge_stream, 0, H, macro, 2, 3, H - 3, 0, three ? 3 : 2))) return rc;
         HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-        if ((rc = launch_step2(s, s->stream, 3, H - 3, macro, 0, 0, 0, 2 * strips, three))) return rc;
+        if ((rc = launch_step2(s, s->stream, 3, H - 3, macro, 0, 0, 0, 2 * strips, three ? 3 : 2))) return rc;
     } else {
         // single step: the six rows the 3-deep halo is cut from (0..2, H-3..H-1) first, then the rest
         const hipStream_t keep = s->stream;
@@ -564,14 +576,20 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
     return LB_OK;
 }
 
-// How many time steps the next launch of a run with `left` steps to go advances: the largest fused
-// kernel first in the remainder (left = 3a + rem with the three-step kernel, 2a + rem with the two-step).
-int next_advance(bool three, bool two, int left)
+// How many time steps the next launch of a run with `left` steps to go advances.  `allowed`: bit d set =
+// the d-step kernel may be used (bit 1 always is).  The deepest kernel D carries the bulk, the remainder
+// left % D goes first, to the deepest kernel that fits it (left = 4a + rem, rem -> 3, 2 or 1 ...).
+int next_advance(int allowed, int left)
 {
-    if (three && left % 3 == 0) return 3;
-    if (two && left >= 2 && (three ? left % 3 == 2 : left % 2 == 0)) return 2;
+    int D = 1;
+    for (int d = 2; d <= 4; ++d)
+        if (allowed & (1 << d)) D = d;
+    const int rem = left % D;
+    for (int d = std::min(rem == 0 ? D : rem, left); d > 1; --d)
+        if (allowed & (1 << d)) return d;
     return 1;
 }
+int depth_mask(bool two, bool three, bool four = false) { return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0); }
 
 // Both compute streams wait for the other one's kernel and for the halo of the lattice just written.
 int slab_step_join(lb_sim *s)
@@ -603,9 +621,9 @@ bool cycle_applicable(const lb_sim *s, int h)
 int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi_n, bool macro)
 {
     if (hi_s - lo_s == hi_n - lo_n)
-        return launch_step2(s, st, lo_s, hi_n, macro, 2, hi_s - lo_s, lo_n - lo_s, 0, true);
-    int rc = launch_step2(s, st, lo_s, hi_s, macro, 1, hi_s - lo_s, 0, 0, true);
-    if (!rc) rc = launch_step2(s, st, lo_n, hi_n, macro, 1, hi_n - lo_n, 0, 0, true);
+        return launch_step2(s, st, lo_s, hi_n, macro, 2, hi_s - lo_s, lo_n - lo_s, 0, 3);
+    int rc = launch_step2(s, st, lo_s, hi_s, macro, 1, hi_s - lo_s, 0, 0, 3);
+    if (!rc) rc = launch_step2(s, st, lo_n, hi_n, macro, 1, hi_n - lo_n, 0, 0, 3);
     return rc;
 }
 
@@ -616,7 +634,7 @@ int slab_cycle_first(lb_sim *s)
     const StepArgs probe = step_args(s, 0, 1, 1);
     int rc = launch_bands(s, s->edge_stream, probe.ghost_s ? -3 : 0, 3, H - 3, probe.ghost_n ? H + 3 : H, false);
     if (rc) return rc;
-    if ((rc = launch_step2(s, s->stream, 3, H - 3, false, 0, 0, 0, 2 * strips, true))) return rc;
+    if ((rc = launch_step2(s, s->stream, 3, H - 3, false, 0, 0, 0, 2 * strips, 3))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
@@ -629,7 +647,7 @@ int slab_cycle_second(lb_sim *s, bool macro)
     int rc = launch_bands(s, s->edge_stream, 0, 6, H - 6, H, macro);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-    return launch_step2(s, s->stream, 6, H - 6, macro, 0, 0, 0, 2 * strips, true);
+    return launch_step2(s, s->stream, 6, H - 6, macro, 0, 0, 0, 2 * strips, 3);
 }
 
 // n time steps on a whole-grid handle: largest fused kernel first in the remainder (n = 3a + rem with
@@ -638,16 +656,18 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 {
     int rc;
     const int v = effective_variant(s);
+    bool four = (v & 256) && step4_applicable(s);
     bool three = (v & 64) && step3_applicable(s);
     bool two = (v & 32) && step2_applicable(s);
     if (s->variant < 0 && s->tuned_steps) {            // lb_autotune's choice overrides the size heuristic
-        three = three && s->tuned_steps == 3;
+        four = four && s->tuned_steps >= 4;
+        three = three && s->tuned_steps >= 3;
         two = two && s->tuned_steps >= 2;
     }
     int left = n_steps;
     // Small grids are launch-bound (a 256^2 step is ~3 us of GPU work against ~5 us of host launch
     // cost): replay GRAPH_STEPS single-step launches captured once into a hipGraph.
-    if (!three && !two && left > GRAPH_STEPS && small_grid(s)) {
+    if (!four && !three && !two && left > GRAPH_STEPS && small_grid(s)) {
         if ((rc = ensure_graph(s))) return rc;
         while (s->graph_exec && left > GRAPH_STEPS) {          // keep >= 1 step for the MACRO launch
             HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
@@ -655,10 +675,9 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
         }
     }
     while (left > 0) {
-        const int adv = next_advance(three, two, left);
+        const int adv = next_advance(depth_mask(two, three, four), left);
         const bool macro = final_macro && (left == adv);
-        if (adv == 3) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, true);
-        else if (adv == 2) rc = launch_step2(s, s->stream, 0, s->H, macro);
+        if (adv >= 2) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, adv);
         else rc = launch_step(s, 0, 1, s->H, macro);
         if (rc) return rc;
         s->cur ^= 1;
@@ -669,21 +688,22 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 }
 
 // Time the candidate configurations of the fused kernels on LIVE steps (every configuration produces
-// bitwise identical results, so tuning advances the simulation like any other steps): three- and
+// bitwise identical results, so tuning advances the simulation like any other steps): four-, three- and
 // two-step marching kernels at 8 and 4 waves per CU, and the single-step kernel.  Which one wins depends
 // on the grid's aspect ratio, the mask and the boundary family (wide, short pipes favour fewer, longer
 // segments: +20 % at 3751 x 1251).  Returns the number of steps advanced, or a negative status.
 int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
-    const Cand cands[] = {{3, 8}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};
-    const int per = 6;                                 // steps per timed sample: 2 x 3 = 3 x 2 = 6 x 1
+    const Cand cands[] = {{4, 8}, {4, 4}, {3, 8}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};
+    const int per = 12;                                // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1
     int used = 0, best = -1;
     float best_ms = 0.f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (size_t c = 0; c < sizeof(cands) / sizeof(cands[0]); ++c) {
+        if (cands[c].steps == 4 && !((effective_variant(s) & 256) && step4_applicable(s))) continue;
         if (cands[c].steps == 3 && !step3_applicable(s)) continue;
         if (cands[c].steps == 2 && !step2_applicable(s)) continue;
         s->tuned_steps = cands[c].steps;
@@ -1206,8 +1226,8 @@ int lb_run(lb_sim *s, int n_steps)
     if (!s->multi_slab()) {
         // Long first run with the automatic variant: time the candidate kernel configurations on the
         // first steps of this very run (they are bitwise equivalent) and keep the fastest.
-        if (s->variant < 0 && !s->tuned_steps && n_steps >= 120 && (step2_applicable(s) || step3_applicable(s))) {
-            const int used = autotune_whole_grid(s, 2);   // <= 5 candidates x 3 samples x 6 steps + 1 = 91 steps
+        if (s->variant < 0 && !s->tuned_steps && n_steps >= 200 && (step2_applicable(s) || step3_applicable(s))) {
+            const int used = autotune_whole_grid(s, 1);   // <= 7 candidates x 2 samples x 12 steps + 1 = 169 steps
             if (used < 0) return used;
             n_steps -= used;
         }
@@ -1249,7 +1269,7 @@ int lb_run(lb_sim *s, int n_steps)
     const bool three = (effective_variant(s) & 64) && step3_applicable(s, hmin);
     const bool stepped = left > 0;
     while (left > 0) {
-        const int adv = next_advance(three, two, left);
+        const int adv = next_advance(depth_mask(two, three), left);
         // 1. edge rows (edge stream) and interior rows (compute stream) of the new lattice, concurrently
         if ((rc = slab_step_launch(s, adv, left == adv))) return rc;
         // 2. halo of the lattice just written, behind the edge kernel on its stream (RCCL over xGMI),
@@ -1389,7 +1409,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_halo, 0));
     }
     while (left > 0) {
-        const int adv = next_advance(three, two, left);
+        const int adv = next_advance(depth_mask(two, three), left);
         for (int i = 0; i < count; ++i)
             if ((rc = slab_step_launch(sims[i], adv, left == adv))) return rc;
         if ((rc = exchange(1, true))) return rc;
@@ -1463,7 +1483,8 @@ int lb_steps_per_launch(lb_sim *s)
     const int v = effective_variant(s);
     int n = 1;
     const int h = s->min_h > 0 ? s->min_h : s->H;
-    if ((v & 64) && step3_applicable(s, h)) n = 3;
+    if ((v & 256) && step4_applicable(s)) n = 4;
+    else if ((v & 64) && step3_applicable(s, h)) n = 3;
     else if ((v & 32) && step2_applicable(s, h)) n = 2;
     if (s->variant < 0 && s->tuned_steps && !s->multi_slab() && s->tuned_steps < n) n = s->tuned_steps;
     return n;

@@ -175,17 +175,20 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
         mask[:, 0] = mask[:, -1] = False
     kw = dict(inlet_rho=1.004, lid_u=0.06)
     sims = []
-    for variant in (0, 32, 33, 97):   # single step / two-step / + NT stores / three-step (+ two-step remainder)
+    # single step / two-step / + NT stores / three-step (+ two-step remainder) / four-step (+ remainders)
+    for variant in (0, 32, 33, 97, 97 | 256):
         s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
+        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4}[variant]
         s.set_f(f0)
-        s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step)
-        s.run(4)                      # 4 = 2+2 = 1+3
+        s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step)
+        s.run(4)                      # 4 = 2+2 = 1+3 = 4
         sims.append(s.get_fields(("f", "rho", "u", "v")))
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(sims[0][k], sims[1][k]), k          # -ffp-contract=on: same rounding in every kernel
         assert np.array_equal(sims[1][k], sims[2][k]), k          # NT stores never change results
         assert np.array_equal(sims[0][k], sims[3][k]), k          # three steps per pass: still bitwise
+        assert np.array_equal(sims[0][k], sims[4][k]), k          # four steps per pass (LDS windows): still bitwise
     code = {"pipe": oracle.BC_PIPE, "periodic": oracle.BC_PERIODIC, "cavity": oracle.BC_CAVITY}[bc]
     o = oracle.O2Sim(nx, ny, 1.6, code, 1.004, 1., 0.06, 1., mask=mask)
     o.set_f(f0)
