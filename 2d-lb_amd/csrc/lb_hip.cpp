@@ -232,6 +232,9 @@ int effective_variant(const lb_sim *s)
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
     int v = pair_bytes >= 1.0e9 ? 9 : 16;
     if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32 | 64;
+    // four steps per pass where they pay without asking the autotuner: whole periodic boxes without obstacles
+    // from 4096^2 up (+14..18 %); walls and obstacles are a draw or a loss (profiles/r01_sweep_variants.txt)
+    if (cells >= 4096.0 * 4096.0 && !s->multi_slab() && s->p.bc_mode == LB_BC_PERIODIC && !s->has_mask) v |= 256;
     return v;
 }
 
@@ -650,24 +653,27 @@ int slab_cycle_second(lb_sim *s, bool macro)
     return launch_step2(s, s->stream, 6, H - 6, macro, 0, 0, 0, 2 * strips, 3);
 }
 
+// Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
+// once lb_autotune has timed this grid -- everything applicable up to the depth it found fastest.
+int whole_grid_depths(const lb_sim *s)
+{
+    if (s->variant < 0 && s->tuned_steps)
+        return depth_mask(step2_applicable(s) && s->tuned_steps >= 2, step3_applicable(s) && s->tuned_steps >= 3,
+                          step4_applicable(s) && s->tuned_steps >= 4);
+    const int v = effective_variant(s);
+    return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s));
+}
+
 // n time steps on a whole-grid handle: largest fused kernel first in the remainder (n = 3a + rem with
 // the three-step kernel, 2a + rem with the two-step kernel), hipGraph replay for small grids.
 int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 {
     int rc;
-    const int v = effective_variant(s);
-    bool four = (v & 256) && step4_applicable(s);
-    bool three = (v & 64) && step3_applicable(s);
-    bool two = (v & 32) && step2_applicable(s);
-    if (s->variant < 0 && s->tuned_steps) {            // lb_autotune's choice overrides the size heuristic
-        four = four && s->tuned_steps >= 4;
-        three = three && s->tuned_steps >= 3;
-        two = two && s->tuned_steps >= 2;
-    }
+    const int depths = whole_grid_depths(s);
     int left = n_steps;
     // Small grids are launch-bound (a 256^2 step is ~3 us of GPU work against ~5 us of host launch
     // cost): replay GRAPH_STEPS single-step launches captured once into a hipGraph.
-    if (!four && !three && !two && left > GRAPH_STEPS && small_grid(s)) {
+    if (depths == depth_mask(false, false) && left > GRAPH_STEPS && small_grid(s)) {
         if ((rc = ensure_graph(s))) return rc;
         while (s->graph_exec && left > GRAPH_STEPS) {          // keep >= 1 step for the MACRO launch
             HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
@@ -675,7 +681,7 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
         }
     }
     while (left > 0) {
-        const int adv = next_advance(depth_mask(two, three, four), left);
+        const int adv = next_advance(depths, left);
         const bool macro = final_macro && (left == adv);
         if (adv >= 2) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, adv);
         else rc = launch_step(s, 0, 1, s->H, macro);
@@ -703,7 +709,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (size_t c = 0; c < sizeof(cands) / sizeof(cands[0]); ++c) {
-        if (cands[c].steps == 4 && !((effective_variant(s) & 256) && step4_applicable(s))) continue;
+        if (cands[c].steps == 4 && !step4_applicable(s)) continue;
         if (cands[c].steps == 3 && !step3_applicable(s)) continue;
         if (cands[c].steps == 2 && !step2_applicable(s)) continue;
         s->tuned_steps = cands[c].steps;
@@ -1480,13 +1486,17 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
 int lb_steps_per_launch(lb_sim *s)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
-    const int v = effective_variant(s);
     int n = 1;
-    const int h = s->min_h > 0 ? s->min_h : s->H;
-    if ((v & 256) && step4_applicable(s)) n = 4;
-    else if ((v & 64) && step3_applicable(s, h)) n = 3;
-    else if ((v & 32) && step2_applicable(s, h)) n = 2;
-    if (s->variant < 0 && s->tuned_steps && !s->multi_slab() && s->tuned_steps < n) n = s->tuned_steps;
+    if (!s->multi_slab()) {
+        const int depths = whole_grid_depths(s);
+        for (int d = 2; d <= 4; ++d)
+            if (depths & (1 << d)) n = d;
+    } else {
+        const int v = effective_variant(s);
+        const int h = s->min_h > 0 ? s->min_h : s->H;
+        if ((v & 64) && step3_applicable(s, h)) n = 3;
+        else if ((v & 32) && step2_applicable(s, h)) n = 2;
+    }
     return n;
 }
 

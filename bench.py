@@ -206,7 +206,8 @@ def main():
         launch_s = ev_ms / 1e3 / args.steps * spl
         bytes_per_launch = B_ALG * n * h * spl
         achieved = bytes_per_launch / launch_s / 1e9
-        kname = {3: "k_step3<PERIODIC> (three fused time steps per pass: step-1 and step-2 results in registers)",
+        kname = {4: "k_step4<PERIODIC> (four fused time steps per pass: stage windows in registers and wave-private LDS)",
+                 3: "k_step3<PERIODIC> (three fused time steps per pass: step-1 and step-2 results in registers)",
                  2: "k_step2<PERIODIC> (two fused time steps per pass: step-1 results in registers)",
                  1: "k_step<PERIODIC> (fused pull-stream+collide)"}[spl]
         line = {

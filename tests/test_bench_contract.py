@@ -49,4 +49,4 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     assert d["roofline"]["frac"] == pytest.approx(d["roofline"]["achieved"] / 8000.0, abs=1e-3)
     assert "workload" in d["config"] and d["vs_baseline"] is None
-    assert d["roofline"]["steps_per_launch"] in (1, 2, 3)
+    assert d["roofline"]["steps_per_launch"] in (1, 2, 3, 4)

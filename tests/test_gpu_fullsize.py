@@ -71,10 +71,10 @@ def test_config4_shear_layer_8192_properties(lbhip):
     1 + 7.5e-9, so the reference arithmetic itself gains ~1e-8 x omega per step: bound 5e-8 per step)."""
     from LB_D2Q9.simulation import Simulation
     import bench
-    n, steps = 8192, 1000                                # 1000 = 1 + 333 x 3: single-step and three-step kernels both run
+    n, steps = 8192, 1003                                # 1003 = 3 + 250 x 4: three-step and four-step kernels both run
     sim = Simulation(n, n, 1.7, bc="periodic")
     sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
-    assert sim.steps_per_launch() == 3
+    assert sim.steps_per_launch() == 4                   # whole periodic box without obstacles: k_step4
     rho0 = sim.get_fields(("rho",))["rho"].astype(np.float64).sum()
     sim.run(steps)
     g = sim.get_fields(("rho", "u", "v"))
