@@ -128,7 +128,9 @@ __device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
 __device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
 {
     rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
-    const float inv = 1.0f / rho;
+    // v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division: the three- and four-step kernels are
+    // bound by vector-ALU issue, and OpenCL's own '/' (D2Q9.cl:95-96) is only specified to 2.5 ulp
+    const float inv = __builtin_amdgcn_rcpf(rho);
     ux = (c.f1 - c.f3 + c.f5 - c.f6 - c.f7 + c.f8) * inv;
     uy = (c.f5 + c.f2 + c.f6 - c.f7 - c.f4 - c.f8) * inv;
     const float usq = ux * ux + uy * uy;

@@ -7,9 +7,9 @@
 // keeps the kernel at two waves per SIMD -- an LDS-resident window costs ~1 % against registers
 // (measured on k_step3, profiles/r01_ablation.txt).  No barriers: a wave only ever reads what it wrote.
 //
-// The cells beyond the strip are recomputed by the edge lanes as scalar cells, as in k_step3, one more
-// ring per stage: step 1 for x0-3..x0-1 | x0+256..x0+258, step 2 for the inner two, step 3 for the
-// innermost.  A halo cell at distance d takes its centre links from itself, the links moving toward the
+// The cells beyond the strip are recomputed as scalar cells, as in k_step3, one more ring per stage: step 1
+// for x0-3..x0-1 | x0+256..x0+258, step 2 for the inner two, step 3 for the innermost -- here by six
+// "halo lanes", one cell each (see k_step4).  A halo cell at distance d takes its centre links from itself, the links moving toward the
 // strip from the cell at d+1, the links moving away from it from the cell at d-1 (d = 1: the strip's own
 // edge cell, out of the vector registers).
 //
@@ -104,6 +104,14 @@ __device__ __forceinline__ void stage_gather(const Window &w, const f4a (&q)[9],
 
 constexpr int STEP4_WAVES = 2;      // waves per workgroup: 2 x 2 windows x 9 KiB = 36 KiB of LDS
 
+// Halo lanes.  The three cells beyond each end of the strip are spread over six lanes -- lanes 0,1,2 own
+// the cells at distance 1,2,3 on the left, lanes 63,62,61 those on the right -- so that one scalar-cell
+// call per stage serves all of them at once (six sequential calls by two lanes made the kernel bound by
+// vector-ALU issue).  A halo cell takes the links moving toward the strip from the lane that owns the
+// cell farther out (`lane_out`) and the links moving away from it from the lane that owns the cell
+// closer in (`lane_in`; for distance 1 that is the strip's own edge cell, in the same lane), through
+// ds_bpermute, which does not occupy the vector ALU.
+
 template <int BC, bool MASK, bool MACRO, bool NTS>
 __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a, int strips, int seg_rows, int nsegs,
                                                                int row_end)
@@ -122,11 +130,12 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     int x4 = xr;
     if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;
     const bool store_lane = xr < a.nx;
-    const bool left = (lane == 0);
-    const bool edge_lane = left || (lane == 63);
-    const int hx1 = left ? x0 - 1 : x0 + STRIP_W;       // halo cells at distance 1, 2, 3 from the strip
-    const int hx2 = left ? x0 - 2 : x0 + STRIP_W + 1;
-    const int hx3 = left ? x0 - 3 : x0 + STRIP_W + 2;
+    const bool left = (lane < 32);
+    const int hd = left ? lane + 1 : 64 - lane;         // distance of my halo cell from the strip (1..3 in halo lanes)
+    const bool halo1 = (hd <= 3), halo2 = (hd <= 2), halo3 = (hd == 1);   // lanes taking part in halo stages 1, 2, 3
+    const int hx = left ? x0 - hd : x0 + STRIP_W - 1 + hd;                 // my halo cell
+    const int lane_out = left ? lane + 1 : lane - 1;    // owner of the cell one farther out
+    const int lane_in = left ? max(lane - 1, 0) : min(lane + 1, 63);      // owner of the cell one closer in
     const long long S = a.plane;
 
     f4a(*W2)[64] = lds_win[wy][0];
@@ -137,13 +146,10 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
         for (int k = 0; k < 9; ++k) { W2[k][lane] = z; W3[k][lane] = z; }
     }
     Window w1 = {};
-    // delay lines of the halo cells: stage 1: cell 1 (centre, toward, away), cell 2 (centre, toward), cell 3
-    // (toward); stage 2: cell 1 (centre, toward), cell 2 (toward); stage 3: cell 1 (toward)
-    Tri s1c1 = {}, s1t1 = {}, s1a1 = {}, s1c2 = {}, s1t2 = {}, s1t3 = {};
-    Tri s2c1 = {}, s2t1 = {}, s2t2 = {};
-    Tri s3t1 = {};
-    // obstacle-mask history: my cells (per byte: bit 1 = row r-1, bit 2 = r-2, bit 3 = r-3); halo cells
-    // (bits 0..2 = cells 1..3 in row r-1, bits 3..5 = in row r-2)
+    // delay lines of MY halo cell: stage 1 (centre, toward, away), stage 2 (centre, toward), stage 3 (toward)
+    Tri s1c = {}, s1t = {}, s1a = {}, s2c = {}, s2t = {}, s3t = {};
+    // obstacle-mask history: my four cells (per byte: bit 1 = row r-1, bit 2 = r-2, bit 3 = r-3); my halo
+    // cell (bit 1 = row r-1, bit 2 = row r-2)
     unsigned mhist = 0, hmask = 0;
     int it = 0;
 
@@ -153,19 +159,14 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
         uc4 mk = {0, 0, 0, 0};
         int rr, ym, yp;
         const bool have = step1_rows(a, r, rr, ym, yp);
-        HaloCell9 n11 = {}, n12 = {}, n13 = {};         // stage-1 links of halo cells 1, 2, 3 in row r
-        unsigned hcur = 0;
+        HaloCell9 n1 = {};                              // stage-1 links of my halo cell in row r
+        bool hsolid = false;
         if (have) {
             gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);
-            if (edge_lane) {
+            if (halo1) {
                 Cell c;
-                bool sol;
-                halo_cell_step1<BC, MASK>(a, hx1, rr, ym, yp, c, sol);
-                n11 = halo_all(c, left); hcur |= sol ? 1u : 0u;
-                halo_cell_step1<BC, MASK>(a, hx2, rr, ym, yp, c, sol);
-                n12 = halo_all(c, left); hcur |= sol ? 2u : 0u;
-                halo_cell_step1<BC, MASK>(a, hx3, rr, ym, yp, c, sol);
-                n13 = halo_all(c, left); hcur |= sol ? 4u : 0u;
+                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, c, hsolid);
+                n1 = halo_all(c, left);
             }
             collide_row<BC, MASK>(a, x4, a.y0 + rr, q1, mk, r4, u4, v4);
         } else {
@@ -174,22 +175,22 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
         }
         // ---- step 2 of row r-1 (window 1, registers) -----------------------------------------------------
         f4a q2[9];
-        HaloCell9 n21 = {}, n22 = {};                   // stage-2 links of halo cells 1, 2 in row r-1
+        HaloCell9 n2 = {};                              // stage-2 links of my halo cell in row r-1
         if (r >= ya - 1) {
             int r2, t0_, t1_;
             (void)step1_rows(a, r - 1, r2, t0_, t1_);
-            stage_gather(w1, q1, s1t1, n11.tm, lane, q2);
-            if (edge_lane) {
-                const int yg = a.y0 + r2;
+            stage_gather(w1, q1, s1t, n1.tm, lane, q2);   // (lanes 0 / 63 own the innermost cells)
+            // toward links of the cell farther out, away links of the cell closer in (all lanes take part)
+            Tri tw = {__shfl(s1t.d, lane_out), 0.f, __shfl(s1t.g, lane_out)};
+            const float tm_new = __shfl(n1.tm, lane_out);
+            float a0 = __shfl(s1a.d, lane_in), ap = __shfl(s1a.g, lane_in), am = __shfl(n1.am, lane_in);
+            if (hd == 1) {                              // closer in = my own edge cell
+                a0 = left ? w1.d3.x : w1.d1.w; ap = left ? w1.g6.x : w1.g5.w; am = left ? q1[7].x : q1[8].w;
+            }
+            if (halo2) {
                 Cell c;
-                // cell 1: away links of the closer cell = my own edge cell
-                halo_cell_next<BC, MASK>(a, hx1, yg, left, (hmask & 1u) != 0, s1c1, n11.cm, s1t2, n12.tm,
-                                         left ? w1.d3.x : w1.d1.w, left ? w1.g6.x : w1.g5.w, left ? q1[7].x : q1[8].w, c);
-                n21 = halo_all(c, left);
-                // cell 2: away links of the closer cell = halo cell 1
-                halo_cell_next<BC, MASK>(a, hx2, yg, left, (hmask & 2u) != 0, s1c2, n12.cm, s1t3, n13.tm,
-                                         s1a1.d, s1a1.g, n11.am, c);
-                n22 = halo_all(c, left);
+                halo_cell_next<BC, MASK>(a, hx, a.y0 + r2, left, (hmask & 2u) != 0, s1c, n1.cm, tw, tm_new, a0, ap, am, c);
+                n2 = halo_all(c, left);
             }
             collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(mhist, 1), r4, u4, v4);
         } else {
@@ -198,18 +199,20 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
         }
         // ---- step 3 of row r-2 (window 2, LDS) -----------------------------------------------------------
         f4a q3[9];
-        HaloCell9 n31 = {};                             // stage-3 links of halo cell 1 in row r-2
+        HaloCell9 n3 = {};                              // stage-3 links of my halo cell in row r-2
         if (r >= ya + 1) {
             int r3, t0_, t1_;
             (void)step1_rows(a, r - 2, r3, t0_, t1_);
             Window w2;
             lds_window_load(W2, lane, it, w2);
-            stage_gather(w2, q2, s2t1, n21.tm, lane, q3);
-            if (edge_lane) {
+            stage_gather(w2, q2, s2t, n2.tm, lane, q3);
+            Tri tw = {__shfl(s2t.d, lane_out), 0.f, __shfl(s2t.g, lane_out)};
+            const float tm_new = __shfl(n2.tm, lane_out);
+            if (halo3) {
                 Cell c;
-                halo_cell_next<BC, MASK>(a, hx1, a.y0 + r3, left, (hmask & 8u) != 0, s2c1, n21.cm, s2t2, n22.tm,
+                halo_cell_next<BC, MASK>(a, hx, a.y0 + r3, left, (hmask & 4u) != 0, s2c, n2.cm, tw, tm_new,
                                          left ? w2.d3.x : w2.d1.w, left ? w2.g6.x : w2.g5.w, left ? q2[7].x : q2[8].w, c);
-                n31 = halo_all(c, left);
+                n3 = halo_all(c, left);
             }
             collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(mhist, 2), r4, u4, v4);
         } else {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
             Window w3;
             lds_window_load(W3, lane, it, w3);
             f4a t[9];
-            stage_gather(w3, q3, s3t1, n31.tm, lane, t);
+            stage_gather(w3, q3, s3t, n3.tm, lane, t);
             collide_row<BC, MASK>(a, x4, a.y0 + r4_, t, mask_bits(mhist, 3), r4, u4, v4);
             if (store_lane) {
                 const long long o = (long long)r4_ * a.pitch;   // row start, uniform
@@ -241,15 +244,12 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
         window_push(w1, q1);
         lds_window_push(W2, lane, it, q2);
         lds_window_push(W3, lane, it, q3);
-        tri_push(s1c1, n11.c0, n11.cp); tri_push(s1t1, n11.t0, n11.tp); tri_push(s1a1, n11.a0, n11.ap);
-        tri_push(s1c2, n12.c0, n12.cp); tri_push(s1t2, n12.t0, n12.tp);
-        tri_push(s1t3, n13.t0, n13.tp);
-        tri_push(s2c1, n21.c0, n21.cp); tri_push(s2t1, n21.t0, n21.tp);
-        tri_push(s2t2, n22.t0, n22.tp);
-        tri_push(s3t1, n31.t0, n31.tp);
+        tri_push(s1c, n1.c0, n1.cp); tri_push(s1t, n1.t0, n1.tp); tri_push(s1a, n1.a0, n1.ap);
+        tri_push(s2c, n2.c0, n2.cp); tri_push(s2t, n2.t0, n2.tp);
+        tri_push(s3t, n3.t0, n3.tp);
         if (MASK) {
             mhist = ((mhist | mask_word(mk)) << 1) & 0x0e0e0e0eu;
-            hmask = ((hmask << 3) | hcur) & 0x3fu;
+            hmask = ((hmask | (hsolid ? 1u : 0u)) << 1) & 0x6u;
         }
     }
 }

@@ -232,9 +232,9 @@ int effective_variant(const lb_sim *s)
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
     int v = pair_bytes >= 1.0e9 ? 9 : 16;
     if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32 | 64;
-    // four steps per pass where they pay without asking the autotuner: whole periodic boxes without obstacles
-    // from 4096^2 up (+14..18 %); walls and obstacles are a draw or a loss (profiles/r01_sweep_variants.txt)
-    if (cells >= 4096.0 * 4096.0 && !s->multi_slab() && s->p.bc_mode == LB_BC_PERIODIC && !s->has_mask) v |= 256;
+    // four steps per pass on whole-grid handles from 4096^2 up (+16..21 % in every boundary family, with and
+    // without obstacles; a loss at 2048^2, where its segments get too short: profiles/r01_sweep_variants.txt)
+    if (cells >= 4096.0 * 4096.0 && !s->multi_slab()) v |= 256;
     return v;
 }
 
