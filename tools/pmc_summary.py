@@ -73,7 +73,7 @@ def main():
         w = st.mean(pmc[(k, "WRITE_SIZE")])
         rd, wr = f * 1024 * fetch_corr, w * 1024 * write_corr
         macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS>
-        spl = 3 if k.startswith("k_step3") else (2 if k.startswith("k_step2") else 1)   # time steps per launch
+        spl = int(k[6]) if k[6:7].isdigit() else 1        # k_step2/3/4: time steps per launch
         alg = 72.0 * side * side * spl + (12.0 * side * side if macro else 0.0)
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
         if not macro:
