@@ -264,13 +264,13 @@ __global__ void k1_hydro(const PhaseArgs a)
     a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
 }
 
-// Halo pack / unpack: the halo of one edge is 18 (3 rows deep) or 45 (6 rows deep) row segments scattered
+// Halo pack / unpack: the halo of one edge is 18 (3 rows deep), 45 (6 deep) or 63 (8 deep) row segments scattered
 // over the planes (HaloTables on the host side).  One tiny kernel gathers both edges into two contiguous
 // buffers (so that an exchange is one send + one receive per neighbour), one scatters the received
 // buffers into the ghost rows.  `neg` lists rows -D..-1 (leaves north, counted from row H / arrives
 // south, counted from row 0), `pos` rows 0..D-1 (leaves south / arrives north).
 struct HaloTable {
-    signed char k[45], row[45];
+    signed char k[63], row[63];
     int n;
 };
 

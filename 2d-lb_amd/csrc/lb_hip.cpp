@@ -35,9 +35,9 @@
 
 namespace {
 
-constexpr int GHOST = 6;   // ghost rows below row 0 and above row H-1 of every plane: a slab runs two three-step
-                           // launches per halo exchange, the first one recomputing 3 of the neighbour's rows
-constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -5)
+constexpr int GHOST = 8;   // ghost rows below row 0 and above row H-1 of every plane: a slab runs two four-step
+                           // launches per halo exchange, the first one recomputing 4 of the neighbour's rows
+constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -7)
 constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (the marching kernels' last
                            // strip reads up to 257 cells past a row's end, every kernel 1 cell before its start)
 
@@ -232,9 +232,10 @@ int effective_variant(const lb_sim *s)
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
     int v = pair_bytes >= 1.0e9 ? 9 : 16;
     if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32 | 64;
-    // four steps per pass on whole-grid handles from 4096^2 up (+16..21 % in every boundary family, with and
-    // without obstacles; a loss at 2048^2, where its segments get too short: profiles/r01_sweep_variants.txt)
-    if (cells >= 4096.0 * 4096.0 && !s->multi_slab()) v |= 256;
+    // four steps per pass from 8192 x 1024 cells up, whole grids and slabs alike (+16..21 % in every boundary
+    // family, with and without obstacles; +2 % at 2048^2, where the segments get short:
+    // profiles/r01_sweep_variants.txt, profiles/r01_slab_proxy_1gpu.txt)
+    if (cells >= 2048.0 * 4096.0) v |= 256;
     return v;
 }
 
@@ -297,7 +298,7 @@ bool step3_applicable(const lb_sim *s, int h = -1)
     return true;
 }
 
-// four steps per pass: whole-grid handles only (a slab would need a 4-deep halo per launch)
+// four steps per pass on a whole-grid handle (slabs use it inside the eight-step halo cycle only: cycle_depth)
 bool step4_applicable(const lb_sim *s)
 {
     if (s->multi_slab() || s->p.nx < 512 || s->H < 128) return false;
@@ -453,13 +454,14 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
 // on the way: of the farthest row only the three links that point toward the receiver, of the next one
 // those plus its cy=0 links, of the others all nine.
 //   D = 3 (18 segments): one three-step launch per exchange; also the format of lb_halo_export/import.
-//   D = 6 (45 segments): two three-step launches per exchange (lb_run's six-step cycle).
+//   D = 6 (45 segments): two three-step launches per exchange (lb_run's six-step cycle);
+//   D = 8 (63 segments): two four-step launches per exchange (eight-step cycle).
 // "neg" tables hold rows -D..-1 (what leaves through a north edge, counted from row H; what a south
 // ghost zone receives, counted from row 0), "pos" tables rows 0..D-1 (leaves south / received north).
 // Entry i of an OUT table of one slab pairs with entry i of the IN table of its neighbour.
 struct HaloSeg { int k, row; };
 constexpr int HALO_SEGS = 18;          // D = 3
-constexpr int HALO_SEGS_DEEP = 45;     // D = 6
+constexpr int HALO_SEGS_DEEP = 63;     // D = 8 (45 for D = 6)
 
 struct HaloTables {
     HaloSeg neg[HALO_SEGS_DEEP], pos[HALO_SEGS_DEEP];
@@ -493,7 +495,7 @@ struct HaloTables {
         return t;
     }
 };
-const HaloTables HALO3(3), HALO6(6);
+const HaloTables HALO3(3), HALO6(6), HALO8(8);
 const HaloSeg *const NORTH_OUT = HALO3.neg;   // + H
 const HaloSeg *const SOUTH_IN = HALO3.neg;    // + 0
 const HaloSeg *const SOUTH_OUT = HALO3.pos;   // + 0
@@ -604,8 +606,9 @@ int slab_step_join(lb_sim *s)
     return LB_OK;
 }
 
-// ---- six-step halo cycle of a slab --------------------------------------------------------------
-// Two three-step launches per halo exchange, ghost zone six rows deep (lattice A = cur at the start):
+// ---- halo cycle of a slab ---------------------------------------------------------------------------
+// Two D-step launches per halo exchange, ghost zone 2D rows deep (D = 3 shown; D = 4 likewise with rows
+// -8..8); lattice A = cur at the start:
 //   edge stream     E1: A rows [-6,6) and [H-6,H+6)  ->  B rows [-3,3) and [H-3,H+3)   (3 ghost rows recomputed)
 //   compute stream  C1: A rows [0,H)                 ->  B rows [3,H-3)
 //   edge stream     E2: B rows [-3,9) and [H-9,H+3)  ->  A rows [0,6) and [H-6,H)      waits for C1
@@ -614,43 +617,47 @@ int slab_step_join(lb_sim *s)
 // and the next C1 waits for E2.  One cross-queue wait per queue and six steps (each costs the waiting
 // queue ~6 us, profiles/r01_slab_timeline.txt), and the exchange has until the middle of the NEXT
 // cycle to arrive instead of the end of the current launch.
-bool cycle_applicable(const lb_sim *s, int h)
+// depth of the fused kernel the halo cycle of a slab runs on: 4 (eight-step cycle), 3 (six-step cycle) or 0
+// (no cycle: exchange after every launch).  h = the smallest slab height of the run.
+int cycle_depth(const lb_sim *s, int h)
 {
     const int v = effective_variant(s);
-    return (v & 64) && !(v & 128) && step3_applicable(s, h) && h >= 32;
+    if (!(v & 64) || (v & 128) || !step3_applicable(s, h) || h < 32) return 0;
+    return ((v & 256) && h >= 64) ? 4 : 3;
 }
+const HaloTables &cycle_halo(int depth) { return depth == 4 ? HALO8 : HALO6; }
 
 // bands of output rows [lo_s, hi_s) and [lo_n, hi_n): one wave per strip and band
-int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi_n, bool macro)
+int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi_n, bool macro, int depth)
 {
     if (hi_s - lo_s == hi_n - lo_n)
-        return launch_step2(s, st, lo_s, hi_n, macro, 2, hi_s - lo_s, lo_n - lo_s, 0, 3);
-    int rc = launch_step2(s, st, lo_s, hi_s, macro, 1, hi_s - lo_s, 0, 0, 3);
-    if (!rc) rc = launch_step2(s, st, lo_n, hi_n, macro, 1, hi_n - lo_n, 0, 0, 3);
+        return launch_step2(s, st, lo_s, hi_n, macro, 2, hi_s - lo_s, lo_n - lo_s, 0, depth);
+    int rc = launch_step2(s, st, lo_s, hi_s, macro, 1, hi_s - lo_s, 0, 0, depth);
+    if (!rc) rc = launch_step2(s, st, lo_n, hi_n, macro, 1, hi_n - lo_n, 0, 0, depth);
     return rc;
 }
 
-// E1 + C1 (the caller flips cur afterwards)
-int slab_cycle_first(lb_sim *s)
+// E1 + C1 (the caller flips cur afterwards); D = depth of the fused kernel (3 or 4)
+int slab_cycle_first(lb_sim *s, int D)
 {
     const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
     const StepArgs probe = step_args(s, 0, 1, 1);
-    int rc = launch_bands(s, s->edge_stream, probe.ghost_s ? -3 : 0, 3, H - 3, probe.ghost_n ? H + 3 : H, false);
+    int rc = launch_bands(s, s->edge_stream, probe.ghost_s ? -D : 0, D, H - D, probe.ghost_n ? H + D : H, false, D);
     if (rc) return rc;
-    if ((rc = launch_step2(s, s->stream, 3, H - 3, false, 0, 0, 0, 2 * strips, 3))) return rc;
+    if ((rc = launch_step2(s, s->stream, D, H - D, false, 0, 0, 0, 2 * strips, D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
 
-// E2 + C2 (the caller flips cur afterwards); ev_boundary = the six edge rows of the new lattice are complete
-int slab_cycle_second(lb_sim *s, bool macro)
+// E2 + C2 (the caller flips cur afterwards); ev_boundary = the 2D edge rows of the new lattice are complete
+int slab_cycle_second(lb_sim *s, bool macro, int D)
 {
     const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
-    int rc = launch_bands(s, s->edge_stream, 0, 6, H - 6, H, macro);
+    int rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-    return launch_step2(s, s->stream, 6, H - 6, macro, 0, 0, 0, 2 * strips, 3);
+    return launch_step2(s, s->stream, 2 * D, H - 2 * D, macro, 0, 0, 0, 2 * strips, D);
 }
 
 // Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
@@ -1254,18 +1261,20 @@ int lb_run(lb_sim *s, int n_steps)
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     int left = n_steps;
     const int hmin = s->min_h > 0 ? s->min_h : s->H;     // all ranks decide on the same height
-    if (cycle_applicable(s, hmin) && left >= 6) {
-        // six-step cycles (see slab_cycle_first); whatever is left over runs launch by launch below
-        if (s->ghost_depth < 6 && (rc = exchange_rccl(s, s->cur, s->edge_stream, HALO6))) return rc;
-        for (; left >= 6; left -= 6) {
-            if ((rc = slab_cycle_first(s))) return rc;
+    const int D = cycle_depth(s, hmin);
+    if (D && left >= 2 * D) {
+        // 2D-step cycles (see slab_cycle_first); whatever is left over runs launch by launch below
+        const HaloTables &T = cycle_halo(D);
+        if (s->ghost_depth < 2 * D && (rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
+        for (; left >= 2 * D; left -= 2 * D) {
+            if ((rc = slab_cycle_first(s, D))) return rc;
             s->cur ^= 1;
-            if ((rc = slab_cycle_second(s, left == 6))) return rc;
+            if ((rc = slab_cycle_second(s, left == 2 * D, D))) return rc;
             s->cur ^= 1;
-            if ((rc = exchange_rccl(s, s->cur, s->edge_stream, HALO6))) return rc;
+            if ((rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
         }
-        s->ghost_depth = 6;
+        s->ghost_depth = 2 * D;
     }
     if (left > 0 && s->ghost_depth < 3) {
         // ghost rows of the current lattice: exchange once before the first step
@@ -1343,14 +1352,16 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
     }
     int hmin = sims[0]->H;
     for (int i = 1; i < count; ++i) hmin = std::min(hmin, sims[i]->H);
-    bool two = true, three = true, cycle = true;
+    bool two = true, three = true;
+    int D = 4;
     for (int i = 0; i < count; ++i) {
         two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i], hmin);
         three = three && (effective_variant(sims[i]) & 64) && step3_applicable(sims[i], hmin);
-        cycle = cycle && cycle_applicable(sims[i], hmin);
+        D = std::min(D, cycle_depth(sims[i], hmin));
     }
     int left = n_steps;
-    if (cycle && left >= 6) {
+    if (D && left >= 2 * D) {
+        const HaloTables &T = cycle_halo(D);
         // The six-step cycle of lb_run with the transport replaced: every member packs its edges on its
         // edge stream, the receivers unpack straight from the senders' buffers.
         for (int i = 0; i < count; ++i)
@@ -1358,7 +1369,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
                 HIP_TRY(hipMalloc(&sims[i]->halo_buf, sizeof(float) * 4 * HALO_SEGS_DEEP * sims[i]->p.nx));
                 sims[i]->bytes += sizeof(float) * 4 * HALO_SEGS_DEEP * sims[i]->p.nx;
             }
-        const size_t n = (size_t)HALO6.n * sims[0]->p.nx;
+        const size_t n = (size_t)T.n * sims[0]->p.nx;
         auto south_of = [&](int i) { return i > 0 ? i - 1 : (wrap ? count - 1 : -1); };
         auto north_of = [&](int i) { return i < count - 1 ? i + 1 : (wrap ? 0 : -1); };
         auto exchange_deep = [&]() -> int {
@@ -1367,7 +1378,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
                 // my send buffers are free again once both neighbours have unpacked the previous halo
                 for (int nb : {south_of(i), north_of(i)})
                     if (nb >= 0) HIP_TRY(hipStreamWaitEvent(me->edge_stream, sims[nb]->ev_halo, 0));
-                if ((rc = halo_pack(me, me->cur, me->edge_stream, HALO6, north_of(i) >= 0, south_of(i) >= 0))) return rc;
+                if ((rc = halo_pack(me, me->cur, me->edge_stream, T, north_of(i) >= 0, south_of(i) >= 0))) return rc;
                 HIP_TRY(hipEventRecord(me->ev_packed, me->edge_stream));
             }
             for (int i = 0; i < count; ++i) {
@@ -1376,7 +1387,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
                 for (int nb : {so, no})
                     if (nb >= 0) HIP_TRY(hipStreamWaitEvent(me->edge_stream, sims[nb]->ev_packed, 0));
                 // my south ghost rows <- what the southern neighbour sent north, and vice versa
-                if ((rc = halo_unpack(me, me->cur, me->edge_stream, HALO6, so >= 0 ? sims[so]->halo_buf : nullptr,
+                if ((rc = halo_unpack(me, me->cur, me->edge_stream, T, so >= 0 ? sims[so]->halo_buf : nullptr,
                                       no >= 0 ? sims[no]->halo_buf + n : nullptr)))
                     return rc;
                 HIP_TRY(hipEventRecord(me->ev_halo, me->edge_stream));
@@ -1384,13 +1395,13 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
             return LB_OK;
         };
         if ((rc = exchange_deep())) return rc;
-        for (; left >= 6; left -= 6) {
+        for (; left >= 2 * D; left -= 2 * D) {
             for (int i = 0; i < count; ++i) {
-                if ((rc = slab_cycle_first(sims[i]))) return rc;
+                if ((rc = slab_cycle_first(sims[i], D))) return rc;
                 sims[i]->cur ^= 1;
             }
             for (int i = 0; i < count; ++i) {
-                if ((rc = slab_cycle_second(sims[i], left == 6))) return rc;
+                if ((rc = slab_cycle_second(sims[i], left == 2 * D, D))) return rc;
                 sims[i]->cur ^= 1;
             }
             if ((rc = exchange_deep())) return rc;
@@ -1400,7 +1411,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         for (int i = 0; i < count; ++i) {
             HIP_TRY(hipStreamSynchronize(sims[i]->edge_stream));
             HIP_TRY(hipStreamSynchronize(sims[i]->stream));
-            sims[i]->ghost_depth = 6;
+            sims[i]->ghost_depth = 2 * D;
             sims[i]->feq_valid = false;
         }
         if (left == 0) return LB_OK;
@@ -1494,7 +1505,8 @@ int lb_steps_per_launch(lb_sim *s)
     } else {
         const int v = effective_variant(s);
         const int h = s->min_h > 0 ? s->min_h : s->H;
-        if ((v & 64) && step3_applicable(s, h)) n = 3;
+        if (cycle_depth(s, h)) n = cycle_depth(s, h);
+        else if ((v & 64) && step3_applicable(s, h)) n = 3;
         else if ((v & 32) && step2_applicable(s, h)) n = 2;
     }
     return n;

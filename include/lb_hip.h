@@ -86,9 +86,9 @@ typedef struct {
  * itself).  Lets the multi-GPU code path run, and be tested, on a single GPU. */
 #define LB_FLAG_HALO 1
 
-/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the six-step halo cycle
- * recomputes three of the neighbour's rows and reads the mask two rows beyond them. */
-#define LB_MASK_HALO_ROWS 5
+/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the eight-step halo cycle
+ * recomputes four of the neighbour's rows and reads the mask three rows beyond them. */
+#define LB_MASK_HALO_ROWS 7
 
 typedef struct lb_sim lb_sim; /* opaque: device buffers, streams, events, RCCL communicator */
 
@@ -171,8 +171,9 @@ int lb_run_group(lb_sim **sims, int count, int n_steps);
  * lb_comm_unique_id and the caller broadcasts it (torch.distributed).
  * lb_comm_init is collective (every rank of the communicator calls it: the ranks agree on the smallest
  * slab height there, which decides the kernels and the exchange rhythm).  Afterwards lb_run on a slab
- * handle exchanges halos itself: six-rows-deep ghost zones, two three-step launches per exchange on
- * slabs of >= 32 rows and nx >= 512, otherwise one exchange of the 3-deep halo per launch. */
+ * handle exchanges halos itself: two four-step (slabs of >= 64 rows) or three-step (>= 32 rows) launches per
+ * exchange with ghost zones eight / six rows deep when nx >= 512, otherwise one exchange of the 3-deep halo
+ * per launch. */
 int lb_comm_unique_id(void *unique_id_128);
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
 

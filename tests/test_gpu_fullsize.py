@@ -89,19 +89,19 @@ def test_config4_shear_layer_8192_properties(lbhip):
 
 
 def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
-    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, three-step kernel, 6-deep halo)
+    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, four-step kernel, 8-deep halo)
     executed as in-library virtual slabs on one device: bitwise equal to the undivided run."""
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing, partition_rows
     import bench
-    n, steps = 8192, 14                           # 2 six-step halo cycles + 2 steps
+    n, steps = 8192, 19                           # 2 eight-step halo cycles + 3 steps
     one = Simulation(n, n, 1.7, bc="periodic")
     one.init_equilibrium(*bench.shear_layer(n, n, 0, n))
     one.run(steps)
     want = one.get_fields(("rho", "u", "v"))
     one.close()
     ring = LocalSlabRing(n, n, 1.7, 8, bc="periodic")
-    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 3
+    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 4
     for s, (y0, h) in zip(ring.slabs, ring.parts):
         s.init_equilibrium(*bench.shear_layer(n, n, y0, h))
     ring.run_in_library(steps)

@@ -241,15 +241,16 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
     one = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, **kw)
     one.set_variant(0)
     one.set_f(f0)
-    # six-step cycles / three-step launches without the cycle / two-step / single-step kernels on slabs
-    for variant in (97, 97 | 128, 33, 1):
+    # eight-step cycles (slabs of >= 64 rows, else six-step) / six-step cycles / three-step launches without
+    # the cycle / two-step / single-step kernels on slabs
+    for variant in (97 | 256, 97, 97 | 128, 33, 1):
         ring = LocalSlabRing(nx, ny, 1.55, nslabs, bc=bc, obstacle_mask=mask, **kw)
         ring.set_variant(variant)
         ring.set_f(f0)
         ring.run_in_library(20)                   # 3 cycles + 2 steps
         ring.run_in_library(7)                    # 1 cycle + 1 step
         ring.run_in_library(4)
-        if variant == 97:
+        if variant == (97 | 256):
             one.run(31)
         a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
         for k in a:
@@ -268,7 +269,7 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
     one.set_variant(0)
     one.set_f(f0)
     one.run(41)
-    for variant in (97, 97 | 128):                # with and without the six-step halo cycle
+    for variant in (97 | 256, 97, 97 | 128):      # eight-step cycle, six-step cycle, no cycle
         two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
         two.set_variant(variant)
         two.comm_init(comm_unique_id(), 0, 1)
