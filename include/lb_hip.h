@@ -126,7 +126,7 @@ int lb_init_pop(lb_sim *s);             /* f = f_streamed = feq (device side of 
 /* ---- the hot path: n time steps (replaces the body of Pipe_Flow.run, opencl_dim.py:372-387:
  *      move -> move_bcs(+obstacle) -> update_hydro -> update_feq -> collide_particles, 6-8 launches and
  *      as many host waits per step) by fused launches that advance one, two or three time steps each
- *      (k_step, k_step2, k_step3; results bitwise independent of which) and no host wait.
+ *      (k_step, k_step2, k_step3, k_step4; results bitwise independent of which) and no host wait.
  *      rho,u,v of the LAST step are stored (they are only observable through get_fields); feq is
  *      rebuilt from them on demand.  Handles with LB_SEM_CYTHON or LB_BC_VELOCITY_INLET run the
  *      un-fused phase kernels in their reference order instead.
@@ -201,7 +201,7 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * non-temporal stores, bit 1 non-temporal loads, bits 2-3 rows per workgroup (0: 4, 1: 1, 2: 2),
  * bit 4 XCD-aware tile order, bit 5 two time steps per pass where applicable (nx >= 512), bit 6 three
  * time steps per pass, bit 7 slabs exchange their halo after every launch instead of every two (no
- * six-step cycle), bit 8 four time steps per pass (whole-grid handles, nx >= 512, >= 128 rows).  Results
+ * halo cycle), bit 8 four time steps per pass (nx >= 512; whole-grid handles of >= 128 rows, slabs of >= 64).  Results
  * never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);
 
