@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timing of the fused kernels (diagnostic build, wrong results by design, timing only).
 LB_DIAG bits: 1 = skip step-1 collide, 2 = skip step-2 collide, 4 = no stores (k_step2) / skip step-3 collide
-(k_step3), 8 = all loads aligned.
+(k_step3), 8 = all loads aligned, 512 = no boundary rule in the 4-cell path.
 Each configuration runs in its own process (the switches are read at lb_create)."""
 import os
 import subprocess
