@@ -217,25 +217,25 @@ void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, b
     }
 }
 
-// variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py; profiles/r01_sweep_variants.txt):
-//   >= 2048^2 cells on this GPU        : temporal blocking -- three time steps per pass on whole-grid
-//                                        handles (k_step3: 141 k MLUPS at 2048^2, 190 k at 4096^2, 201 k at
-//                                        8192^2), two on row slabs (k_step2: 141 k at 8192^2), vs 83 k single-step
-//   lattice pair >= 1 GB (4096^2 up)   : + non-temporal stores (+3..6 %), and 2 rows x 512 cells per
-//                                        workgroup wherever the single-step kernel runs
-//   smaller (Infinity-Cache resident)  : single step, plain stores, XCD-aware tile order (87 k MLUPS at
-//                                        1024^2; the marching kernels have too few waves there)
+// variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py, tools/rect_probe.py;
+// profiles/r01_sweep_variants.txt):
+//   >= 1024^2 / 1280^2 cells on this GPU : temporal blocking -- three / four time steps per pass (marching
+//                                          kernels; nx >= 512 and enough rows, else they do not apply)
+//   lattice pair >= 1 GB (4096^2 up)     : + non-temporal stores (+3..6 %), and 2 rows x 512 cells per
+//                                          workgroup wherever the single-step kernel runs
+//   smaller (Infinity-Cache resident)    : single step, plain stores, XCD-aware tile order
 int effective_variant(const lb_sim *s)
 {
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
     int v = pair_bytes >= 1.0e9 ? 9 : 16;
-    if (cells >= 2048.0 * 2048.0) v = (v & ~16) | 32 | 64;
-    // four steps per pass from 8192 x 1024 cells up, whole grids and slabs alike (+16..21 % in every boundary
-    // family, with and without obstacles; +2 % at 2048^2, where the segments get short:
-    // profiles/r01_sweep_variants.txt, profiles/r01_slab_proxy_1gpu.txt)
-    if (cells >= 2048.0 * 4096.0) v |= 256;
+    // from 1024^2 cells: three steps per pass (110 k MLUPS at 1024^2 against 87 k single-step); from 1280^2:
+    // four (125 k at 1280^2, 158 k at 1536^2, 170 k at 2048^2, 220 k from 3072^2), whole grids and slabs alike,
+    // in every boundary family, with and without obstacles (profiles/r01_sweep_variants.txt,
+    // profiles/r01_slab_proxy_1gpu.txt).  Smaller grids: single step, replayed through a hipGraph.
+    if (cells >= 1024.0 * 1024.0) v = (v & ~16) | 32 | 64;
+    if (cells >= 1280.0 * 1280.0) v |= 256;
     return v;
 }
 
@@ -340,7 +340,10 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         segs = capacity / strips;
         if (segs < 1) segs = 1;
         seg_rows = (rows + segs - 1) / segs;
-        if (seg_rows < 16) seg_rows = 16;
+        // (floor: grids of 1024^2 .. 2048^2 are latency-bound, not bandwidth-bound -- filling every wave slot
+        //  with a short segment beats fewer, longer ones although each segment recomputes 2(d-1) rows: with the
+        //  earlier floor of 16 rows 2048^2 ran at 142 k MLUPS, with 4..8 at 170 k: profiles/r01_sweep_variants.txt)
+        if (seg_rows < 4) seg_rows = 4;
         segs = (rows + seg_rows - 1) / seg_rows;
         a.seg_stride = seg_rows;
     }
