@@ -1,0 +1,120 @@
+// kernels_tile.h -- four time steps per pass for SMALL grids: 2-D tiles staged in LDS.
+// Included by lb_hip.cpp after kernels_fused.h.
+//
+// Grids below ~1024^2 cells live in the Infinity Cache and are not bandwidth-bound: a single-step launch costs
+// its ~2 us of dependent-kernel boundary plus one global-memory round trip per step, and the marching kernels
+// (one global round trip per row) are worse.  Here a workgroup loads a 40 x 40 cell region (a 32 x 32 tile +
+// 4 halo cells on every side) of all nine planes into LDS once, advances it four time steps without touching
+// global memory -- after step s the outermost s rings hold stale data and are no longer computed --, and
+// stores the 32 x 32 tile.  Per step: every thread pulls the nine links of its cells out of LDS into
+// registers, applies the boundary rule / obstacle swap / relaxation (the same cell functions as every other
+// kernel: results are bitwise identical), and after a barrier writes the post-collision values back in place.
+// Redundant work: (40^2 + 38^2 + 36^2 + 34^2) / (4 * 32^2) = 1.34.  LDS: 9 x 1600 floats + 1600 mask bytes
+// = 59.2 KB per workgroup, two workgroups per CU.
+#pragma once
+
+namespace {
+
+constexpr int TILE = 32;                    // cells per tile edge
+constexpr int TILE_T = 4;                   // time steps per pass = halo width
+constexpr int TILE_L = TILE + 2 * TILE_T;   // edge of the region held in LDS
+constexpr int TILE_CELLS = TILE_L * TILE_L;
+constexpr int TILE_THREADS = 512;            // 8 waves; 4 cells per thread keep the kernel near 100 VGPR
+constexpr int TILE_CPT = (TILE_CELLS + TILE_THREADS - 1) / TILE_THREADS;   // cells per thread
+
+template <int BC, bool MASK, bool MACRO>
+__global__ __launch_bounds__(TILE_THREADS) void k_tile4(const StepArgs a, int tiles_x)
+{
+    __shared__ float lds[9][TILE_CELLS];
+    __shared__ unsigned char lmask[TILE_CELLS];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int gx0 = tx * TILE - TILE_T, gy0 = ty * TILE - TILE_T;     // global coordinates of region cell (0,0)
+    const long long P = a.pitch, S = a.plane;
+
+    // my cells: linear index c = ly * TILE_L + lx, global (gx, gy) wrapped where the box is periodic
+    int gxs[TILE_CPT], gys[TILE_CPT];
+    bool inbox[TILE_CPT];
+#pragma unroll
+    for (int i = 0; i < TILE_CPT; ++i) {
+        const int c = tid + i * TILE_THREADS;
+        const int lx = c % TILE_L, ly = c / TILE_L;
+        int gx = gx0 + lx, gy = gy0 + ly;
+        bool in = c < TILE_CELLS;
+        if (BC == LB_BC_PERIODIC) {
+            gx = gx < 0 ? gx + a.nx : (gx >= a.nx ? gx - a.nx : gx);
+            gy = gy < 0 ? gy + a.ny : (gy >= a.ny ? gy - a.ny : gy);
+        } else {
+            in = in && gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny;
+        }
+        gxs[i] = gx; gys[i] = gy; inbox[i] = in;
+        if (c < TILE_CELLS) {
+            const long long o = (long long)gy * P + gx;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) lds[k][c] = in ? a.src[k * S + o] : 0.f;
+            lmask[c] = (MASK && in) ? a.mask[o] : 0;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int s = 1; s <= TILE_T; ++s) {
+        Cell cs[TILE_CPT];
+        bool act[TILE_CPT];
+        // ---- pull + boundary rule + obstacle swap + relaxation, into registers ----------------------------
+#pragma unroll
+        for (int i = 0; i < TILE_CPT; ++i) {
+            const int c = tid + i * TILE_THREADS;
+            const int lx = c % TILE_L, ly = c / TILE_L;
+            act[i] = inbox[i] && lx >= s && lx < TILE_L - s && ly >= s && ly < TILE_L - s;
+            if (act[i]) {
+                Cell q;
+                q.f0 = lds[0][c];
+                q.f1 = lds[1][c - 1];
+                q.f2 = lds[2][c - TILE_L];
+                q.f3 = lds[3][c + 1];
+                q.f4 = lds[4][c + TILE_L];
+                q.f5 = lds[5][c - TILE_L - 1];
+                q.f6 = lds[6][c - TILE_L + 1];
+                q.f7 = lds[7][c + TILE_L + 1];
+                q.f8 = lds[8][c + TILE_L - 1];
+                if (BC != LB_BC_PERIODIC) {
+                    const bool w = (gxs[i] == 0), e = (gxs[i] == a.nx - 1), so = (gys[i] == 0), no = (gys[i] == a.ny - 1);
+                    if (w || e || so || no) {
+                        if (BC == LB_BC_PIPE) bc_pipe_cell(q, w, e, so, no, a.rho_in, a.rho_out);
+                        if (BC == LB_BC_CAVITY) bc_cavity_cell(q, w, e, so, no, a.lid_u, a.rho0);
+                    }
+                }
+                if (MASK) bounce_cell(q, lmask[c] != 0);
+                float rho, ux, uy;
+                relax_cell(q, a.omega, rho, ux, uy);
+                cs[i] = q;
+                if (s == TILE_T) {
+                    // the cells still computed in the last step are exactly the tile: store them
+                    const bool mine = gx0 + lx == gxs[i] && gy0 + ly == gys[i];   // not a periodic image of another tile's cell
+                    if (mine || BC != LB_BC_PERIODIC) {
+                        const long long o = (long long)gys[i] * P + gxs[i];
+                        float *d = a.dst + o;
+                        d[0] = q.f0; d[S] = q.f1; d[2 * S] = q.f2; d[3 * S] = q.f3; d[4 * S] = q.f4;
+                        d[5 * S] = q.f5; d[6 * S] = q.f6; d[7 * S] = q.f7; d[8 * S] = q.f8;
+                        if (MACRO) { a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy; }
+                    }
+                }
+            }
+        }
+        if (s == TILE_T) break;
+        __syncthreads();
+        // ---- post-collision values back in place ------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < TILE_CPT; ++i) {
+            if (act[i]) {
+                const int c = tid + i * TILE_THREADS;
+                lds[0][c] = cs[i].f0; lds[1][c] = cs[i].f1; lds[2][c] = cs[i].f2; lds[3][c] = cs[i].f3; lds[4][c] = cs[i].f4;
+                lds[5][c] = cs[i].f5; lds[6][c] = cs[i].f6; lds[7][c] = cs[i].f7; lds[8][c] = cs[i].f8;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace

@@ -15,7 +15,7 @@
 // H..H+2 are ghost rows (slab halo, three deep for the three-step kernel / don't-care at walls), so
 // element (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+3)*pitch + x .
 // Source layout (one translation unit): d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2,
-// k_step3), kernels_step4.h (k_step4), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
+// k_step3), kernels_step4.h (k_step4), kernels_tile.h (k_tile4), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
 // 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
 #include <hip/hip_runtime.h>
@@ -65,6 +65,7 @@ int fail(int code, const char *fmt, ...)
 #include "d2q9_cell.h"
 #include "kernels_fused.h"
 #include "kernels_step4.h"
+#include "kernels_tile.h"
 #include "kernels_phases.h"
 
 namespace {
@@ -306,6 +307,12 @@ bool step4_applicable(const lb_sim *s)
     return true;
 }
 
+// four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
+bool tile_applicable(const lb_sim *s)
+{
+    return !s->multi_slab() && s->p.nx >= 64 && s->H >= 64;
+}
+
 bool step2_applicable(const lb_sim *s, int h = -1)
 {
     if (h < 0) h = s->H;
@@ -353,6 +360,31 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+template <int BC>
+void launch_tile_bc(const lb_sim *s, const StepArgs &a, dim3 grid, int tiles_x, bool macro)
+{
+#define LB_LAUNCHT(MASK, MACRO) \
+    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO>), grid, dim3(TILE_THREADS), 0, s->stream, a, tiles_x)
+    if (s->has_mask) { if (macro) LB_LAUNCHT(true, true); else LB_LAUNCHT(true, false); }
+    else             { if (macro) LB_LAUNCHT(false, true); else LB_LAUNCHT(false, false); }
+#undef LB_LAUNCHT
+}
+
+// Four time steps of a whole-grid handle through 32 x 32 LDS tiles.
+int launch_tile4(lb_sim *s, bool macro)
+{
+    const StepArgs a = step_args(s, 0, 1, s->H);
+    const int tiles_x = (s->p.nx + TILE - 1) / TILE, tiles_y = (s->H + TILE - 1) / TILE;
+    const dim3 grid(tiles_x * tiles_y);
+    switch (s->p.bc_mode) {
+    case LB_BC_PIPE: launch_tile_bc<LB_BC_PIPE>(s, a, grid, tiles_x, macro); break;
+    case LB_BC_PERIODIC: launch_tile_bc<LB_BC_PERIODIC>(s, a, grid, tiles_x, macro); break;
+    default: launch_tile_bc<LB_BC_CAVITY>(s, a, grid, tiles_x, macro); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -665,8 +697,15 @@ int slab_cycle_second(lb_sim *s, bool macro, int D)
 
 // Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
 // once lb_autotune has timed this grid -- everything applicable up to the depth it found fastest.
+bool use_tile_kernel(const lb_sim *s)
+{
+    if (s->variant < 0 && s->tuned_steps) return s->tuned_wpc < 0;      // lb_autotune picked k_tile4
+    return (effective_variant(s) & 512) && tile_applicable(s);
+}
+
 int whole_grid_depths(const lb_sim *s)
 {
+    if (use_tile_kernel(s)) return depth_mask(false, false, true);      // k_tile4 + single steps for the remainder
     if (s->variant < 0 && s->tuned_steps)
         return depth_mask(step2_applicable(s) && s->tuned_steps >= 2, step3_applicable(s) && s->tuned_steps >= 3,
                           step4_applicable(s) && s->tuned_steps >= 4);
@@ -680,6 +719,7 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 {
     int rc;
     const int depths = whole_grid_depths(s);
+    const bool tile = use_tile_kernel(s);
     int left = n_steps;
     // Small grids are launch-bound (a 256^2 step is ~3 us of GPU work against ~5 us of host launch
     // cost): replay GRAPH_STEPS single-step launches captured once into a hipGraph.
@@ -693,7 +733,8 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
     while (left > 0) {
         const int adv = next_advance(depths, left);
         const bool macro = final_macro && (left == adv);
-        if (adv >= 2) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, adv);
+        if (adv == 4 && tile) rc = launch_tile4(s, macro);
+        else if (adv >= 2) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, adv);
         else rc = launch_step(s, 0, 1, s->H, macro);
         if (rc) return rc;
         s->cur ^= 1;
@@ -711,15 +752,18 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
-    const Cand cands[] = {{4, 8}, {4, 4}, {3, 8}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};
-    const int per = 12;                                // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1
+    const Cand cands[] = {{4, 8}, {4, 4}, {4, -1}, {3, 8}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
+    // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1; small grids: 36, so that the single-step candidate
+    // runs the way it would (hipGraph replay of 16 launches)
+    const int per = small_grid(s) ? 36 : 12;
     int used = 0, best = -1;
     float best_ms = 0.f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (size_t c = 0; c < sizeof(cands) / sizeof(cands[0]); ++c) {
-        if (cands[c].steps == 4 && !step4_applicable(s)) continue;
+        if (cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) continue;
+        if (cands[c].wpc < 0 && !tile_applicable(s)) continue;
         if (cands[c].steps == 3 && !step3_applicable(s)) continue;
         if (cands[c].steps == 2 && !step2_applicable(s)) continue;
         s->tuned_steps = cands[c].steps;
@@ -1242,8 +1286,9 @@ int lb_run(lb_sim *s, int n_steps)
     if (!s->multi_slab()) {
         // Long first run with the automatic variant: time the candidate kernel configurations on the
         // first steps of this very run (they are bitwise equivalent) and keep the fastest.
-        if (s->variant < 0 && !s->tuned_steps && n_steps >= 200 && (step2_applicable(s) || step3_applicable(s))) {
-            const int used = autotune_whole_grid(s, 1);   // <= 7 candidates x 2 samples x 12 steps + 1 = 169 steps
+        if (s->variant < 0 && !s->tuned_steps && n_steps >= 200 &&
+            (step2_applicable(s) || step3_applicable(s) || tile_applicable(s))) {
+            const int used = autotune_whole_grid(s, 1);   // <= 8 candidates x 2 samples x 12 steps + 1 = 193 steps
             if (used < 0) return used;
             n_steps -= used;
         }
@@ -1520,7 +1565,7 @@ int lb_autotune(lb_sim *s)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune inside a split step");
     if (s->multi_slab() || s->p.semantics != LB_SEM_OPENCL || s->p.bc_mode == LB_BC_VELOCITY_INLET ||
-        !(step2_applicable(s) || step3_applicable(s)))
+        !(step2_applicable(s) || step3_applicable(s) || tile_applicable(s)))
         return 0;                                      // nothing to choose between
     DeviceGuard guard(s->p.device);
     return autotune_whole_grid(s, 6);

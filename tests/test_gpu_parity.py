@@ -175,11 +175,12 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
         mask[:, 0] = mask[:, -1] = False
     kw = dict(inlet_rho=1.004, lid_u=0.06)
     sims = []
-    # single step / two-step / + NT stores / three-step (+ two-step remainder) / four-step (+ remainders)
-    for variant in (0, 32, 33, 97, 97 | 256):
+    # single step / two-step / + NT stores / three-step (+ two-step remainder) / four-step (+ remainders) /
+    # four steps through LDS tiles (+ single-step remainders)
+    for variant in (0, 32, 33, 97, 97 | 256, 512):
         s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
-        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4}[variant]
+        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4}[variant]
         s.set_f(f0)
         s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step)
         s.run(4)                      # 4 = 2+2 = 1+3 = 4
@@ -189,11 +190,40 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
         assert np.array_equal(sims[1][k], sims[2][k]), k          # NT stores never change results
         assert np.array_equal(sims[0][k], sims[3][k]), k          # three steps per pass: still bitwise
         assert np.array_equal(sims[0][k], sims[4][k]), k          # four steps per pass (LDS windows): still bitwise
+        assert np.array_equal(sims[0][k], sims[5][k]), k          # four steps per pass (LDS tiles): still bitwise
     code = {"pipe": oracle.BC_PIPE, "periodic": oracle.BC_PERIODIC, "cavity": oracle.BC_CAVITY}[bc]
     o = oracle.O2Sim(nx, ny, 1.6, code, 1.004, 1., 0.06, 1., mask=mask)
     o.set_f(f0)
     o.run(11)
     assert_fields_close(sims[1], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
+
+
+@pytest.mark.parametrize("bc,nx,ny", [("pipe", 96, 64), ("periodic", 64, 96), ("cavity", 130, 70), ("periodic", 256, 256),
+                                      ("pipe", 301, 101)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_tile_kernel_equals_single_step_kernel_small_grids(lbhip, bc, nx, ny, masked):
+    """k_tile4 (variant bit 9): four time steps per pass inside 32 x 32 LDS tiles, for the small grids the
+    marching kernels do not serve; tile edges that are not multiples of 32, periodic images, walls, masks."""
+    from LB_D2Q9.simulation import Simulation
+    rng = np.random.default_rng(7 * nx + ny)
+    f0 = _random_state(rng, nx, ny)
+    mask = None
+    if masked:
+        mask = rng.random((nx, ny)) < 0.05
+        if bc != "periodic":
+            mask[0, :] = mask[-1, :] = False
+            mask[:, 0] = mask[:, -1] = False
+    kw = dict(inlet_rho=1.004, lid_u=0.06)
+    out = []
+    for variant in (0, 512):
+        s = Simulation(nx, ny, 1.45, bc=bc, obstacle_mask=mask, **kw)
+        s.set_variant(variant)
+        s.set_f(f0)
+        s.run(9)                      # 9 = 1 + 4 + 4
+        s.run(8)
+        out.append(s.get_fields(("f", "rho", "u", "v")))
+    for k in ("f", "rho", "u", "v"):
+        assert np.array_equal(out[0][k], out[1][k]), k
 
 
 # ---- row slabs ---------------------------------------------------------------------------------------
