@@ -15,21 +15,27 @@
 
 namespace {
 
-constexpr int TILE = 32;                    // cells per tile edge
 constexpr int TILE_T = 4;                   // time steps per pass = halo width
-constexpr int TILE_L = TILE + 2 * TILE_T;   // edge of the region held in LDS
-constexpr int TILE_CELLS = TILE_L * TILE_L;
-constexpr int TILE_THREADS = 512;            // 8 waves; 4 cells per thread keep the kernel near 100 VGPR
-constexpr int TILE_CPT = (TILE_CELLS + TILE_THREADS - 1) / TILE_THREADS;   // cells per thread
+constexpr int TILE_CPT = 4;                 // cells per thread (keeps the kernel near 70 VGPR)
 
-template <int BC, bool MASK, bool MACRO>
-__global__ __launch_bounds__(TILE_THREADS) void k_tile4(const StepArgs a, int tiles_x)
+// TW x TH = the tile; the region held in LDS is (TW + 8) x (TH + 8).  Three shapes, picked by the host so that
+// small grids still spread over the chip: 32 x 32 (512 threads), 32 x 16 (256), 16 x 16 (192).
+template <int TW, int TH>
+struct TileShape {
+    static constexpr int LW = TW + 2 * TILE_T, LH = TH + 2 * TILE_T, CELLS = LW * LH;
+    static constexpr int THREADS = ((CELLS + TILE_CPT - 1) / TILE_CPT + 63) / 64 * 64;
+};
+
+template <int BC, bool MASK, bool MACRO, int TW, int TH>
+__global__ __launch_bounds__((TileShape<TW, TH>::THREADS)) void k_tile4(const StepArgs a, int tiles_x)
 {
+    constexpr int TILE_L = TileShape<TW, TH>::LW, TILE_LH = TileShape<TW, TH>::LH;
+    constexpr int TILE_CELLS = TileShape<TW, TH>::CELLS, TILE_THREADS = TileShape<TW, TH>::THREADS;
     __shared__ float lds[9][TILE_CELLS];
     __shared__ unsigned char lmask[TILE_CELLS];
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int gx0 = tx * TILE - TILE_T, gy0 = ty * TILE - TILE_T;     // global coordinates of region cell (0,0)
+    const int gx0 = tx * TW - TILE_T, gy0 = ty * TH - TILE_T;         // global coordinates of region cell (0,0)
     const long long P = a.pitch, S = a.plane;
 
     // my cells: linear index c = ly * TILE_L + lx, global (gx, gy) wrapped where the box is periodic
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile4(const StepArgs a, int ti
         for (int i = 0; i < TILE_CPT; ++i) {
             const int c = tid + i * TILE_THREADS;
             const int lx = c % TILE_L, ly = c / TILE_L;
-            act[i] = inbox[i] && lx >= s && lx < TILE_L - s && ly >= s && ly < TILE_L - s;
+            act[i] = inbox[i] && lx >= s && lx < TILE_L - s && ly >= s && ly < TILE_LH - s;
             if (act[i]) {
                 Cell q;
                 q.f0 = lds[0][c];

@@ -365,26 +365,38 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     return LB_OK;
 }
 
-template <int BC>
-void launch_tile_bc(const lb_sim *s, const StepArgs &a, dim3 grid, int tiles_x, bool macro)
+template <int BC, int TW, int TH>
+void launch_tile_shape(const lb_sim *s, const StepArgs &a, bool macro)
 {
+    const int tiles_x = (s->p.nx + TW - 1) / TW, tiles_y = (s->H + TH - 1) / TH;
+    const dim3 grid(tiles_x * tiles_y), block(TileShape<TW, TH>::THREADS);
 #define LB_LAUNCHT(MASK, MACRO) \
-    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO>), grid, dim3(TILE_THREADS), 0, s->stream, a, tiles_x)
+    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO, TW, TH>), grid, block, 0, s->stream, a, tiles_x)
     if (s->has_mask) { if (macro) LB_LAUNCHT(true, true); else LB_LAUNCHT(true, false); }
     else             { if (macro) LB_LAUNCHT(false, true); else LB_LAUNCHT(false, false); }
 #undef LB_LAUNCHT
 }
 
-// Four time steps of a whole-grid handle through 32 x 32 LDS tiles.
+template <int BC>
+void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
+{
+    // the largest tile that still gives every CU a workgroup (smaller tiles recompute more halo, but a small
+    // grid is bound by latency, not by work)
+    const long long cells = (long long)s->p.nx * s->H;
+    const int shape = cells >= 32LL * 32 * s->cu_count ? 1 : (cells >= 32LL * 16 * s->cu_count ? 2 : 3);
+    if (shape == 1) launch_tile_shape<BC, 32, 32>(s, a, macro);
+    else if (shape == 2) launch_tile_shape<BC, 32, 16>(s, a, macro);
+    else launch_tile_shape<BC, 16, 16>(s, a, macro);
+}
+
+// Four time steps of a whole-grid handle through LDS tiles.
 int launch_tile4(lb_sim *s, bool macro)
 {
     const StepArgs a = step_args(s, 0, 1, s->H);
-    const int tiles_x = (s->p.nx + TILE - 1) / TILE, tiles_y = (s->H + TILE - 1) / TILE;
-    const dim3 grid(tiles_x * tiles_y);
     switch (s->p.bc_mode) {
-    case LB_BC_PIPE: launch_tile_bc<LB_BC_PIPE>(s, a, grid, tiles_x, macro); break;
-    case LB_BC_PERIODIC: launch_tile_bc<LB_BC_PERIODIC>(s, a, grid, tiles_x, macro); break;
-    default: launch_tile_bc<LB_BC_CAVITY>(s, a, grid, tiles_x, macro); break;
+    case LB_BC_PIPE: launch_tile_bc<LB_BC_PIPE>(s, a, macro); break;
+    case LB_BC_PERIODIC: launch_tile_bc<LB_BC_PERIODIC>(s, a, macro); break;
+    default: launch_tile_bc<LB_BC_CAVITY>(s, a, macro); break;
     }
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -697,10 +709,16 @@ int slab_cycle_second(lb_sim *s, bool macro, int D)
 
 // Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
 // once lb_autotune has timed this grid -- everything applicable up to the depth it found fastest.
+// Four steps per pass through LDS tiles (k_tile4) instead of the marching kernels: asked for (variant bit 9),
+// found fastest by lb_autotune, or -- automatic -- on whole grids below ~1400^2 cells and on grids the marching
+// kernels do not serve (27 k MLUPS at 256^2, 82 k at 512^2, 120 k at 1024^2, 138 k at 1280^2, against 19 / 57 /
+// 113 / 129 k; from 1536^2 the marching kernel wins, 163 against 153 k: profiles/r01_sweep_variants.txt).
 bool use_tile_kernel(const lb_sim *s)
 {
-    if (s->variant < 0 && s->tuned_steps) return s->tuned_wpc < 0;      // lb_autotune picked k_tile4
-    return (effective_variant(s) & 512) && tile_applicable(s);
+    if (!tile_applicable(s)) return false;
+    if (s->variant >= 0) return (s->variant & 512) != 0;
+    if (s->tuned_steps) return s->tuned_wpc < 0;
+    return (double)s->p.nx * s->H < 1400.0 * 1400.0 || !step4_applicable(s);
 }
 
 int whole_grid_depths(const lb_sim *s)
@@ -1286,9 +1304,12 @@ int lb_run(lb_sim *s, int n_steps)
     if (!s->multi_slab()) {
         // Long first run with the automatic variant: time the candidate kernel configurations on the
         // first steps of this very run (they are bitwise equivalent) and keep the fastest.
-        if (s->variant < 0 && !s->tuned_steps && n_steps >= 200 &&
+        // (it consumes up to 8 candidates x 2 samples x 12 steps + 1 = 193 steps; 577 on small grids, whose
+        //  samples are 36 steps long)
+        const int tune_steps = 8 * 2 * (small_grid(s) ? 36 : 12) + 1;
+        if (s->variant < 0 && !s->tuned_steps && n_steps >= tune_steps + 7 &&
             (step2_applicable(s) || step3_applicable(s) || tile_applicable(s))) {
-            const int used = autotune_whole_grid(s, 1);   // <= 8 candidates x 2 samples x 12 steps + 1 = 193 steps
+            const int used = autotune_whole_grid(s, 1);
             if (used < 0) return used;
             n_steps -= used;
         }
