@@ -341,7 +341,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         // as many wave-items as the chip holds at once (waves per CU from the kernel's register
         // budget; tunable), each marching an equal share of the rows
         int waves_per_cu = s->tuned_wpc > 0 ? s->tuned_wpc : 8;
-        if (const char *e = getenv("LB_STEP2_WAVES_PER_CU")) waves_per_cu = atoi(e) > 0 ? atoi(e) : waves_per_cu;
+        static const int wpc_env = getenv("LB_STEP2_WAVES_PER_CU") ? atoi(getenv("LB_STEP2_WAVES_PER_CU")) : 0;   // tuning knob
+        if (wpc_env > 0) waves_per_cu = wpc_env;
         const int capacity = s->cu_count * waves_per_cu - reserve;
         const int rows = row_end - row_begin;
         segs = capacity / strips;
