@@ -63,62 +63,97 @@ __global__ __launch_bounds__((TileShape<TW, TH>::THREADS)) void k_tile4(const St
     }
     __syncthreads();
 
+    // Wall cells (x = 0, nx-1; y = 0, ny-1) are not processed in the main pass but in one extra pass in which
+    // thread t takes the t-th wall cell of the region (west column, east column, south row, north row; corners
+    // belong to the columns): in the linear cell order every wave of a wall tile holds a few wall cells and
+    // would execute the whole boundary rule four times per step.  Positions inside the region, -1 = this tile
+    // does not touch that wall; all workgroup-uniform.
+    int lxw = -1, lxe = -1, lys = -1, lyn = -1;
+    if (BC != LB_BC_PERIODIC) {
+        if (gx0 <= 0 && 0 < gx0 + TILE_L) lxw = -gx0;
+        if (gx0 <= a.nx - 1 && a.nx - 1 < gx0 + TILE_L) lxe = a.nx - 1 - gx0;
+        if (gy0 <= 0 && 0 < gy0 + TILE_LH) lys = -gy0;
+        if (gy0 <= a.ny - 1 && a.ny - 1 < gy0 + TILE_LH) lyn = a.ny - 1 - gy0;
+    }
+    const bool wall_tile = BC != LB_BC_PERIODIC && (lxw >= 0 || lxe >= 0 || lys >= 0 || lyn >= 0);
+    // my wall cell (thread t: [0,LH) west column, [LH,2LH) east, [2LH,2LH+L) south row, [2LH+L,2LH+2L) north)
+    int wlx = -1, wly = -1;
+    if (wall_tile) {
+        int t = tid;
+        if (t < TILE_LH) { wlx = lxw; wly = t; }
+        else if ((t -= TILE_LH) < TILE_LH) { wlx = lxe; wly = t; }
+        else if ((t -= TILE_LH) < TILE_L) { wlx = t; wly = lys; if (t == lxw || t == lxe) wlx = -1; }
+        else if ((t -= TILE_L) < TILE_L) { wlx = t; wly = lyn; if (t == lxw || t == lxe) wlx = -1; }
+        if (wlx < 0 || wly < 0) wlx = wly = -1;
+        else {
+            const int gx = gx0 + wlx, gy = gy0 + wly;
+            if (gx < 0 || gx >= a.nx || gy < 0 || gy >= a.ny) wlx = wly = -1;
+        }
+    }
+    const int wc = wly * TILE_L + wlx;
+
+    // pull (+ boundary rule) + obstacle swap + relaxation of region cell c at global (gx, gy); in the last step
+    // the result goes to global memory (the cells still computed then are exactly the tile)
+    auto cell_step = [&](int c, int gx, int gy, auto wall, bool last, bool mine, Cell &q) {
+        q.f0 = lds[0][c];
+        q.f1 = lds[1][c - 1];
+        q.f2 = lds[2][c - TILE_L];
+        q.f3 = lds[3][c + 1];
+        q.f4 = lds[4][c + TILE_L];
+        q.f5 = lds[5][c - TILE_L - 1];
+        q.f6 = lds[6][c - TILE_L + 1];
+        q.f7 = lds[7][c + TILE_L + 1];
+        q.f8 = lds[8][c + TILE_L - 1];
+        if (decltype(wall)::value) {
+            const bool w = (gx == 0), e = (gx == a.nx - 1), so = (gy == 0), no = (gy == a.ny - 1);
+            if (BC == LB_BC_PIPE) bc_pipe_cell(q, w, e, so, no, a.rho_in, a.rho_out);
+            if (BC == LB_BC_CAVITY) bc_cavity_cell(q, w, e, so, no, a.lid_u, a.rho0);
+        }
+        if (MASK) bounce_cell(q, lmask[c] != 0);
+        float rho, ux, uy;
+        relax_cell(q, a.omega, rho, ux, uy);
+        if (last && mine) {
+            const long long o = (long long)gy * P + gx;
+            float *d = a.dst + o;
+            d[0] = q.f0; d[S] = q.f1; d[2 * S] = q.f2; d[3 * S] = q.f3; d[4 * S] = q.f4;
+            d[5 * S] = q.f5; d[6 * S] = q.f6; d[7 * S] = q.f7; d[8 * S] = q.f8;
+            if (MACRO) { a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy; }
+        }
+    };
+    auto cell_put = [&](int c, const Cell &q) {
+        lds[0][c] = q.f0; lds[1][c] = q.f1; lds[2][c] = q.f2; lds[3][c] = q.f3; lds[4][c] = q.f4;
+        lds[5][c] = q.f5; lds[6][c] = q.f6; lds[7][c] = q.f7; lds[8][c] = q.f8;
+    };
+
 #pragma unroll 1
     for (int s = 1; s <= TILE_T; ++s) {
-        Cell cs[TILE_CPT];
-        bool act[TILE_CPT];
-        // ---- pull + boundary rule + obstacle swap + relaxation, into registers ----------------------------
+        const bool last = (s == TILE_T);
+        Cell cs[TILE_CPT], wq;
+        bool act[TILE_CPT], wact = false;
+        // ---- main pass: every cell that is not on a wall ----------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TILE_CPT; ++i) {
             const int c = tid + i * TILE_THREADS;
             const int lx = c % TILE_L, ly = c / TILE_L;
             act[i] = inbox[i] && lx >= s && lx < TILE_L - s && ly >= s && ly < TILE_LH - s;
+            if (BC != LB_BC_PERIODIC) act[i] = act[i] && lx != lxw && lx != lxe && ly != lys && ly != lyn;
             if (act[i]) {
-                Cell q;
-                q.f0 = lds[0][c];
-                q.f1 = lds[1][c - 1];
-                q.f2 = lds[2][c - TILE_L];
-                q.f3 = lds[3][c + 1];
-                q.f4 = lds[4][c + TILE_L];
-                q.f5 = lds[5][c - TILE_L - 1];
-                q.f6 = lds[6][c - TILE_L + 1];
-                q.f7 = lds[7][c + TILE_L + 1];
-                q.f8 = lds[8][c + TILE_L - 1];
-                if (BC != LB_BC_PERIODIC) {
-                    const bool w = (gxs[i] == 0), e = (gxs[i] == a.nx - 1), so = (gys[i] == 0), no = (gys[i] == a.ny - 1);
-                    if (w || e || so || no) {
-                        if (BC == LB_BC_PIPE) bc_pipe_cell(q, w, e, so, no, a.rho_in, a.rho_out);
-                        if (BC == LB_BC_CAVITY) bc_cavity_cell(q, w, e, so, no, a.lid_u, a.rho0);
-                    }
-                }
-                if (MASK) bounce_cell(q, lmask[c] != 0);
-                float rho, ux, uy;
-                relax_cell(q, a.omega, rho, ux, uy);
-                cs[i] = q;
-                if (s == TILE_T) {
-                    // the cells still computed in the last step are exactly the tile: store them
-                    const bool mine = gx0 + lx == gxs[i] && gy0 + ly == gys[i];   // not a periodic image of another tile's cell
-                    if (mine || BC != LB_BC_PERIODIC) {
-                        const long long o = (long long)gys[i] * P + gxs[i];
-                        float *d = a.dst + o;
-                        d[0] = q.f0; d[S] = q.f1; d[2 * S] = q.f2; d[3 * S] = q.f3; d[4 * S] = q.f4;
-                        d[5 * S] = q.f5; d[6 * S] = q.f6; d[7 * S] = q.f7; d[8 * S] = q.f8;
-                        if (MACRO) { a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy; }
-                    }
-                }
+                const bool mine = BC != LB_BC_PERIODIC || (gx0 + lx == gxs[i] && gy0 + ly == gys[i]);   // not a periodic image
+                cell_step(c, gxs[i], gys[i], std::false_type(), last, mine, cs[i]);
             }
         }
-        if (s == TILE_T) break;
+        // ---- wall pass ------------------------------------------------------------------------------------------
+        if (wall_tile) {
+            wact = wlx >= s && wlx < TILE_L - s && wly >= s && wly < TILE_LH - s;
+            if (wact) cell_step(wc, gx0 + wlx, gy0 + wly, std::true_type(), last, true, wq);
+        }
+        if (last) break;
         __syncthreads();
         // ---- post-collision values back in place ------------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < TILE_CPT; ++i) {
-            if (act[i]) {
-                const int c = tid + i * TILE_THREADS;
-                lds[0][c] = cs[i].f0; lds[1][c] = cs[i].f1; lds[2][c] = cs[i].f2; lds[3][c] = cs[i].f3; lds[4][c] = cs[i].f4;
-                lds[5][c] = cs[i].f5; lds[6][c] = cs[i].f6; lds[7][c] = cs[i].f7; lds[8][c] = cs[i].f8;
-            }
-        }
+        for (int i = 0; i < TILE_CPT; ++i)
+            if (act[i]) cell_put(tid + i * TILE_THREADS, cs[i]);
+        if (wact) cell_put(wc, wq);
         __syncthreads();
     }
 }

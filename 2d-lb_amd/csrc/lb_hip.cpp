@@ -719,10 +719,10 @@ bool use_tile_kernel(const lb_sim *s)
     if (!tile_applicable(s)) return false;
     if (s->variant >= 0) return (s->variant & 512) != 0;
     if (s->tuned_steps) return s->tuned_wpc < 0;
-    // (periodic boxes only: the walled instantiations carry the boundary rule in every cell's path and run at
-    //  53 k MLUPS at 512^2 / 82 k at 1024^2, no better than what they would replace -- left to lb_autotune)
-    if (s->p.bc_mode != LB_BC_PERIODIC) return false;
-    return (double)s->p.nx * s->H < 1400.0 * 1400.0 || !step4_applicable(s);
+    // (walled boxes: 61 k MLUPS at 512^2 against 55 k single-step, 98 against 95 k marching at 1024^2 -- they
+    //  pay for the in-box bookkeeping and a wall pass; the marching kernels take over earlier)
+    const double limit = s->p.bc_mode == LB_BC_PERIODIC ? 1400.0 * 1400.0 : 1000.0 * 1000.0;
+    return (double)s->p.nx * s->H < limit || !step4_applicable(s);
 }
 
 int whole_grid_depths(const lb_sim *s)
