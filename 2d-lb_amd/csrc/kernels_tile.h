@@ -46,19 +46,23 @@ __global__ __launch_bounds__((TileShape<TW, TH>::THREADS)) void k_tile4(const St
         const int c = tid + i * TILE_THREADS;
         const int lx = c % TILE_L, ly = c / TILE_L;
         int gx = gx0 + lx, gy = gy0 + ly;
-        bool in = c < TILE_CELLS;
+        int sx = gx, sy = gy;                           // where the cell's data comes from
         if (BC == LB_BC_PERIODIC) {
-            gx = gx < 0 ? gx + a.nx : (gx >= a.nx ? gx - a.nx : gx);
-            gy = gy < 0 ? gy + a.ny : (gy >= a.ny ? gy - a.ny : gy);
+            gx = sx = gx < 0 ? gx + a.nx : (gx >= a.nx ? gx - a.nx : gx);
+            gy = sy = gy < 0 ? gy + a.ny : (gy >= a.ny ? gy - a.ny : gy);
         } else {
-            in = in && gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny;
+            // cells outside a walled box are computed like any other, from copies of the nearest cells inside:
+            // nothing valid consumes them (the boundary rule overwrites every link pulled from outside), and
+            // the main pass needs no in-box bookkeeping
+            sx = min(max(gx, 0), a.nx - 1);
+            sy = min(max(gy, 0), a.ny - 1);
         }
-        gxs[i] = gx; gys[i] = gy; inbox[i] = in;
+        gxs[i] = gx; gys[i] = gy; inbox[i] = c < TILE_CELLS;
         if (c < TILE_CELLS) {
-            const long long o = (long long)gy * P + gx;
+            const long long o = (long long)sy * P + sx;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) lds[k][c] = in ? a.src[k * S + o] : 0.f;
-            lmask[c] = (MASK && in) ? a.mask[o] : 0;
+            for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
+            lmask[c] = (MASK && sx == gx && sy == gy) ? a.mask[o] : 0;
         }
     }
     __syncthreads();
@@ -138,7 +142,9 @@ __global__ __launch_bounds__((TileShape<TW, TH>::THREADS)) void k_tile4(const St
             act[i] = inbox[i] && lx >= s && lx < TILE_L - s && ly >= s && ly < TILE_LH - s;
             if (BC != LB_BC_PERIODIC) act[i] = act[i] && lx != lxw && lx != lxe && ly != lys && ly != lyn;
             if (act[i]) {
-                const bool mine = BC != LB_BC_PERIODIC || (gx0 + lx == gxs[i] && gy0 + ly == gys[i]);   // not a periodic image
+                // not a periodic image of another tile's cell / inside the walled box
+                const bool mine = BC == LB_BC_PERIODIC ? (gx0 + lx == gxs[i] && gy0 + ly == gys[i])
+                                                       : (gxs[i] >= 0 && gxs[i] < a.nx && gys[i] >= 0 && gys[i] < a.ny);
                 cell_step(c, gxs[i], gys[i], std::false_type(), last, mine, cs[i]);
             }
         }

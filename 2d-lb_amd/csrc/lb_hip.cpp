@@ -719,10 +719,9 @@ bool use_tile_kernel(const lb_sim *s)
     if (!tile_applicable(s)) return false;
     if (s->variant >= 0) return (s->variant & 512) != 0;
     if (s->tuned_steps) return s->tuned_wpc < 0;
-    // (walled boxes: 61 k MLUPS at 512^2 against 55 k single-step, 98 against 95 k marching at 1024^2 -- they
-    //  pay for the in-box bookkeeping and a wall pass; the marching kernels take over earlier)
-    const double limit = s->p.bc_mode == LB_BC_PERIODIC ? 1400.0 * 1400.0 : 1000.0 * 1000.0;
-    return (double)s->p.nx * s->H < limit || !step4_applicable(s);
+    // (walled boxes likewise: pipe 24 / 74 / 112 / 123 k at 256^2 / 512^2 / 1024^2 / 1280^2 against 16.5 / 55 / 95 / 113 k;
+    //  marching from 1536^2: 136 against 130 k)
+    return (double)s->p.nx * s->H < 1400.0 * 1400.0 || !step4_applicable(s);
 }
 
 int whole_grid_depths(const lb_sim *s)
