@@ -1,29 +1,30 @@
 // kernels_tile.h -- four time steps per pass for SMALL grids: 2-D tiles staged in LDS.
 // Included by lb_hip.cpp after kernels_fused.h.
 //
-// Grids below ~1024^2 cells live in the Infinity Cache and are not bandwidth-bound: a single-step launch costs
+// Grids below ~1600^2 cells live in the Infinity Cache and are not bandwidth-bound: a single-step launch costs
 // its ~2 us of dependent-kernel boundary plus one global-memory round trip per step, and the marching kernels
-// (one global round trip per row) are worse.  Here a workgroup loads a 40 x 40 cell region (a 32 x 32 tile +
-// 4 halo cells on every side) of all nine planes into LDS once, advances it four time steps without touching
+// (one global round trip per row) are worse.  Here a workgroup loads a region -- a 32 x 16 tile + 4 halo cells on every side = 40 x 24
+// cells -- of all nine planes into LDS once, advances it four time steps without touching
 // global memory -- after step s the outermost s rings hold stale data and are no longer computed --, and
-// stores the 32 x 32 tile.  Per step: every thread pulls the nine links of its cells out of LDS into
+// stores the tile.  Per step: every thread pulls the nine links of its cells out of LDS into
 // registers, applies the boundary rule / obstacle swap / relaxation (the same cell functions as every other
 // kernel: results are bitwise identical), and after a barrier writes the post-collision values back in place.
-// Redundant work: (40^2 + 38^2 + 36^2 + 34^2) / (4 * 32^2) = 1.34.  LDS: 9 x 1600 floats + 1600 mask bytes
-// = 59.2 KB per workgroup, two workgroups per CU.
+// Redundant work with 32 x 16 tiles: (40*24 + 38*22 + 36*20 + 34*18) / (4 * 512) = 1.53.  LDS: 9 x 960 floats + 960
+// mask bytes = 35.5 KB per workgroup, four workgroups per CU.
 #pragma once
 
 namespace {
 
 constexpr int TILE_T = 4;                   // time steps per pass = halo width
-constexpr int TILE_CPT = 4;                 // cells per thread (keeps the kernel near 70 VGPR)
 
-// TW x TH = the tile; the region held in LDS is (TW + 8) x (TH + 8).  Three shapes, picked by the host so that
-// small grids still spread over the chip: 32 x 32 (512 threads), 32 x 16 (256), 16 x 16 (192).
+// TW x TH = the tile; the region held in LDS is (TW + 8) x (TH + 8).  Two shapes, picked by the host: 32 x 16
+// (512 threads) and, so that small grids still spread over the chip, 16 x 16 (576 threads).
 template <int TW, int TH>
 struct TileShape {
     static constexpr int LW = TW + 2 * TILE_T, LH = TH + 2 * TILE_T, CELLS = LW * LH;
-    static constexpr int THREADS = ((CELLS + TILE_CPT - 1) / TILE_CPT + 63) / 64 * 64;
+    // cells per thread: few, so that the kernel stays near 50-60 VGPR and four workgroups share a CU
+    static constexpr int CPT = (TW * TH >= 512) ? 2 : 1;
+    static constexpr int THREADS = ((CELLS + CPT - 1) / CPT + 63) / 64 * 64;
 };
 
 template <int BC, bool MASK, bool MACRO, int TW, int TH>
@@ -31,6 +32,7 @@ __global__ __launch_bounds__((TileShape<TW, TH>::THREADS)) void k_tile4(const St
 {
     constexpr int TILE_L = TileShape<TW, TH>::LW, TILE_LH = TileShape<TW, TH>::LH;
     constexpr int TILE_CELLS = TileShape<TW, TH>::CELLS, TILE_THREADS = TileShape<TW, TH>::THREADS;
+    constexpr int TILE_CPT = TileShape<TW, TH>::CPT;
     __shared__ float lds[9][TILE_CELLS];
     __shared__ unsigned char lmask[TILE_CELLS];
     const int tid = threadIdx.x;

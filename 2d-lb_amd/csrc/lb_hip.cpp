@@ -381,12 +381,11 @@ void launch_tile_shape(const lb_sim *s, const StepArgs &a, bool macro)
 template <int BC>
 void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
 {
-    // the largest tile that still gives every CU a workgroup (smaller tiles recompute more halo, but a small
-    // grid is bound by latency, not by work)
+    // 32 x 16 tiles (512 threads, two cells per thread, 49-60 VGPR: four workgroups per CU -- with 32 x 32 tiles and
+    // four cells per thread the same kernel ran at 117 instead of 144 k MLUPS at 1024^2: occupancy is what hides
+    // the LDS round trips); 16 x 16 tiles, one cell per thread, for grids that would not give every CU a workgroup
     const long long cells = (long long)s->p.nx * s->H;
-    const int shape = cells >= 32LL * 32 * s->cu_count ? 1 : (cells >= 32LL * 16 * s->cu_count ? 2 : 3);
-    if (shape == 1) launch_tile_shape<BC, 32, 32>(s, a, macro);
-    else if (shape == 2) launch_tile_shape<BC, 32, 16>(s, a, macro);
+    if (cells >= 330LL * 330) launch_tile_shape<BC, 32, 16>(s, a, macro);
     else launch_tile_shape<BC, 16, 16>(s, a, macro);
 }
 
@@ -721,7 +720,7 @@ bool use_tile_kernel(const lb_sim *s)
     if (s->tuned_steps) return s->tuned_wpc < 0;
     // (walled boxes likewise: pipe 24 / 74 / 112 / 123 k at 256^2 / 512^2 / 1024^2 / 1280^2 against 16.5 / 55 / 95 / 113 k;
     //  marching from 1536^2: 136 against 130 k)
-    return (double)s->p.nx * s->H < 1400.0 * 1400.0 || !step4_applicable(s);
+    return (double)s->p.nx * s->H < 1600.0 * 1600.0 || !step4_applicable(s);
 }
 
 int whole_grid_depths(const lb_sim *s)
