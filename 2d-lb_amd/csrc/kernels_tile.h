@@ -18,21 +18,21 @@ namespace {
 constexpr int TILE_T = 4;                   // time steps per pass = halo width
 
 // TW x TH = the tile; the region held in LDS is (TW + 8) x (TH + 8).  Two shapes, picked by the host: 32 x 16
-// (512 threads) and, so that small grids still spread over the chip, 16 x 16 (576 threads).
-template <int TW, int TH>
+// (two cells per thread: 512 threads; one: 960) and, so that small grids still spread over the chip, 16 x 16.
+// CPT = cells per thread: few, so that the kernel stays near 45-60 VGPR and several workgroups share a CU
+template <int TW, int TH, int CPT_>
 struct TileShape {
     static constexpr int LW = TW + 2 * TILE_T, LH = TH + 2 * TILE_T, CELLS = LW * LH;
-    // cells per thread: few, so that the kernel stays near 50-60 VGPR and four workgroups share a CU
-    static constexpr int CPT = (TW * TH >= 512) ? 2 : 1;
+    static constexpr int CPT = CPT_;
     static constexpr int THREADS = ((CELLS + CPT - 1) / CPT + 63) / 64 * 64;
 };
 
-template <int BC, bool MASK, bool MACRO, int TW, int TH>
-__global__ __launch_bounds__((TileShape<TW, TH>::THREADS)) void k_tile4(const StepArgs a, int tiles_x)
+template <int BC, bool MASK, bool MACRO, int TW, int TH, int CPT>
+__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(const StepArgs a, int tiles_x)
 {
-    constexpr int TILE_L = TileShape<TW, TH>::LW, TILE_LH = TileShape<TW, TH>::LH;
-    constexpr int TILE_CELLS = TileShape<TW, TH>::CELLS, TILE_THREADS = TileShape<TW, TH>::THREADS;
-    constexpr int TILE_CPT = TileShape<TW, TH>::CPT;
+    constexpr int TILE_L = TileShape<TW, TH, CPT>::LW, TILE_LH = TileShape<TW, TH, CPT>::LH;
+    constexpr int TILE_CELLS = TileShape<TW, TH, CPT>::CELLS, TILE_THREADS = TileShape<TW, TH, CPT>::THREADS;
+    constexpr int TILE_CPT = TileShape<TW, TH, CPT>::CPT;
     __shared__ float lds[9][TILE_CELLS];
     __shared__ unsigned char lmask[TILE_CELLS];
     const int tid = threadIdx.x;

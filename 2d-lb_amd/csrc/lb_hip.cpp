@@ -366,13 +366,13 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     return LB_OK;
 }
 
-template <int BC, int TW, int TH>
+template <int BC, int TW, int TH, int CPT>
 void launch_tile_shape(const lb_sim *s, const StepArgs &a, bool macro)
 {
     const int tiles_x = (s->p.nx + TW - 1) / TW, tiles_y = (s->H + TH - 1) / TH;
-    const dim3 grid(tiles_x * tiles_y), block(TileShape<TW, TH>::THREADS);
+    const dim3 grid(tiles_x * tiles_y), block(TileShape<TW, TH, CPT>::THREADS);
 #define LB_LAUNCHT(MASK, MACRO) \
-    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO, TW, TH>), grid, block, 0, s->stream, a, tiles_x)
+    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO, TW, TH, CPT>), grid, block, 0, s->stream, a, tiles_x)
     if (s->has_mask) { if (macro) LB_LAUNCHT(true, true); else LB_LAUNCHT(true, false); }
     else             { if (macro) LB_LAUNCHT(false, true); else LB_LAUNCHT(false, false); }
 #undef LB_LAUNCHT
@@ -384,9 +384,11 @@ void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
     // 32 x 16 tiles (512 threads, two cells per thread, 49-60 VGPR: four workgroups per CU -- with 32 x 32 tiles and
     // four cells per thread the same kernel ran at 117 instead of 144 k MLUPS at 1024^2: occupancy is what hides
     // the LDS round trips); 16 x 16 tiles, one cell per thread, for grids that would not give every CU a workgroup
+    // (two cells per thread from 900^2: 145 against 134 k at 1024^2; one below: 90 against 83 k at 512^2)
     const long long cells = (long long)s->p.nx * s->H;
-    if (cells >= 330LL * 330) launch_tile_shape<BC, 32, 16>(s, a, macro);
-    else launch_tile_shape<BC, 16, 16>(s, a, macro);
+    if (cells >= 900LL * 900) launch_tile_shape<BC, 32, 16, 2>(s, a, macro);
+    else if (cells >= 330LL * 330) launch_tile_shape<BC, 32, 16, 1>(s, a, macro);
+    else launch_tile_shape<BC, 16, 16, 1>(s, a, macro);
 }
 
 // Four time steps of a whole-grid handle through LDS tiles.
