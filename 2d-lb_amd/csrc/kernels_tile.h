@@ -40,9 +40,24 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
     const int gx0 = tx * TW - TILE_T, gy0 = ty * TH - TILE_T;         // global coordinates of region cell (0,0)
     const long long P = a.pitch, S = a.plane;
 
-    // my cells: linear index c = ly * TILE_L + lx, global (gx, gy) wrapped where the box is periodic
-    int gxs[TILE_CPT], gys[TILE_CPT];
-    bool inbox[TILE_CPT];
+    // Wall cells (x = 0, nx-1; y = 0, ny-1) are not processed in the main pass but in one extra pass in which
+    // thread t takes the t-th wall cell of the region (west column, east column, south row, north row; corners
+    // belong to the columns): in the linear cell order every wave of a wall tile holds a few wall cells and
+    // would execute the whole boundary rule four times per step.  Positions inside the region, -1 = this tile
+    // does not touch that wall; all workgroup-uniform.
+    int lxw = -1, lxe = -1, lys = -1, lyn = -1;
+    if (BC != LB_BC_PERIODIC) {
+        if (gx0 <= 0 && 0 < gx0 + TILE_L) lxw = -gx0;
+        if (gx0 <= a.nx - 1 && a.nx - 1 < gx0 + TILE_L) lxe = a.nx - 1 - gx0;
+        if (gy0 <= 0 && 0 < gy0 + TILE_LH) lys = -gy0;
+        if (gy0 <= a.ny - 1 && a.ny - 1 < gy0 + TILE_LH) lyn = a.ny - 1 - gy0;
+    }
+    const bool wall_tile = BC != LB_BC_PERIODIC && (lxw >= 0 || lxe >= 0 || lys >= 0 || lyn >= 0);
+
+    // my cells: linear index c = ly * TILE_L + lx, global (gx, gy) wrapped where the box is periodic; ring = how
+    // many steps the cell stays in the computed part of the region (-1: never -- padding lanes, wall cells)
+    int gxs[TILE_CPT], gys[TILE_CPT], ring[TILE_CPT];
+    bool mine[TILE_CPT];                                // mine to store: not a periodic image / inside the walled box
 #pragma unroll
     for (int i = 0; i < TILE_CPT; ++i) {
         const int c = tid + i * TILE_THREADS;
@@ -59,7 +74,10 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
             sx = min(max(gx, 0), a.nx - 1);
             sy = min(max(gy, 0), a.ny - 1);
         }
-        gxs[i] = gx; gys[i] = gy; inbox[i] = c < TILE_CELLS;
+        gxs[i] = gx; gys[i] = gy;
+        ring[i] = c < TILE_CELLS ? min(min(lx, TILE_L - 1 - lx), min(ly, TILE_LH - 1 - ly)) : -1;
+        if (BC != LB_BC_PERIODIC && (lx == lxw || lx == lxe || ly == lys || ly == lyn)) ring[i] = -1;
+        mine[i] = BC == LB_BC_PERIODIC ? (gx0 + lx == gx && gy0 + ly == gy) : (gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny);
         if (c < TILE_CELLS) {
             const long long o = (long long)sy * P + sx;
 #pragma unroll
@@ -69,19 +87,6 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
     }
     __syncthreads();
 
-    // Wall cells (x = 0, nx-1; y = 0, ny-1) are not processed in the main pass but in one extra pass in which
-    // thread t takes the t-th wall cell of the region (west column, east column, south row, north row; corners
-    // belong to the columns): in the linear cell order every wave of a wall tile holds a few wall cells and
-    // would execute the whole boundary rule four times per step.  Positions inside the region, -1 = this tile
-    // does not touch that wall; all workgroup-uniform.
-    int lxw = -1, lxe = -1, lys = -1, lyn = -1;
-    if (BC != LB_BC_PERIODIC) {
-        if (gx0 <= 0 && 0 < gx0 + TILE_L) lxw = -gx0;
-        if (gx0 <= a.nx - 1 && a.nx - 1 < gx0 + TILE_L) lxe = a.nx - 1 - gx0;
-        if (gy0 <= 0 && 0 < gy0 + TILE_LH) lys = -gy0;
-        if (gy0 <= a.ny - 1 && a.ny - 1 < gy0 + TILE_LH) lyn = a.ny - 1 - gy0;
-    }
-    const bool wall_tile = BC != LB_BC_PERIODIC && (lxw >= 0 || lxe >= 0 || lys >= 0 || lyn >= 0);
     // my wall cell (thread t: [0,LH) west column, [LH,2LH) east, [2LH,2LH+L) south row, [2LH+L,2LH+2L) north)
     int wlx = -1, wly = -1;
     if (wall_tile) {
@@ -97,6 +102,7 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         }
     }
     const int wc = wly * TILE_L + wlx;
+    const int wring = wlx < 0 ? -1 : min(min(wlx, TILE_L - 1 - wlx), min(wly, TILE_LH - 1 - wly));
 
     // pull (+ boundary rule) + obstacle swap + relaxation of region cell c at global (gx, gy); in the last step
     // the result goes to global memory (the cells still computed then are exactly the tile)
@@ -140,19 +146,12 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
 #pragma unroll
         for (int i = 0; i < TILE_CPT; ++i) {
             const int c = tid + i * TILE_THREADS;
-            const int lx = c % TILE_L, ly = c / TILE_L;
-            act[i] = inbox[i] && lx >= s && lx < TILE_L - s && ly >= s && ly < TILE_LH - s;
-            if (BC != LB_BC_PERIODIC) act[i] = act[i] && lx != lxw && lx != lxe && ly != lys && ly != lyn;
-            if (act[i]) {
-                // not a periodic image of another tile's cell / inside the walled box
-                const bool mine = BC == LB_BC_PERIODIC ? (gx0 + lx == gxs[i] && gy0 + ly == gys[i])
-                                                       : (gxs[i] >= 0 && gxs[i] < a.nx && gys[i] >= 0 && gys[i] < a.ny);
-                cell_step(c, gxs[i], gys[i], std::false_type(), last, mine, cs[i]);
-            }
+            act[i] = ring[i] >= s;
+            if (act[i]) cell_step(c, gxs[i], gys[i], std::false_type(), last, mine[i], cs[i]);
         }
         // ---- wall pass ------------------------------------------------------------------------------------------
         if (wall_tile) {
-            wact = wlx >= s && wlx < TILE_L - s && wly >= s && wly < TILE_LH - s;
+            wact = wring >= s;
             if (wact) cell_step(wc, gx0 + wlx, gy0 + wly, std::true_type(), last, true, wq);
         }
         if (last) break;
