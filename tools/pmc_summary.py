@@ -34,9 +34,20 @@ def short(name):
 def main():
     src, tag, side = sys.argv[1], sys.argv[2], int(sys.argv[3])
     kt = rows_of(os.path.join(src, "kt", "**", "*_kernel_trace.csv"))
-    dur = {}
+    # Launches of one marching kernel differ in geometry while lb_autotune samples its candidates (8 or 4 waves
+    # per CU): the table keeps them apart by grid size, "name" alone = the geometry with the most launches, i.e.
+    # the one the timed region runs.
+    by_geo = {}
     for r in kt:
-        dur.setdefault(short(r["Kernel_Name"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        by_geo.setdefault(short(r["Kernel_Name"]), {}).setdefault(r.get("Grid_Size_X", r.get("Grid_Size", "?")), []).append(
+            int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    dur = {}
+    for k, geos in by_geo.items():
+        main = max(geos, key=lambda g: len(geos[g]))
+        dur[k] = geos[main]
+        for g, v in geos.items():
+            if g != main:
+                dur["%s [other geometry: grid %s]" % (k, g)] = v
     vg = {short(r["Kernel_Name"]): (r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"]) for r in kt}
     pmc = {}
     for which, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -51,10 +62,21 @@ def main():
              "| kernel | calls | avg us | min us | max us | VGPR | SGPR | scratch | LDS |", "|---|---|---|---|---|---|---|---|---|"]
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         lines.append("| %s | %d | %.1f | %.1f | %.1f | %s | %s | %s | %s |" % (
-            k, len(v), st.mean(v) / 1e3, min(v) / 1e3, max(v) / 1e3, *vg[k]))
+            k, len(v), st.mean(v) / 1e3, min(v) / 1e3, max(v) / 1e3, *vg[k.split(" [")[0]]))
+
+    # the bench line of the same (kernel-trace) run: its HIP-event launch time must agree with the table
+    try:
+        import re
+        log = open(os.path.join(src, "kt.log")).read()
+        m_l, m_v, m_k = re.search(r'"launch_ms": ([0-9.]+)', log), re.search(r'"value": ([0-9.]+)', log), re.search(r'"kernel": "(k_step\d?)', log)
+        if m_l and m_v:
+            lines += ["", "bench.py inside this run (HIP events over the timed region): %s MLUPS, launch_ms %s of %s."
+                      % (m_v.group(1), m_l.group(1), m_k.group(1) if m_k else "the hot kernel")]
+    except OSError:
+        pass
 
     # calibration on the copy kernel (bytes known: lattice allocation read once, written once)
-    copy_bytes = (9 * (side + 2) * ((side + 63) // 64 * 64) + 128) * 4
+    copy_bytes = (9 * (side + 16) * ((side + 63) // 64 * 64) + 1024) * 4      # 8 ghost rows per side, 2 x 512 guard floats
     copy_fetch = st.mean(pmc[("k_copy4<false>", "FETCH_SIZE")]) * 1024
     copy_write = st.mean(pmc[("k_copy4<false>", "WRITE_SIZE")]) * 1024
     fetch_corr = copy_bytes / copy_fetch
