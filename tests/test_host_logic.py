@@ -140,6 +140,32 @@ def test_partition_rows_and_neighbours():
     assert neighbours(1, 2, True) == (0, 0)
 
 
+def test_mask_halo_rows_of_a_slab_match_the_header():
+    """The obstacle-mask rows a slab keeps of its neighbours: LB_MASK_HALO_ROWS of them per side (the halo cycle
+    recomputes four of the neighbour's rows and reads the mask three rows beyond), nearest last below / nearest
+    first above, wrapped in a periodic box, absent at a wall, empty outside a walled box."""
+    import re
+    from LB_D2Q9 import _native
+    from LB_D2Q9.slabs import MASK_HALO_ROWS, _SlabSet
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lb_hip.h")).read()
+    assert MASK_HALO_ROWS == _native.LB_MASK_HALO_ROWS == int(re.search(r"#define LB_MASK_HALO_ROWS (\d+)", hdr).group(1))
+    d, nx, ny = MASK_HALO_ROWS, 5, 40
+    mask = np.zeros((nx, ny), bool)
+    mask[2, :] = np.arange(ny) % 3 == 0                        # row y is solid at x=2 iff y % 3 == 0
+    rows = lambda ys: np.array([[(y % ny) % 3 == 0 if x == 2 else False for x in range(nx)] for y in ys])
+    south, north = _SlabSet._mask_halo_rows(mask, 10, 12, ny, False)
+    assert south.shape == north.shape == (d, nx)
+    assert np.array_equal(south, rows(range(10 - d, 10))) and np.array_equal(north, rows(range(22, 22 + d)))
+    south, north = _SlabSet._mask_halo_rows(mask, 0, 12, ny, False)          # bottom slab of a walled box
+    assert south is None and np.array_equal(north, rows(range(12, 12 + d)))
+    south, north = _SlabSet._mask_halo_rows(mask, 0, 12, ny, True)           # periodic: wraps to the top rows
+    assert np.array_equal(south, rows(range(ny - d, ny)))
+    south, north = _SlabSet._mask_halo_rows(mask, ny - 4, 4, ny, True)
+    assert np.array_equal(north, rows(range(0, d)))
+    south, north = _SlabSet._mask_halo_rows(mask, ny - 12, 9, ny, False)     # 3 rows below the top wall: the rest is empty
+    assert north[:3].any() == rows(range(ny - 3, ny)).any() and not north[3:].any()
+
+
 # ---- headless frame dumper (reference: field_visualizer.py:146-161) -------------------------------------------
 class _FakeSim(object):
     """run()/get_fields() provider without a GPU: a rigid rotation whose angle grows with the step count."""
