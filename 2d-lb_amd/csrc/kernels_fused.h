@@ -291,8 +291,8 @@ __device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int r
 }
 
 // Segment i of a launch covers output rows [row_begin + i*seg_stride, +seg_rows) clipped to row_end:
-// one contiguous range cut into equal shares (seg_stride == seg_rows), or the two 2-row edge bands
-// of a slab (seg_stride = H-2) that are computed first so their halo can travel early.
+// one contiguous range cut into equal shares (seg_stride == seg_rows), or the two edge bands of a slab
+// (seg_stride = their distance) that are computed first so their halo can travel early.
 template <int BC, bool MASK, bool MACRO, bool NTS>
 __global__ __launch_bounds__(256, 2) void k_step2(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void k_step2(const StepArgs a, int strips, 
 // step 1 of row r (from memory), step 2 of row r-1 (from window 1), step 3 of row r-2 (from window 2,
 // stored).  The edge lanes now recompute two cells beyond the strip for step 1 (x0-2, x0-1 |
 // x0+256, x0+257) and one for step 2 (x0-1 | x0+256), all as scalar cells with the same arithmetic.
-// Whole-grid handles only (a slab would need a 3-deep halo).  ~25 B of HBM traffic per lattice update.
+// On slabs it reads the neighbours' rows from the ghost zone (lb_run's halo cycle).  ~25 B of HBM traffic per
+// lattice update.
 
 // Post-collision links of one halo cell that later stages can ask for: the centre links (cx = 0) and
 // the three links that point toward the strip (cx = +1 on the left side, -1 on the right side),
