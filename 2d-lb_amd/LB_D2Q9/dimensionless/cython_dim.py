@@ -8,9 +8,10 @@ moment overrides).  The reference's two paths are different discretisations (the
 and drift ~1 % apart at walls over 1000 steps), so users of the CPU classes get THIS module
 and users of the OpenCL class get ``hip_dim`` / ``opencl_dim``.
 
-It is a compatibility path: one kernel per phase (~15x slower than the fused OpenCL-path kernels, three
-orders of magnitude faster than the reference's own CPU loop), fp32 throughout where the reference
-keeps ``u, v`` and the equilibrium temporaries in float64 (differences <= 1e-6 per step, tests).
+It is a compatibility path: the phase methods launch one kernel per phase, ``run(n)`` a boundary kernel plus ONE fused
+kernel per step (bitwise equal to the five phase calls; ~3x slower than the fused OpenCL-path kernels, four orders of
+magnitude faster than the reference's own CPU loop), fp32 throughout where the reference keeps ``u, v`` and the
+equilibrium temporaries in float64 (differences <= 1e-6 per step, tests).
 
 Differences a caller can see: ``self.f``, ``self.rho`` ... are ``DeviceField`` objects (``.get()`` or
 ``np.asarray(...)`` give host copies) instead of live numpy arrays - assign state through

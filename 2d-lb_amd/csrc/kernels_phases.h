@@ -68,6 +68,13 @@ __global__ void k_hydro(const PhaseArgs a)   // D2Q9.cl:67-100
     a.v[o] = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
 }
 
+// equilibrium of link k (one expression, shared by k_feq and the fused Cython-path step so that both round alike)
+__device__ __forceinline__ float feq_link(int k, float rho, float ux, float uy, float usq)
+{
+    const float cu = d_cx[k] * ux + d_cy[k] * uy;
+    return d_w[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
+}
+
 __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -76,10 +83,7 @@ __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
     const float rho = a.rho[o], ux = a.u[o], uy = a.v[o];
     const float usq = ux * ux + uy * uy;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const float cu = d_cx[k] * ux + d_cy[k] * uy;
-        a.feq[k * a.plane + o] = d_w[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
-    }
+    for (int k = 0; k < 9; ++k) a.feq[k * a.plane + o] = feq_link(k, rho, ux, uy, usq);
 }
 
 __global__ void k_collide(const PhaseArgs a) // D2Q9.cl:102-121
@@ -168,8 +172,9 @@ __global__ void k_hydro_vel(const PhaseArgs a)
 // boundary rules BEFORE streaming and fed by the stored inlet/outlet velocity of the previous step, plain
 // bounce-back walls, an in-place streaming whose loop bounds leave four tangential links unmoved on one
 // wall row/column each, and overrides in the moment update.  These three kernels restate it phase by
-// phase (one thread per cell, un-fused: a compatibility path, ~15x slower than the fused OpenCL-path
-// kernels and ~2000x faster than the reference's CPU loop); k_feq and k_collide are shared.
+// phase (one thread per cell); k_feq and k_collide are shared.  lb_run fuses all but the boundary phase into
+// k1_step below: a compatibility path, ~3x slower than the fused OpenCL-path kernels and four orders of
+// magnitude faster than the reference's CPU loop.
 // x = i (0..lx), y = j (0..ly) in the .pyx's notation.
 
 // cython_dim.pyx:204-269 `move_bcs` (+ :468-513 obstacle swap), in place
@@ -237,20 +242,16 @@ __global__ void k1_move(const PhaseArgs a)
     a.fs[k * a.plane + (long long)y * a.pitch + x] = a.f[k * a.plane + (long long)sy * a.pitch + sx];
 }
 
-// cython_dim.pyx:302-333 `update_hydro` (+ :459-466 obstacle zeroing)
-__global__ void k1_hydro(const PhaseArgs a)
+// cython_dim.pyx:302-333 `update_hydro` (+ :459-466 obstacle zeroing) of one cell
+__device__ __forceinline__ void c1_moments(const PhaseArgs &a, int x, int y, bool solid, float f0, float f1, float f2,
+                                           float f3, float f4, float f5, float f6, float f7, float f8, float &rho,
+                                           float &ux, float &uy)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
     const int lx = a.nx - 1, ly = a.ny - 1;
-    const long long o = (long long)y * a.pitch + x, S = a.plane;
-    const float *f = a.f + o;
-    const float f0 = f[0], f1 = f[S], f2 = f[2 * S], f3 = f[3 * S], f4 = f[4 * S], f5 = f[5 * S], f6 = f[6 * S],
-                f7 = f[7 * S], f8 = f[8 * S];
-    float rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
+    rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
     const float inv = 1.0f / rho;
-    float ux = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
-    float uy = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
+    ux = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
+    uy = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
     if (y == 0 || y == ly) { ux = 0.f; uy = 0.f; }              // walls
     if (x == 0) {                                                // pressure inlet: rho pinned, u from the knowns
         rho = a.rho_in;
@@ -260,8 +261,50 @@ __global__ void k1_hydro(const PhaseArgs a)
         rho = a.rho_out;
         ux = -1.f + ((f0 + f2 + f4) + 2.f * (f1 + f5 + f8)) / a.rho_out;
     }
-    if (a.mask && a.mask[o]) { ux = 0.f; uy = 0.f; }
+    if (solid) { ux = 0.f; uy = 0.f; }
+}
+
+__global__ void k1_hydro(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    const float *f = a.f + o;
+    float rho, ux, uy;
+    c1_moments(a, x, y, a.mask && a.mask[o], f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S],
+               f[8 * S], rho, ux, uy);
     a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+}
+
+// One Cython-path time step after its boundary phase, fused: the restricted pull of k1_move, the moments of
+// k1_hydro, the equilibrium of k_feq and the relaxation of k_collide for one cell, from lattice a.f (already through
+// k1_bcs) into lattice a.fs -- the same expressions, hence the same bits as the five un-fused launches, at a
+// fifth of their traffic.  rho, u, v are stored every step (the next boundary phase reads the stored u).
+__global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    const long long o = (long long)y * a.pitch + x, S = a.plane, P = a.pitch;
+    const bool up = (y >= 1), dn = (y <= ly - 1), le = (x >= 1), ri = (x <= lx - 1);
+    // k: moved (cython_dim.pyx:271-299)                    source when moved
+    const float f0 = a.f[o];
+    const float f1 = a.f[1 * S + ((up && le) ? o - 1 : o)];              // 1,5: j >= 1, i >= 1
+    const float f5 = a.f[5 * S + ((up && le) ? o - P - 1 : o)];
+    const float f2 = a.f[2 * S + ((up && ri) ? o - P : o)];              // 2,6: j >= 1, i <= lx-1
+    const float f6 = a.f[6 * S + ((up && ri) ? o - P + 1 : o)];
+    const float f4 = a.f[4 * S + ((dn && le) ? o + P : o)];              // 4,8: j <= ly-1, i >= 1
+    const float f8 = a.f[8 * S + ((dn && le) ? o + P - 1 : o)];
+    const float f3 = a.f[3 * S + ((dn && ri) ? o + 1 : o)];              // 3,7: j <= ly-1, i <= lx-1
+    const float f7 = a.f[7 * S + ((dn && ri) ? o + P + 1 : o)];
+    float rho, ux, uy;
+    c1_moments(a, x, y, a.mask && a.mask[o], f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
+    a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+    const float usq = ux * ux + uy * uy;
+    const float fk[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        a.fs[k * S + o] = fk[k] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
 }
 
 // Halo pack / unpack: the halo of one edge is 18 (3 rows deep), 45 (6 deep) or 63 (8 deep) row segments scattered

@@ -1297,12 +1297,16 @@ int lb_run(lb_sim *s, int n_steps)
         return LB_OK;
     }
     if (s->p.semantics == LB_SEM_CYTHON) {
-        // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles
+        // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles -- the boundary phase
+        // in place (k1_bcs), the other four fused into one pass from the current lattice into the other (k1_step);
+        // bitwise equal to the five phase calls (test_cython_path_fused_run_equals_phase_calls)
         for (int it = 0; it < n_steps; ++it) {
-            if ((rc = lb_move_bcs(s)) || (rc = lb_move(s)) || (rc = lb_update_hydro(s)) || (rc = lb_update_feq(s)) ||
-                (rc = lb_collide_particles(s)))
-                return rc;
+            hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+            hipLaunchKernelGGL(k1_step, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+            HIP_TRY(hipGetLastError());
+            s->cur ^= 1;
         }
+        if (n_steps) s->feq_valid = false;
         return LB_OK;
     }
     if (!s->multi_slab()) {

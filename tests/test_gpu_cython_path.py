@@ -95,3 +95,30 @@ def test_cython_semantics_restrictions(lbhip):
         Simulation(64, 64, 1.0, bc="periodic", semantics="cython")
     with pytest.raises(_native.LbError):
         Simulation(64, 64, 1.0, bc="pipe", semantics="cython", y0=0, local_ny=32)
+
+
+def test_cython_path_fused_run_equals_phase_calls(lbhip):
+    """run(n) on the Cython-path classes = boundary phase + ONE fused pass (restricted pull, moments, equilibrium,
+    relaxation) per step; it must equal the five phase calls of the reference's loop (cython_dim.pyx:346-359) bit
+    for bit, with and without an obstacle, on sizes that are not multiples of the launch shape."""
+    from LB_D2Q9.dimensionless import cython_dim as lb
+    for cls, extra in ((lb.Pipe_Flow, {}), (lb.Pipe_Flow_Cylinder, dict(cylinder_center=[.6, .5], cylinder_radius=.12))):
+        kw = dict(diameter=1., rho=1., viscosity=.2, pressure_grad=-1.5, pipe_length=2.7, N=37, time_prefactor=.2,
+                  verbose=False)
+        if extra:
+            kw.update(N=90)                          # N counts lattice points per cylinder radius there
+        kw.update(extra)
+        np.random.seed(3)
+        a = cls(**kw)
+        f0 = a.get_fields()["f"]
+        b = cls(**kw)
+        b.set_f(f0)
+        g0 = a.get_fields()
+        b.set_fields(g0["rho"], g0["u"], g0["v"])
+        a.run(23)
+        for _ in range(23):
+            b.move_bcs(); b.move(); b.update_hydro(); b.update_feq(); b.collide_particles()
+        ga, gb = a.get_fields(), b.get_fields()
+        for k in ("f", "rho", "u", "v", "feq"):
+            assert np.array_equal(ga[k], gb[k]), (cls.__name__, k)
+        assert np.all(np.isfinite(ga["f"]))

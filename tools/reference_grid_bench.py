@@ -3,7 +3,7 @@
 len=3, N=125, cylinder r=0.1 at (.75,.5)) = 3751 x 1251 = 4.693e6 cells, as timed in
 docs/python_cython_opencl_comparison.ipynb (:136, 233, 271-273: OpenCL 317.5 MLUPS / 1000 steps on a GTX
 Titan Black; :404-406: Cython 5.9 MLUPS / 20 steps).  Runs both drop-in classes (OpenCL-path semantics =
-fused kernels; Cython-path semantics = un-fused compatibility kernels) and prints MLUPS the way the
+fused kernels; Cython-path semantics = boundary phase + one fused pass per step) and prints MLUPS the way the
 notebook computes it (wall clock around run(), nx*ny*steps/t/1e6)."""
 import os
 import sys
@@ -18,7 +18,7 @@ def main():
     kw = dict(diameter=1., rho=1., viscosity=1., pressure_grad=-10., pipe_length=3., N=125,
               cylinder_center=[.75, .5], cylinder_radius=.1, verbose=False)
     for name, mod, steps in (("opencl_dim (fused HIP kernels)", opencl_dim, 1000),
-                             ("cython_dim (Cython-path semantics, un-fused HIP kernels)", cython_dim, 200)):
+                             ("cython_dim (Cython-path semantics, bcs + one fused pass)   ", cython_dim, 200)):
         sim = mod.Pipe_Flow_Cylinder(**kw)
         sim.run(130)                             # long enough for the engine to pick its kernel configuration
         best = 0.0
