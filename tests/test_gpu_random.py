@@ -1,6 +1,8 @@
 """Randomised GPU parity sweep: random grid shapes (including tiny, odd, non-multiple-of-4 and
 strip-boundary widths), boundary families, masks, kernel variants and step counts.  Every variant must
 equal the single-step kernel bit for bit and match the oracle within the fp32 tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,20 +10,21 @@ from test_gpu_parity import assert_fields_close, _random_state
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = (1, 9, 16, 24, 33, 41, 97, 105)        # NT / tile shapes / XCD order / two-step / three-step combinations
+# NT / tile shapes / XCD order / two-, three-, four-step marching kernels / LDS-tile kernel / the automatic choice
+VARIANTS = (1, 9, 16, 24, 33, 41, 97, 105, 97 | 256, 105 | 256, 512, 512 | 1, -1)
 WIDTHS = (2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 600, 768, 1021, 1024, 1028, 1280)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LB_RANDOM_SEEDS", "36"))))   # more for a soak
 def test_random_configuration(lbhip, oracle, seed):
     from LB_D2Q9.simulation import Simulation
     rng = np.random.default_rng(1000 + seed)
     bc = ("pipe", "periodic", "cavity")[seed % 3]
     nx = int(rng.choice(WIDTHS))
-    ny = int(rng.choice((2, 3, 7, 33, 64, 129, 130, 200, 257)))
+    ny = int(rng.choice((2, 3, 7, 33, 64, 129, 130, 200, 257, 300)))
     if bc == "periodic" and nx % 4 and nx >= 512:
         nx += 4 - nx % 4                                   # the marching kernels need nx % 4 == 0 when periodic
-    steps = int(rng.integers(1, 8))
+    steps = int(rng.integers(1, 14))
     omega = float(rng.uniform(0.6, 1.8))
     masked = bool(rng.integers(0, 2)) and nx > 4 and ny > 4
     mask = None
@@ -36,7 +39,7 @@ def test_random_configuration(lbhip, oracle, seed):
     base.set_f(f0)
     base.run(steps)
     want = base.get_fields(("f", "rho", "u", "v"))
-    for variant in rng.choice(VARIANTS, size=3, replace=False):
+    for variant in rng.choice(VARIANTS, size=4, replace=False):
         s = Simulation(nx, ny, omega, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(int(variant))
         s.set_f(f0)
