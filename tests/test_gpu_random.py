@@ -53,3 +53,40 @@ def test_random_configuration(lbhip, oracle, seed):
     o.set_f(f0)
     o.run(steps)
     assert_fields_close(want, o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LB_RANDOM_SLAB_SEEDS", "12"))))
+def test_random_slab_partition(lbhip, seed):
+    """Random row-slab partitions run through the in-library multi-GPU schedule (lb_run_group: halo cycles of two
+    four- or three-step launches, launch-by-launch remainders, walls with bands of unequal height, masks) must
+    equal the undivided run bit for bit."""
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.slabs import LocalSlabRing
+    rng = np.random.default_rng(5000 + seed)
+    bc = ("periodic", "pipe", "cavity")[seed % 3]
+    nx = int(rng.choice((512, 516, 768, 1000, 1024, 1284)))
+    nslabs = int(rng.integers(2, 6))
+    ny = int(rng.integers(nslabs * 7, 700))                  # slab heights from 7 rows (no fused kernel) to 350
+    variant = int(rng.choice((-1, 97 | 256, 97, 97 | 128, 33, 1)))
+    mask = None
+    if rng.integers(0, 2):
+        mask = rng.random((nx, ny)) < 0.03
+        mask[0, :] = mask[-1, :] = False
+        if bc != "periodic":
+            mask[:, 0] = mask[:, -1] = False
+    kw = dict(inlet_rho=1.005, lid_u=0.05)
+    f0 = _random_state(rng, nx, ny)
+    one = Simulation(nx, ny, 1.5, bc=bc, obstacle_mask=mask, **kw)
+    one.set_variant(0)
+    one.set_f(f0)
+    ring = LocalSlabRing(nx, ny, 1.5, nslabs, bc=bc, obstacle_mask=mask, **kw)
+    ring.set_variant(variant)
+    ring.set_f(f0)
+    total = 0
+    for n in rng.integers(1, 30, size=3):
+        ring.run_in_library(int(n))
+        total += int(n)
+    one.run(total)
+    a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (bc, nx, ny, nslabs, variant, total, k)
