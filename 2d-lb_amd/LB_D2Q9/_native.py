@@ -15,7 +15,7 @@ LB_SEM_OPENCL, LB_SEM_CYTHON = 0, 1
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
             "velocity_inlet": LB_BC_VELOCITY_INLET}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/lb_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -25,7 +25,8 @@ EXPORTS = (
     "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_run",
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group",
-    "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
+    "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
+    "lb_autotune_quick", "lb_hot_kernel",
 )
 
 
@@ -81,6 +82,8 @@ def lib():
     L.lb_layout.argtypes = [h, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64)]
     L.lb_set_variant.argtypes = [h, I]
     L.lb_copy_calibration.argtypes = [h, I, ct.POINTER(ct.c_int64)]
+    L.lb_autotune_quick.argtypes = [h, I]
+    L.lb_hot_kernel.argtypes = [h, ct.c_char_p, I]
     if L.lb_abi_version() != ABI_VERSION:
         raise LbError("liblbhip.so ABI %d != binding ABI %d: rebuild" % (L.lb_abi_version(), ABI_VERSION))
     _lib = L

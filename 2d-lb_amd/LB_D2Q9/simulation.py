@@ -184,9 +184,17 @@ class Simulation(object):
 
     # -- the hot path --------------------------------------------------------
     def run(self, num_iterations, wait=True):
-        """num_iterations fused time steps (one HIP launch each).  The reference returns with the
-        work complete (it waits after every kernel); pass wait=False to only enqueue."""
-        check(self._lib.lb_run(self._h, int(num_iterations)))
+        """num_iterations fused time steps.  The reference returns with the work complete (it waits after
+        every kernel); pass wait=False to only enqueue (never blocks the host).  A blocking run long enough to
+        pay for it first times the candidate kernel configurations on its own first steps (lb_autotune_quick:
+        they are bitwise equivalent, the trajectory is unchanged) and keeps the fastest for this grid."""
+        n = int(num_iterations)
+        if wait and n > 0:
+            used = self._lib.lb_autotune_quick(self._h, n - 7)
+            if used < 0:
+                check(used)
+            n -= used
+        check(self._lib.lb_run(self._h, n))
         if wait:
             self.sync()
 
@@ -228,39 +236,71 @@ class Simulation(object):
         return out
 
     # -- state I/O (the reference has none: state only leaves through get_fields) --------------
-    def save_checkpoint(self, path):
-        """Write everything needed to continue this run bit for bit: populations, the macroscopic
-        fields of the last step, the obstacle mask and the lattice parameters (.npz)."""
+    CHECKPOINT_VERSION = 2
+    _CKPT_SCALARS = ("nx", "ny", "y0", "local_ny", "bc_mode", "omega", "inlet_rho", "outlet_rho", "lid_u", "rho0",
+                     "inlet_u", "outlet_u")
+
+    @staticmethod
+    def _ckpt_path(path):
+        """np.savez appends '.npz' to a bare path; np.load does not: use one spelling for both."""
+        path = str(path)
+        return path if path.endswith(".npz") else path + ".npz"
+
+    def checkpoint_arrays(self):
+        """Everything needed to continue this run bit for bit, as a dict of arrays: populations, the macroscopic
+        fields of the last step, the obstacle mask, every lattice parameter of the handle (boundary family,
+        semantics, imposed speeds, halo flag) and a format version."""
         g = self.get_fields(("f", "rho", "u", "v"))
-        np.savez(path, f=g["f"], rho=g["rho"], u=g["u"], v=g["v"],
+        d = dict(f=g["f"], rho=g["rho"], u=g["u"], v=g["v"],
                  mask=(self._mask_host if self._mask_host is not None else np.zeros((0, 0), np.int32)),
-                 nx=self.nx, ny=self.ny, y0=self.y0, local_ny=self.local_ny, bc_mode=self.bc_mode,
-                 omega=self.omega, inlet_rho=self.inlet_rho, outlet_rho=self.outlet_rho,
-                 lid_u=self.lid_u, rho0=self.rho0)
+                 version=self.CHECKPOINT_VERSION, semantics=np.array(self.semantics), halo=int(self._halo))
+        for k in self._CKPT_SCALARS:
+            d[k] = getattr(self, k)
+        return d
+
+    def save_checkpoint(self, path):
+        """Write checkpoint_arrays() to `path` (.npz appended when missing)."""
+        np.savez(self._ckpt_path(path), **self.checkpoint_arrays())
+
+    def _check_compatible(self, d):
+        if int(d["version"]) != self.CHECKPOINT_VERSION:
+            raise ValueError("checkpoint format %d, this build reads %d" % (int(d["version"]), self.CHECKPOINT_VERSION))
+        if (int(d["nx"]), int(d["ny"]), int(d["y0"]), int(d["local_ny"])) != (self.nx, self.ny, self.y0, self.local_ny):
+            raise ValueError("checkpoint is for a %dx%d lattice (slab %d+%d), this one is %dx%d (slab %d+%d)"
+                             % (int(d["nx"]), int(d["ny"]), int(d["y0"]), int(d["local_ny"]),
+                                self.nx, self.ny, self.y0, self.local_ny))
+        if int(d["bc_mode"]) != self.bc_mode:
+            raise ValueError("checkpoint was written with a different boundary family")
+        if str(d["semantics"]) != self.semantics:
+            raise ValueError("checkpoint was written with semantics=%r, this lattice has %r" % (str(d["semantics"]), self.semantics))
+        for k in ("omega", "inlet_rho", "outlet_rho", "lid_u", "rho0", "inlet_u", "outlet_u"):
+            if np.float32(d[k]) != np.float32(getattr(self, k)):
+                raise ValueError("checkpoint has %s = %r, this lattice %r" % (k, float(d[k]), getattr(self, k)))
 
     def load_checkpoint(self, path):
-        """Restore a state written by save_checkpoint into this (same-shaped) lattice."""
-        with np.load(path) as d:
-            if (int(d["nx"]), int(d["ny"]), int(d["y0"]), int(d["local_ny"])) != (self.nx, self.ny, self.y0, self.local_ny):
-                raise ValueError("checkpoint is for a %dx%d lattice (slab %d+%d), this one is %dx%d (slab %d+%d)"
-                                 % (int(d["nx"]), int(d["ny"]), int(d["y0"]), int(d["local_ny"]),
-                                    self.nx, self.ny, self.y0, self.local_ny))
-            if int(d["bc_mode"]) != self.bc_mode:
-                raise ValueError("checkpoint was written with a different boundary family")
-            if d["mask"].size:
-                self.set_obstacle_mask(d["mask"])
-            self.set_fields(d["rho"], d["u"], d["v"])
-            self.set_f(d["f"])
+        """Restore a state written by save_checkpoint into this lattice; every parameter must match
+        (a different omega or boundary family would silently change the physics)."""
+        with np.load(self._ckpt_path(path)) as d:
+            self.restore_arrays(d)
+
+    def restore_arrays(self, d):
+        self._check_compatible(d)
+        self.set_obstacle_mask(d["mask"] if d["mask"].size else None)
+        self.set_fields(d["rho"], d["u"], d["v"])
+        self.set_f(d["f"])
 
     @classmethod
     def from_checkpoint(cls, path, device=0):
         """Build a new Simulation from a checkpoint file."""
-        with np.load(path) as d:
+        with np.load(cls._ckpt_path(path)) as d:
+            if int(d["version"]) != cls.CHECKPOINT_VERSION:
+                raise ValueError("checkpoint format %d, this build reads %d" % (int(d["version"]), cls.CHECKPOINT_VERSION))
             sim = cls(int(d["nx"]), int(d["ny"]), float(d["omega"]), bc=int(d["bc_mode"]),
                       inlet_rho=float(d["inlet_rho"]), outlet_rho=float(d["outlet_rho"]), lid_u=float(d["lid_u"]),
                       rho0=float(d["rho0"]), device=device, y0=int(d["y0"]), local_ny=int(d["local_ny"]),
-                      halo=int(d["local_ny"]) != int(d["ny"]))
-        sim.load_checkpoint(path)
+                      halo=bool(int(d["halo"])), semantics=str(d["semantics"]),
+                      inlet_u=float(d["inlet_u"]), outlet_u=float(d["outlet_u"]))
+            sim.restore_arrays(d)
         return sim
 
     # -- row-slab stepping (driven by LB_D2Q9.slabs) -------------------------------
@@ -282,8 +322,9 @@ class Simulation(object):
     MASK_HALO_ROWS = _native.LB_MASK_HALO_ROWS
 
     def set_obstacle_mask_halo(self, south_rows=None, north_rows=None):
-        """Mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-5 .. y0-1,
-        north_rows = rows y0+H .. y0+H+4, each (MASK_HALO_ROWS, nx), non-zero = solid; None = no solid cells."""
+        """Mask rows of the neighbouring slabs next to this one: south_rows = global rows y0-MASK_HALO_ROWS .. y0-1
+        (nearest last), north_rows = rows y0+H .. y0+H+MASK_HALO_ROWS-1 (nearest first), each (MASK_HALO_ROWS, nx),
+        non-zero = solid; None = no solid cells."""
         rows = []
         for r in (south_rows, north_rows):
             if r is not None and np.asarray(r).shape != (self.MASK_HALO_ROWS, self.nx):
@@ -331,8 +372,14 @@ class Simulation(object):
             check(n)
         return n
 
+    def hot_kernel(self):
+        """Name of the kernel run() spends its time in for this grid / variant / tuning (lb_hot_kernel)."""
+        buf = ct.create_string_buffer(160)
+        check(self._lib.lb_hot_kernel(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def steps_per_launch(self):
-        """2 when run() uses the two-steps-per-pass kernel for this grid/variant, else 1."""
+        """Time steps one launch of run()'s hot kernel advances for this grid / variant / tuning: 4, 3, 2 or 1."""
         n = self._lib.lb_steps_per_launch(self._h)
         if n < 0:
             check(n)

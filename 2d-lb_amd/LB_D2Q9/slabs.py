@@ -185,6 +185,10 @@ class DistributedSlab(_SlabSet):
 
     # -- RCCL inside the engine ------------------------------------------------------------------
     def _attach_rccl(self):
+        """Collective.  A rank that cannot set RCCL up must not leave its peers blocked in a broadcast or inside
+        ncclCommInitRank, so every stage ends in an agreement over torch.distributed before the next one starts:
+        (1) librccl loads everywhere, (2) rank 0 made a unique id (a flag byte travels with it), (3) every rank's
+        lb_comm_init returned.  On failure EVERY rank raises LbError (bench.py then falls back to transport='torch')."""
         import torch
         from .simulation import comm_unique_id
         dist = self._dist
@@ -192,12 +196,36 @@ class DistributedSlab(_SlabSet):
         dev = torch.device("cuda", self.engine.device) if on_gpu else torch.device("cpu")
         if on_gpu:
             torch.cuda.set_device(dev)
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(int(t[0]))
+
+        err = None
+        try:
+            _native.check(_native.lib().lb_comm_available())
+        except _native.LbError as exc:
+            err = exc
+        if not all_ok(err is None):
+            raise _native.LbError("RCCL cannot be loaded on every rank (%s)" % (err or "a peer failed"))
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)              # [128] = 1: the id is valid
         if self.rank == 0:
-            uid = torch.tensor(list(comm_unique_id()), dtype=torch.uint8, device=dev)
+            try:
+                uid = torch.tensor(list(comm_unique_id()) + [1], dtype=torch.uint8, device=dev)
+            except _native.LbError as exc:
+                err = exc
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast(uid, src=src, group=self.group)
-        self.engine.comm_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.nranks)
+        uid = uid.cpu().numpy()
+        if not uid[128]:
+            raise _native.LbError("rank 0 could not create an RCCL unique id (%s)" % (err or "see rank 0"))
+        try:
+            self.engine.comm_init(uid[:128].tobytes(), self.rank, self.nranks)
+        except _native.LbError as exc:
+            err = exc
+        if not all_ok(err is None):
+            raise _native.LbError("lb_comm_init failed on a rank (%s)" % (err or "a peer failed"))
 
     # -- torch.distributed driven exchange ----------------------------------------------------------
     def _torch_buffers(self):

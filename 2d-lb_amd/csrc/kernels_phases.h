@@ -102,42 +102,56 @@ __global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
     if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
 }
 
-// D2Q9.cl:263-321 `move_bcs_PeriodicBC_VelocityInlet` (+ the obstacle swap of the OLD obstacle subclass).
-// The north / south rows copy three links from the opposite wall row: planes no thread of this launch
-// writes on that row, so the in-place update is race-free, as in the reference.
+// D2Q9.cl:263-321 `move_bcs_PeriodicBC_VelocityInlet`, in place like the reference: every thread stores only the
+// planes its rule sets.  The north row reads planes 4,7,8 of row 0 and the south row planes 2,5,6 of row ny-1 --
+// planes this launch never writes on those rows (row 0 stores 2,5,6 [+1,5,8 / 3,6,7 never: the inlet / outlet rules
+// skip the wall rows], row ny-1 stores 4,7,8) -- so the launch is race-free.  The obstacle swap is a second launch
+// (k_bounce), as in the reference, where `bounceback_in_obstacle` runs after `move_bcs` (OLD obstacle subclass).
 __global__ void k_bcs_vel(const PhaseArgs a)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
+    if (!(x == 0 || x == a.nx - 1 || y == 0 || y == a.ny - 1)) return;
     const long long o = (long long)y * a.pitch + x, S = a.plane;
     float *f = a.f + o;
-    const bool solid = a.mask && a.mask[o];
-    if (!(x == 0 || x == a.nx - 1 || y == 0 || y == a.ny - 1 || solid)) return;
-    Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
+    const float f0 = f[0], f1 = f[S], f2 = f[2 * S], f3 = f[3 * S], f4 = f[4 * S], f5 = f[5 * S], f6 = f[6 * S],
+                f7 = f[7 * S], f8 = f[8 * S];
     if (x == 0 && y >= 1 && y < a.ny - 1) {
-        const float rho_w = (1.f / (1.f - a.u_w)) * (c.f0 + c.f2 + c.f4 + 2.f * (c.f3 + c.f6 + c.f7));
-        const float h = 0.5f * (c.f2 - c.f4), t = (1.f / 6.f) * rho_w * a.u_w;
-        c.f1 = c.f3 + (2.f / 3.f) * rho_w * a.u_w;
-        c.f5 = c.f7 - h + t;
-        c.f8 = c.f6 + h + t;
+        const float rho_w = (1.f / (1.f - a.u_w)) * (f0 + f2 + f4 + 2.f * (f3 + f6 + f7));
+        const float h = 0.5f * (f2 - f4), t = (1.f / 6.f) * rho_w * a.u_w;
+        f[S] = f3 + (2.f / 3.f) * rho_w * a.u_w;
+        f[5 * S] = f7 - h + t;
+        f[8 * S] = f6 + h + t;
     }
     if (x == a.nx - 1 && y >= 1 && y < a.ny - 1) {
-        const float rho_e = (1.f / (1.f + a.u_e)) * (c.f0 + c.f2 + c.f4 + 2.f * (c.f1 + c.f5 + c.f8));
-        const float h = 0.5f * (c.f2 - c.f4), t = (1.f / 6.f) * rho_e * a.u_e;
-        c.f3 = c.f1 - (2.f / 3.f) * rho_e * a.u_e;
-        c.f6 = c.f5 + h - t;
-        c.f7 = c.f8 - h - t;
+        const float rho_e = (1.f / (1.f + a.u_e)) * (f0 + f2 + f4 + 2.f * (f1 + f5 + f8));
+        const float h = 0.5f * (f2 - f4), t = (1.f / 6.f) * rho_e * a.u_e;
+        f[3 * S] = f1 - (2.f / 3.f) * rho_e * a.u_e;
+        f[6 * S] = f5 + h - t;
+        f[7 * S] = f8 - h - t;
     }
     if (y == a.ny - 1) {
-        c.f4 = a.f[4 * S + x]; c.f8 = a.f[8 * S + x]; c.f7 = a.f[7 * S + x];
+        f[4 * S] = a.f[4 * S + x]; f[8 * S] = a.f[8 * S + x]; f[7 * S] = a.f[7 * S + x];
     }
     if (y == 0) {
         const long long top = (long long)(a.ny - 1) * a.pitch + x;
-        c.f2 = a.f[2 * S + top]; c.f6 = a.f[6 * S + top]; c.f5 = a.f[5 * S + top];
+        f[2 * S] = a.f[2 * S + top]; f[6 * S] = a.f[6 * S + top]; f[5 * S] = a.f[5 * S + top];
     }
-    bounce_cell(c, solid);
-    f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
-    f[5 * S] = c.f5; f[6 * S] = c.f6; f[7 * S] = c.f7; f[8 * S] = c.f8;
+}
+
+// D2Q9.cl:398-433 `bounceback_in_obstacle` on its own (after k_bcs_vel; k_bcs / k1_bcs fuse it: their rules are
+// cell-local)
+__global__ void k_bounce(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    if (!a.mask[o]) return;
+    float *f = a.f + o;
+    const float f1 = f[S], f2 = f[2 * S], f3 = f[3 * S], f4 = f[4 * S], f5 = f[5 * S], f6 = f[6 * S], f7 = f[7 * S],
+                f8 = f[8 * S];
+    f[S] = f3; f[3 * S] = f1; f[2 * S] = f4; f[4 * S] = f2;
+    f[5 * S] = f7; f[7 * S] = f5; f[6 * S] = f8; f[8 * S] = f6;
 }
 
 // D2Q9.cl:323-374 `update_hydro_PeriodicBC_VelocityInlet`: v on the inlet / outlet columns and u, v

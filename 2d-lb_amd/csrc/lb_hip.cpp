@@ -11,9 +11,11 @@
 //                                 323-327, 395-407) and the per-step launch sequence of run() (:372-387)
 //
 // Device layout: structure of arrays, nine planes per lattice, two lattices
-// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -3..-1 and
-// H..H+2 are ghost rows (slab halo, three deep for the three-step kernel / don't-care at walls), so
-// element (k, x, y) of a slab of H rows lives at   lattice + GUARD + k*plane + (y+3)*pitch + x .
+// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -GHOST..-1 and
+// H..H+GHOST-1 are ghost rows (GHOST = 8: slab halo, deep enough for two four-step launches per exchange /
+// don't-care at walls), so element (k, x, y) of a slab of H rows lives at
+//   lattice + GUARD + k*plane + (y+GHOST)*pitch + x ;
+// the obstacle mask is uint8 [H + 2*LB_MASK_HALO_ROWS][pitch], row y at mask + y*pitch (7 rows of each neighbour).
 // Source layout (one translation unit): d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2,
 // k_step3), kernels_step4.h (k_step4), kernels_tile.h (k_tile4), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
@@ -141,8 +143,8 @@ struct lb_sim {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int min_h = 0;              // smallest slab height over the ranks (every rank must pick the same schedule)
-    float *halo_buf = nullptr;  // 4 x 45*nx floats: send north, send south, recv south, recv north
-    int ghost_depth = 0;        // ghost rows of lat[cur] hold this many of the neighbours' edge rows (0, 3 or 6)
+    float *halo_buf = nullptr;  // 4 x HALO_SEGS_DEEP (63) x nx floats: send north, send south, recv south, recv north
+    int ghost_depth = 0;        // ghost rows of lat[cur] hold this many of the neighbours' edge rows (0, 3, 6 or 8)
     int variant = -1;           // < 0: automatic (effective_variant)
     hipGraph_t graph = nullptr;            // GRAPH_STEPS single-step launches, captured for small grids
     hipGraphExec_t graph_exec = nullptr;
@@ -778,11 +780,27 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1; small grids: 36, so that the single-step candidate
     // runs the way it would (hipGraph replay of 16 launches)
     const int per = small_grid(s) ? 36 : 12;
+    const int keep_steps = s->tuned_steps, keep_wpc = s->tuned_wpc;
     int used = 0, best = -1;
     float best_ms = 0.f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    // any failure: events destroyed, the previous choice restored (the steps taken so far stay taken -- they are
+    // ordinary time steps)
+    auto bail = [&](int rc) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        s->tuned_steps = keep_steps;
+        s->tuned_wpc = keep_wpc;
+        return rc;
+    };
+#define TUNE_TRY(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return bail(fail(LB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+    TUNE_TRY(hipEventCreate(&e0));
+    TUNE_TRY(hipEventCreate(&e1));
     for (size_t c = 0; c < sizeof(cands) / sizeof(cands[0]); ++c) {
         if (cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) continue;
         if (cands[c].wpc < 0 && !tile_applicable(s)) continue;
@@ -792,20 +810,23 @@ int autotune_whole_grid(lb_sim *s, int rounds)
         s->tuned_wpc = cands[c].wpc;
         float ms_min = 0.f;
         for (int r = 0; r <= rounds; ++r) {            // round 0 warms the configuration up
-            HIP_TRY(hipEventRecord(e0, s->stream));
+            TUNE_TRY(hipEventRecord(e0, s->stream));
             int rc = run_whole_grid(s, per, false);     // no rho,u,v epilogue: it would weigh on the short samples
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(e1, s->stream));
-            HIP_TRY(hipEventSynchronize(e1));
+            if (rc) return bail(rc);
+            TUNE_TRY(hipEventRecord(e1, s->stream));
+            TUNE_TRY(hipEventSynchronize(e1));
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            TUNE_TRY(hipEventElapsedTime(&ms, e0, e1));
             used += per;
             if (r >= 1 && (r == 1 || ms < ms_min)) ms_min = ms;
         }
         if (best < 0 || ms_min < best_ms) { best = (int)c; best_ms = ms_min; }
     }
+#undef TUNE_TRY
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    e0 = e1 = nullptr;
+    if (best < 0) return bail(0);                       // nothing applicable
     s->tuned_steps = cands[best].steps;
     s->tuned_wpc = cands[best].wpc;
     // one more step that stores rho,u,v so that the observable state is consistent again
@@ -814,6 +835,15 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     s->cur ^= 1;
     s->feq_valid = false;
     return used + 1;
+}
+
+// steps a quick (one-round) tuning pass consumes at most: 8 candidates x 2 samples x 12 (36) steps + 1
+int autotune_quick_cost(const lb_sim *s) { return 8 * 2 * (small_grid(s) ? 36 : 12) + 1; }
+
+bool autotune_applies(const lb_sim *s)
+{
+    return !s->multi_slab() && s->p.semantics == LB_SEM_OPENCL && s->p.bc_mode != LB_BC_VELOCITY_INLET &&
+           (step2_applicable(s) || step3_applicable(s) || tile_applicable(s));
 }
 
 }  // namespace
@@ -1036,6 +1066,7 @@ int lb_get_f(lb_sim *s, float *f)
 }
 
 int lb_update_feq(lb_sim *s);
+int lb_steps_per_launch(lb_sim *s);
 
 int lb_get_feq(lb_sim *s, float *feq)
 {
@@ -1070,9 +1101,9 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
         }
     // kernels of an un-waited run() may still be reading the mask: the handle's streams are
     // non-blocking, so order the upload behind them explicitly
-    (void)hipStreamSynchronize(s->stream);
-    (void)hipStreamSynchronize(s->edge_stream);
-    hipError_t e = hipMemcpy(s->mask, tmp, n, hipMemcpyHostToDevice);
+    hipError_t e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->edge_stream);
+    if (e == hipSuccess) e = hipMemcpy(s->mask, tmp, n, hipMemcpyHostToDevice);
     free(tmp);
     if (e != hipSuccess) return fail(LB_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
     // An all-zero mask on one slab must still take the MASK kernel if the caller asked for a
@@ -1088,9 +1119,16 @@ int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_
     DeviceGuard guard(s->p.device);
     uint8_t *tmp = (uint8_t *)calloc((size_t)s->pitch * MASK_GHOST, 1);
     if (!tmp) return fail(LB_ERR_ARG, "out of host memory");
-    // south_rows = global rows y0-2, y0-1; north_rows = rows y0+H, y0+H+1 (each [2][nx], nearest last / first)
-    (void)hipStreamSynchronize(s->stream);
-    (void)hipStreamSynchronize(s->edge_stream);
+    // south_rows = global rows y0-MASK_GHOST .. y0-1 (nearest last); north_rows = rows y0+H .. y0+H+MASK_GHOST-1
+    // (nearest first); each [LB_MASK_HALO_ROWS][nx]
+    {
+        hipError_t e = hipStreamSynchronize(s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->edge_stream);
+        if (e != hipSuccess) {
+            free(tmp);
+            return fail(LB_ERR_HIP, "mask halo upload: %s", hipGetErrorString(e));
+        }
+    }
     const int32_t *rows[2] = {south_rows, north_rows};
     uint8_t *dst[2] = {s->mask - (size_t)MASK_GHOST * s->pitch, s->mask + (size_t)s->H * s->pitch};
     for (int side = 0; side < 2; ++side) {
@@ -1142,9 +1180,11 @@ int lb_move_bcs(lb_sim *s)
     DeviceGuard guard(s->p.device);
     if (s->p.semantics == LB_SEM_CYTHON)
         hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
-    else if (s->p.bc_mode == LB_BC_VELOCITY_INLET)
+    else if (s->p.bc_mode == LB_BC_VELOCITY_INLET) {
         hipLaunchKernelGGL(k_bcs_vel, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
-    else
+        HIP_TRY(hipGetLastError());
+        if (s->has_mask) hipLaunchKernelGGL(k_bounce, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    } else
         hipLaunchKernelGGL(k_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -1302,6 +1342,7 @@ int lb_run(lb_sim *s, int n_steps)
         // bitwise equal to the five phase calls (test_cython_path_fused_run_equals_phase_calls)
         for (int it = 0; it < n_steps; ++it) {
             hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+            HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k1_step, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
             HIP_TRY(hipGetLastError());
             s->cur ^= 1;
@@ -1309,20 +1350,7 @@ int lb_run(lb_sim *s, int n_steps)
         if (n_steps) s->feq_valid = false;
         return LB_OK;
     }
-    if (!s->multi_slab()) {
-        // Long first run with the automatic variant: time the candidate kernel configurations on the
-        // first steps of this very run (they are bitwise equivalent) and keep the fastest.
-        // (it consumes up to 8 candidates x 2 samples x 12 steps + 1 = 193 steps; 577 on small grids, whose
-        //  samples are 36 steps long)
-        const int tune_steps = 8 * 2 * (small_grid(s) ? 36 : 12) + 1;
-        if (s->variant < 0 && !s->tuned_steps && n_steps >= tune_steps + 7 &&
-            (step2_applicable(s) || step3_applicable(s) || tile_applicable(s))) {
-            const int used = autotune_whole_grid(s, 1);
-            if (used < 0) return used;
-            n_steps -= used;
-        }
-        return run_whole_grid(s, n_steps);
-    }
+    if (!s->multi_slab()) return run_whole_grid(s, n_steps);     // (never blocks the host: tuning is lb_autotune*'s job)
     if (!s->comm)
         return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
     if (n_steps == 0) return LB_OK;
@@ -1530,6 +1558,8 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
 }
 
 // ---- RCCL --------------------------------------------------------------------------------
+int lb_comm_available(void) { return rccl_load(); }
+
 int lb_comm_unique_id(void *unique_id_128)
 {
     if (!unique_id_128) return fail(LB_ERR_ARG, "null argument");
@@ -1593,11 +1623,37 @@ int lb_autotune(lb_sim *s)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune inside a split step");
-    if (s->multi_slab() || s->p.semantics != LB_SEM_OPENCL || s->p.bc_mode == LB_BC_VELOCITY_INLET ||
-        !(step2_applicable(s) || step3_applicable(s) || tile_applicable(s)))
-        return 0;                                      // nothing to choose between
+    if (!autotune_applies(s)) return 0;                // nothing to choose between
     DeviceGuard guard(s->p.device);
     return autotune_whole_grid(s, 6);
+}
+
+int lb_autotune_quick(lb_sim *s, int max_steps)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune_quick inside a split step");
+    if (!autotune_applies(s) || s->variant >= 0 || s->tuned_steps || max_steps < autotune_quick_cost(s)) return 0;
+    DeviceGuard guard(s->p.device);
+    return autotune_whole_grid(s, 1);
+}
+
+int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
+{
+    if (!s || !buf || buflen < 1) return fail(LB_ERR_ARG, "bad argument");
+    static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET"};
+    const char *kernel = "k_step";
+    if (s->p.semantics == LB_SEM_CYTHON) kernel = "k1_bcs + k1_step";
+    else if (s->p.bc_mode == LB_BC_VELOCITY_INLET) kernel = "un-fused phase kernels";
+    else {
+        const int spl = lb_steps_per_launch(s);
+        if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";
+        else if (spl == 4) kernel = "k_step4 (marching strips, stage windows in registers + wave-private LDS)";
+        else if (spl == 3) kernel = "k_step3 (marching strips, register windows)";
+        else if (spl == 2) kernel = "k_step2 (marching strips, register window)";
+        else kernel = "k_step (one fused pull-stream + collide pass)";
+    }
+    snprintf(buf, (size_t)buflen, "%s<%s%s>", kernel, bc_names[s->p.bc_mode], s->has_mask ? ", MASK" : "");
+    return LB_OK;
 }
 
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)

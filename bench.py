@@ -2,23 +2,35 @@
 """Headline benchmark: MLUPS + achieved HBM GB/s of the fused D2Q9 step on an 8192x8192 fp32
 periodic shear layer (BASELINE.json: metric / configs[3]), 1..8 MI355X, row slabs + RCCL halo.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns one rank process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (stream + BC + moments + feq + BGK collide, one fused HIP
-launch per slab) over the whole grid.  The grid is fixed as N grows (strong scaling, as the
-north-star states its 8-GPU target).  Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path (stream + BC + moments + feq + BGK collide) over the whole grid.  The
+grid is fixed as N grows (strong scaling, as the north-star states its 8-GPU target).  Rank 0 prints ONE JSON
+line.
+
+Timing.  After W warm-up steps the K-step block -- barrier + device sync, K steps, barrier + device sync,
+MAX over ranks -- is repeated until at least MIN_BLOCKS blocks and MIN_TIMED_S seconds have been timed;
+`ms_per_step` / `value` come from the MEDIAN block (`timing` lists min / max / count), so a 5 ms sample on a
+fresh box no longer decides the line.
 
 Extra objects in the line:
-  roofline     - the fused kernel against the HBM roofline: achieved = 72 B x cells per launch /
-                 average launch duration (HIP events on the engine's stream over the timed region).
+  roofline     - the dominant kernel against the HBM roofline.  `achieved` = the bytes one launch MUST move --
+                 72 B x the cells of its slab (nine fp32 planes read once, nine written once), whatever
+                 number of time steps the launch fuses -- / its average duration (HIP events on the engine's
+                 stream over the timed blocks); `frac` = achieved / 8 TB/s, <= 1 by construction.
+                 `effective_GBps` = 72 B x lattice UPDATES / time (what an un-blocked kernel would have to move
+                 for the same MLUPS; exceeds the peak when several steps share one pass) is reported beside it,
+                 never as `frac`.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of
+                 this same command (profiles/pmc_traffic.json; see `traffic_source`), not measured in this run.
   cpu_baseline - oracle port of the reference's Cython CPU path (oracle/d2q9_oracle.c o1_run),
                  1 core, on a bounded sample; reported, not a target.  Rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,8 +39,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
 
-B_ALG = 72.0            # algorithmic bytes per lattice update: 9 fp32 read + 9 fp32 written
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+B_ALG = 72.0              # algorithmic bytes per lattice update: 9 fp32 read + 9 fp32 written
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling quoted by the same guide
+MIN_BLOCKS, MIN_TIMED_S, MAX_BLOCKS = 5, 0.5, 2000
 
 
 def shear_layer(nx, ny, y0, h, U=0.04, seed=0):
@@ -52,7 +66,6 @@ def cpu_baseline(budget_s=12.0, n=4096, all_cores_budget_s=4.0):
     from oracle import oracle as O
     kw = dict(diameter=1., rho=1., viscosity=0.05, pressure_grad=-1., pipe_length=1., N=n - 1,
               time_prefactor=(n - 1) / 10.)
-    t_build = time.perf_counter()
     sim = O.O1Sim.pipe_flow(numpy2=False, **kw)
     sim.run(1)                                   # touch every page once
     steps, t0 = 0, time.perf_counter()
@@ -85,15 +98,60 @@ def cpu_baseline(budget_s=12.0, n=4096, all_cores_budget_s=4.0):
 
 def load_pmc_traffic(n_side, steps_per_launch=1):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
-    workload (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); None when absent."""
+    workload (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); (None, None) when absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
         ent = d.get("%d/%d" % (n_side, steps_per_launch))
-        return ent.get("hbm_bytes_per_launch") if ent else None
+        if not ent:
+            return None, None
+        return ent.get("hbm_bytes_per_launch"), "committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+            "command, read side calibrated on k_copy4), not measured in this run" % ent.get("source", "profiles/pmc_traffic.json")
     except (OSError, ValueError):
-        return None
+        return None, None
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start one rank process per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), wait, forward rank 0's line.  This parent
+    never touches HIP or torch.cuda (a process that initialised the GPU must not start replacing itself, and
+    has no need to: the children are ordinary subprocesses)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves its peers blocked in a collective: poll, and take the others down with it
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        failed = next((r for r, c in enumerate(codes) if c not in (None, 0)), None)
+        if failed is None and all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:                       # (exact PIDs of the children started above)
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write(procs[0].stdout.read().decode(errors="replace"))
+        raise SystemExit("bench: rank %d exited with status %s" % (failed, procs[failed].returncode))
+    out = procs[0].stdout.read().decode(errors="replace")
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if not any(l.startswith("{") for l in out.splitlines()):
+        raise SystemExit("bench: rank 0 printed no result line")
 
 
 def main():
@@ -109,20 +167,29 @@ def main():
     ap.add_argument("--force-slab-path", action="store_true",
                     help="run through DistributedSlab / the RCCL halo path even with one rank (a 1-rank periodic "
                          "ring exchanging with itself): exercises the multi-GPU code on a single GPU")
-    ap.add_argument("--calibrate", type=int, default=0,
-                    help="also launch N plain float4 copies of known size before the timed region "
-                         "(FETCH_SIZE calibration for rocprofv3 --pmc runs; adds copy_GBps to the line)")
+    ap.add_argument("--calibrate", type=int, default=3,
+                    help="launch N plain float4 copies of known size before the timed region (the device's own "
+                         "streaming rate, `copy_GBps`; also the FETCH_SIZE calibration of rocprofv3 --pmc runs); 0 = skip")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
+    ap.add_argument("--min-blocks", type=int, default=MIN_BLOCKS)
     args = ap.parse_args()
+    if args.steps < 1:
+        raise SystemExit("--steps must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
+        return
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_slab_path:
@@ -132,7 +199,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from LB_D2Q9.simulation import Simulation
-    from LB_D2Q9.slabs import DistributedSlab, partition_rows
+    from LB_D2Q9.slabs import DistributedSlab
 
     n = args.size
     if world == 1 and not args.force_slab_path:
@@ -178,15 +245,23 @@ def main():
         copy_gbs = {"plain": round(eng.copy_calibration(args.calibrate, False)[0], 1),
                     "nontemporal": round(eng.copy_calibration(args.calibrate, True)[0], 1)}
     sim.run(args.warmup, wait=False)
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = sim.timed_run(args.steps)          # enqueue K steps between two HIP events, wait for them
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(t[0]), float(t[1])
+
+    # ---- timed region: blocks of exactly K steps, each bracketed by barrier + device sync -------------------
+    walls, evs, total = [], [], 0.0
+    while len(walls) < MAX_BLOCKS and (len(walls) < args.min_blocks or total < args.min_timed_s):
+        barrier()
+        t0 = time.perf_counter()
+        ev_ms = sim.timed_run(args.steps)      # enqueue K steps between two HIP events on the engine's stream, wait
+        barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:                   # MAX over ranks; also makes every rank take the same loop decision
+            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, ev_ms = float(t[0]), float(t[1])
+        walls.append(wall)
+        evs.append(ev_ms)
+        total += wall
+    wall, ev_ms = statistics.median(walls), statistics.median(evs)
 
     # sanity: the run must have produced finite numbers (guards against timing a broken kernel)
     chk = eng.get_fields(("rho",))["rho"]
@@ -197,19 +272,30 @@ def main():
         cells = float(n) * n
         mlups = cells * args.steps / wall / 1e6
         # dominant kernel = the fused step over this rank's rows; rank 0's slab is representative.
-        # One launch advances spl time steps (2 with the two-steps-per-pass kernel), i.e. it performs
-        # spl x n x h lattice updates = spl x 72 B x n x h algorithmic bytes.
+        # One launch advances spl time steps: it performs spl x n x h lattice updates, but what it MUST move is
+        # one read and one write of the slab's nine planes, 72 B x n x h, whatever spl is.
         python_driven = dist is not None and args.transport == "torch"      # that path is single-step
         spl = 1 if python_driven else eng.steps_per_launch()
+        kname = "k_step (python-driven exchange)" if python_driven else eng.hot_kernel()
         # K timed steps = (K // spl) launches of the spl-step kernel (+ at most one shorter launch for the
         # remainder, priced at the same per-step rate)
         launch_s = ev_ms / 1e3 / args.steps * spl
-        bytes_per_launch = B_ALG * n * h * spl
+        bytes_per_launch = B_ALG * n * h
         achieved = bytes_per_launch / launch_s / 1e9
-        kname = {4: "k_step4<PERIODIC> (four fused time steps per pass: stage windows in registers and wave-private LDS)",
-                 3: "k_step3<PERIODIC> (three fused time steps per pass: step-1 and step-2 results in registers)",
-                 2: "k_step2<PERIODIC> (two fused time steps per pass: step-1 results in registers)",
-                 1: "k_step<PERIODIC> (fused pull-stream+collide)"}[spl]
+        effective = bytes_per_launch * spl / launch_s / 1e9
+        traffic, traffic_source = load_pmc_traffic(n, spl) if dist is None else (None, None)
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy": round(achieved / COPY_CEILING_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
+                "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "effective_GBps": round(effective, 1), "effective_x_roofline": round(effective / HBM_PEAK_GBS, 4),
+                "note": "achieved = 72 B x cells of one launch (compulsory: each plane read once, written once) / "
+                        "launch time; effective_GBps = 72 B x lattice updates / time is NOT an HBM rate when "
+                        "steps_per_launch > 1"}
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",
@@ -217,19 +303,20 @@ def main():
             "ms_per_step": round(wall * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "achieved_hbm_GBps": round(mlups * 1e6 * B_ALG / 1e9, 1),
+            "achieved_hbm_GBps": round(world * achieved, 1),
+            "timing": {"blocks": len(walls), "block_steps": args.steps, "statistic": "median",
+                       "min_ms_per_step": round(min(walls) * 1e3 / args.steps, 4),
+                       "max_ms_per_step": round(max(walls) * 1e3 / args.steps, 4),
+                       "timed_s": round(total, 3)},
             "config": {"workload": "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
                                    "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
                                                                     "" if dist is None else ", halo via " + args.transport),
                        "grid": [n, n], "bytes_per_lattice_update": B_ALG},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(n, spl) if dist is None else None,
-                         "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
-                         "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "roofline": roof,
         }
         if copy_gbs is not None:
             line["copy_GBps"] = copy_gbs
+            roof["frac_of_copy_on_this_device"] = round(achieved / max(copy_gbs.values()), 4)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

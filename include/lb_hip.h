@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 2
+#define LB_ABI_VERSION 3
 
 typedef enum {
     LB_OK = 0,
@@ -58,8 +58,9 @@ typedef enum {
 /* Which of the reference's two (numerically different) paths the handle reproduces.
  * OPENCL: LB_D2Q9/D2Q9.cl driven as opencl_dim.py:372-387 does -- the fused, fast path.
  * CYTHON: LB_D2Q9/dimensionless/cython_dim.pyx:160-359 -- boundary rules before streaming, bounce-back
- *         walls, restricted in-place streaming, moment overrides; PIPE family, whole-grid handles,
- *         un-fused kernels only (a compatibility path for users of the reference's CPU classes). */
+ *         walls, restricted in-place streaming, moment overrides; PIPE family, whole-grid handles
+ *         (a compatibility path for users of the reference's CPU classes: lb_run launches the boundary
+ *         phase + one fused pass per step, the phase entry points one kernel each). */
 typedef enum {
     LB_SEM_OPENCL = 0,
     LB_SEM_CYTHON = 1
@@ -174,6 +175,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps);
  * handle exchanges halos itself: two four-step (slabs of >= 64 rows) or three-step (>= 32 rows) launches per
  * exchange with ghost zones eight / six rows deep when nx >= 512, otherwise one exchange of the 3-deep halo
  * per launch. */
+int lb_comm_available(void);               /* 0 when librccl can be loaded in this process (no communicator is made) */
 int lb_comm_unique_id(void *unique_id_128);
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
 
@@ -184,14 +186,22 @@ int lb_timer_stop(lb_sim *s, float *elapsed_ms);
 /* Device layout facts for DESIGN.md / bench.py: pitch (floats), plane stride
  * (floats), bytes allocated. */
 int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated);
-/* Time steps advanced by one launch of the hot kernel in lb_run with the current variant:
- * 3 / 2 when the three- / two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch with it). */
+/* Time steps advanced by one launch of the hot kernel in lb_run with the current variant / tuning:
+ * 4, 3 or 2 when a four- / three- / two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch
+ * with it). */
 int lb_steps_per_launch(lb_sim *s);
+/* Name of that kernel, e.g. "k_step4 (...)<PERIODIC>", written into buf (NUL-terminated, truncated to buflen). */
+int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 /* Pick the fastest configuration of the fused kernels for THIS grid by timing each candidate on a few
  * live time steps (all candidates give bitwise identical results, so this simply advances the
  * simulation): returns the number of steps advanced (0 when there is nothing to choose), <0 on error.
- * lb_run does it by itself at the start of the first run of >= 120 steps with the automatic variant. */
+ * Blocks the host (it reads HIP event times).  lb_run never tunes by itself. */
 int lb_autotune(lb_sim *s);
+/* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
+ * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
+ * variant automatic and the pass (193 steps; 577 on grids <= 768^2) fits into max_steps; returns the number
+ * of steps advanced, 0 when it did nothing. */
+int lb_autotune_quick(lb_sim *s, int max_steps);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
  * (which is scratch between steps).  *bytes_moved = bytes read + written.  Known traffic in the
  * fused kernel's access shape: corrects rocprofv3 FETCH_SIZE on gfx950 and gives the device's

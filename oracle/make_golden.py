@@ -450,9 +450,29 @@ def gen_o1(m):
          columns=np.array(["N", "radius", "L", "T", "Re", "omega", "inlet_rho", "nx", "ny"]))
 
 
+def gen_o1_config1(m):
+    """BASELINE config 1 at full size through the imported reference: 256 x 256 Poiseuille start-up flow,
+    `Pipe_Flow.run` (cython_dim.pyx:346-359), 1000 steps from f = feq (the perturbation of init_pop replaced by
+    none).  Stored: x-means of u and rho, every fourth row / column of rho, u, v, and the derived constants."""
+    kw = dict(diameter=1., rho=1., viscosity=.05, pressure_grad=-1., pipe_length=1., N=255, time_prefactor=25.5)
+    s = m.Pipe_Flow(**kw)
+    s.update_feq()
+    s.f = s.feq.copy()
+    s.run(1000)
+    rho, u, v = np.array(s.rho), np.array(s.u), np.array(s.v)
+    save("o1_config1_256", kw_names=np.array(list(kw.keys())), kw_vals=np.array(list(kw.values()), float),
+         nx=s.nx, ny=s.ny, omega=s.omega, inlet_rho=s.inlet_rho, outlet_rho=s.outlet_rho, T=s.T, Re=s.Re,
+         steps=1000, stride=4, u_xmean=u.mean(axis=0), v_xmean=v.mean(axis=0), rho_ymean=rho.astype(np.float64).mean(axis=1),
+         rho_sub=rho[::4, ::4].copy(), u_sub=u[::4, ::4].copy(), v_sub=v[::4, ::4].copy(),
+         u_col0=u[0].copy(), u_collast=u[-1].copy())
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="lb_golden_", dir="/tmp")
     print("scratch dir", tmp)
+    if "--only-config1" in sys.argv:
+        gen_o1_config1(build_o1(tmp))
+        return
     L = build_o2(tmp)
     if "--only-velocity-inlet" not in sys.argv and "--only-d2q9i" not in sys.argv:
         gen_o2(L)
@@ -463,7 +483,9 @@ def main():
     gen_o2_d2q9i(build_o2(tmp, "D2Q9i.cl"))
     if "--only-d2q9i" in sys.argv:
         return
-    gen_o1(build_o1(tmp))
+    m = build_o1(tmp)
+    gen_o1(m)
+    gen_o1_config1(m)
 
 
 if __name__ == "__main__":

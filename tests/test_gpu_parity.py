@@ -105,6 +105,29 @@ def test_fused_equals_unfused_sequence(lbhip):
         assert maxdiff(ga[k], gb[k]) <= 1e-6, k
 
 
+def test_fused_opencl_path_kernel_vs_imported_cython_reference_interior(lbhip):
+    """The strictly pinned oracle leg is O1 (the imported, cythonized reference).  Away from walls the two reference
+    paths are the same scheme (stream + BGK), which is how the reference authors checked their OpenCL port against
+    their CPU code: |difference| <= 1e-6 outside a 3-cell margin (testing/Bryan/opencl_check_03.ipynb:593, 778).
+    Here the fused HIP kernel takes one step from the state the imported reference had before its third step
+    (fixture o1_pipe_33x17: pre_* -> t_collide_f / t_hydro_*) and must agree with it in the interior."""
+    from LB_D2Q9.simulation import Simulation
+    d = golden("o1_pipe_33x17")
+    nx, ny = int(d["nx"]), int(d["ny"])
+    for variant in (-1, 0, 512):                       # automatic choice, single-step kernel, LDS-tile kernel (1 step = k_step)
+        sim = Simulation(nx, ny, float(d["omega"]), bc="pipe", inlet_rho=float(d["inlet_rho"]), outlet_rho=float(d["outlet_rho"]))
+        sim.set_variant(variant)
+        sim.set_f(np.asarray(d["pre_f"]).transpose(1, 2, 0))        # reference layout (9, nx, ny) -> (nx, ny, 9)
+        sim.run(1)
+        g = sim.get_fields(("f", "rho", "u", "v"))
+        inner = (slice(3, -3), slice(3, -3))
+        assert maxdiff(g["f"][inner], np.asarray(d["t_collide_f"]).transpose(1, 2, 0)[inner]) <= 1e-6
+        assert maxdiff(g["rho"][inner], d["t_hydro_rho"][inner]) <= 1e-6
+        assert maxdiff(g["u"][inner], d["t_hydro_u"][inner]) <= 1e-6
+        assert maxdiff(g["v"][inner], d["t_hydro_v"][inner]) <= 1e-6
+        sim.close()
+
+
 # ---- build-defined boundary families against the oracle -------------------------------------------
 def _random_state(rng, nx, ny, amp=0.02):
     w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
@@ -382,6 +405,46 @@ def test_checkpoint_restart_is_bitwise(lbhip, tmp_path):
     for k in ga:
         assert np.array_equal(ga[k], gb[k]), k
     assert g["rho"].shape == (nx, ny)
+
+
+def test_checkpoint_round_trips_every_handle_parameter(lbhip, tmp_path):
+    """A checkpoint rebuilds the handle it was taken from: Cython-path semantics, the velocity-inlet family with its
+    imposed speeds, a bare path (np.savez appends .npz), a cleared obstacle; loading into a lattice with another
+    omega / semantics is refused instead of silently changing the physics."""
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 70, 40
+    rng = np.random.default_rng(8)
+    f0 = _random_state(rng, nx, ny)
+    for kw in (dict(bc="pipe", inlet_rho=1.004, semantics="cython"),
+               dict(bc="velocity_inlet", inlet_u=0.03, outlet_u=0.025),
+               dict(bc="cavity", lid_u=0.07, rho0=1.01)):
+        a = Simulation(nx, ny, 1.2, **kw)
+        a.set_f(f0)
+        a.run(6)
+        path = str(tmp_path / ("ckpt_" + kw["bc"] + kw.get("semantics", "")))       # no suffix
+        a.save_checkpoint(path)
+        b = Simulation.from_checkpoint(path)
+        assert b.semantics == a.semantics and b.bc_mode == a.bc_mode
+        assert (b.inlet_u, b.outlet_u, b.lid_u, b.rho0) == (a.inlet_u, a.outlet_u, a.lid_u, a.rho0)
+        a.run(7); b.run(7)
+        ga, gb = a.get_fields(("f", "rho", "u", "v")), b.get_fields(("f", "rho", "u", "v"))
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]), (kw, k)
+    # mismatches are refused
+    a = Simulation(nx, ny, 1.2, bc="pipe", inlet_rho=1.004)
+    a.set_f(f0)
+    a.save_checkpoint(str(tmp_path / "p"))
+    for other in (dict(omega=1.3), dict(semantics="cython"), dict(inlet_rho=1.005)):
+        kw = dict(omega=1.2, bc="pipe", inlet_rho=1.004)
+        kw.update(other)
+        with pytest.raises(ValueError):
+            Simulation(nx, ny, **kw).load_checkpoint(str(tmp_path / "p"))
+    # a checkpoint without an obstacle clears the obstacle of the lattice it is loaded into
+    mask = rng.random((nx, ny)) < 0.1
+    c = Simulation(nx, ny, 1.2, bc="pipe", inlet_rho=1.004, obstacle_mask=mask)
+    c.load_checkpoint(str(tmp_path / "p.npz"))
+    a.run(5); c.run(5)
+    assert np.array_equal(a.get_fields(("f",))["f"], c.get_fields(("f",))["f"])
 
 
 def test_frame_dumper_on_pipe_flow_cylinder(lbhip, tmp_path):

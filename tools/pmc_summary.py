@@ -68,7 +68,7 @@ def main():
     try:
         import re
         log = open(os.path.join(src, "kt.log")).read()
-        m_l, m_v, m_k = re.search(r'"launch_ms": ([0-9.]+)', log), re.search(r'"value": ([0-9.]+)', log), re.search(r'"kernel": "(k_step\d?)', log)
+        m_l, m_v, m_k = re.search(r'"launch_ms": ([0-9.]+)', log), re.search(r'"value": ([0-9.]+)', log), re.search(r'"kernel": "(k_[a-z]+\d?)', log)
         if m_l and m_v:
             lines += ["", "bench.py inside this run (HIP events over the timed region): %s MLUPS, launch_ms %s of %s."
                       % (m_v.group(1), m_l.group(1), m_k.group(1) if m_k else "the hot kernel")]
@@ -85,7 +85,7 @@ def main():
               "Calibration on `k_copy4<false>` (reads %.0f B, writes the same): FETCH_SIZE x 1024 = %.4g B -> "
               "read correction x%.3f; WRITE_SIZE x 1024 = %.4g B -> write correction x%.3f." % (
                   copy_bytes, copy_fetch, fetch_corr, copy_write, write_corr), "",
-              "| kernel | FETCH_SIZE (KiB) | WRITE_SIZE (KiB) | HBM read B (corrected) | HBM write B | total B | algorithmic B | ratio |",
+              "| kernel | FETCH_SIZE (KiB) | WRITE_SIZE (KiB) | HBM read B (corrected) | HBM write B | total B | compulsory B (72 B x cells) | ratio |",
               "|---|---|---|---|---|---|---|---|"]
     out = {}
     for k in sorted(dur):
@@ -96,13 +96,19 @@ def main():
         rd, wr = f * 1024 * fetch_corr, w * 1024 * write_corr
         macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS>
         spl = int(k[6]) if k[6:7].isdigit() else 1        # k_step2/3/4: time steps per launch
-        alg = 72.0 * side * side * spl + (12.0 * side * side if macro else 0.0)
+        alg = 72.0 * side * side + (12.0 * side * side if macro else 0.0)      # compulsory bytes of one launch, whatever spl
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
         if not macro:
             out["%d/%d" % (side, spl)] = {"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
                    "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
                    "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    # rocprofv3's own --stats table of the SAME kernel-trace run, verbatim (never left over from another run)
+    stats = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        stats.sort(key=os.path.getmtime)
+        import shutil
+        shutil.copyfile(stats[-1], os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
     with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.md" % tag), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     jpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
