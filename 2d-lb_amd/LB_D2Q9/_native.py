@@ -26,7 +26,7 @@ EXPORTS = (
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group",
     "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
-    "lb_autotune_quick", "lb_hot_kernel",
+    "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state",
 )
 
 
@@ -83,6 +83,8 @@ def lib():
     L.lb_set_variant.argtypes = [h, I]
     L.lb_copy_calibration.argtypes = [h, I, ct.POINTER(ct.c_int64)]
     L.lb_autotune_quick.argtypes = [h, I]
+    L.lb_get_corner_state.argtypes = [h, vp]
+    L.lb_set_corner_state.argtypes = [h, vp]
     L.lb_hot_kernel.argtypes = [h, ct.c_char_p, I]
     if L.lb_abi_version() != ABI_VERSION:
         raise LbError("liblbhip.so ABI %d != binding ABI %d: rebuild" % (L.lb_abi_version(), ABI_VERSION))

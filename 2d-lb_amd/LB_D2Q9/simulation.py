@@ -256,6 +256,8 @@ class Simulation(object):
                  version=self.CHECKPOINT_VERSION, semantics=np.array(self.semantics), halo=int(self._halo))
         for k in self._CKPT_SCALARS:
             d[k] = getattr(self, k)
+        if self.bc_mode == _native.LB_BC_VELOCITY_INLET:
+            d["corner_state"] = self.get_corner_state()
         return d
 
     def save_checkpoint(self, path):
@@ -288,6 +290,20 @@ class Simulation(object):
         self.set_obstacle_mask(d["mask"] if d["mask"].size else None)
         self.set_fields(d["rho"], d["u"], d["v"])
         self.set_f(d["f"])
+        if self.bc_mode == _native.LB_BC_VELOCITY_INLET:
+            self.set_corner_state(d["corner_state"])           # (after set_f, which resets them to f's own corners)
+
+    def get_corner_state(self):
+        """bc='velocity_inlet': the eight corner links no kernel of that rule set writes (include/lb_hip.h)."""
+        out = np.zeros(8, np.float32)
+        check(self._lib.lb_get_corner_state(self._h, out.ctypes.data))
+        return out
+
+    def set_corner_state(self, values):
+        v = np.ascontiguousarray(values, np.float32)
+        if v.shape != (8,):
+            raise ValueError("corner state = 8 floats")
+        check(self._lib.lb_set_corner_state(self._h, v.ctypes.data))
 
     @classmethod
     def from_checkpoint(cls, path, device=0):

@@ -169,9 +169,12 @@ class DistributedSlab(_SlabSet):
         self.transport = transport
         make = engine_factory or _default_engine
         m = None if obstacle_mask is None else self._cut(obstacle_mask, self.y0, self.h)
+        self._mask_local = m
         if device is None:
             import os
             device = int(os.environ.get("LOCAL_RANK", "0")) if engine_factory is None else 0
+        self.omega, self._engine_kw = omega, dict(kw)
+        self._has_mask = obstacle_mask is not None
         self.engine = make(nx=nx, ny=ny, omega=omega, bc=bc, obstacle_mask=m, device=device,
                            y0=self.y0, local_ny=self.h, halo=True, **kw)
         if obstacle_mask is not None and hasattr(self.engine, "set_obstacle_mask_halo"):
@@ -314,6 +317,98 @@ class DistributedSlab(_SlabSet):
 
     def get_local_fields(self, which=("f", "feq", "u", "v", "rho")):
         return self.engine.get_fields(which)
+
+    # -- state I/O across ranks (the reference has none) --------------------------------------
+    CHECKPOINT_VERSION = 1
+
+    def save_checkpoint(self, path):
+        """Collective.  `path` becomes a directory: one shard per rank (`shard_0003.npz`: that slab's populations,
+        macroscopic fields and obstacle rows) and `manifest.json` written by rank 0 (grid, boundary family, lattice
+        parameters, the row partition).  Nothing is gathered: every rank writes its own rows."""
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        g = self.engine.get_fields(("f", "rho", "u", "v"))
+        mask = getattr(self.engine, "_mask_host", None)
+        if mask is None and self._has_mask:
+            mask = self._mask_local
+        np.savez(os.path.join(path, "shard_%04d.npz" % self.rank), f=g["f"], rho=g["rho"], u=g["u"], v=g["v"],
+                 mask=(np.zeros((0, 0), np.uint8) if mask is None else (np.asarray(mask) != 0).astype(np.uint8)),
+                 y0=self.y0, h=self.h)
+        if self.rank == 0:
+            man = {"version": self.CHECKPOINT_VERSION, "nx": self.nx, "ny": self.ny, "bc": self.bc if isinstance(self.bc, str) else int(self.bc),
+                   "omega": float(self.omega), "params": {k: float(v) for k, v in self._engine_kw.items() if isinstance(v, (int, float))},
+                   "nranks": self.nranks, "partition_rows": [list(p) for p in self.parts], "has_mask": bool(self._has_mask)}
+            with open(os.path.join(path, "manifest.json"), "w") as fh:
+                json.dump(man, fh, indent=1)
+        self._dist.barrier(group=self.group)
+
+    @staticmethod
+    def read_manifest(path):
+        import json
+        import os
+        with open(os.path.join(path, "manifest.json")) as fh:
+            man = json.load(fh)
+        if man["version"] != DistributedSlab.CHECKPOINT_VERSION:
+            raise ValueError("checkpoint format %r, this build reads %d" % (man["version"], DistributedSlab.CHECKPOINT_VERSION))
+        return man
+
+    def load_checkpoint(self, path):
+        """Collective.  Restore a state written by save_checkpoint -- by ANY number of ranks: every rank re-cuts
+        its own rows [y0, y0+h) out of the shards that overlap them (and the obstacle rows of its neighbours)."""
+        import os
+        man = self.read_manifest(path)
+        if (man["nx"], man["ny"]) != (self.nx, self.ny):
+            raise ValueError("checkpoint is for a %dx%d grid, this run is %dx%d" % (man["nx"], man["ny"], self.nx, self.ny))
+        if _is_periodic(man["bc"]) != self.periodic or str(man["bc"]) != str(self.bc if isinstance(self.bc, str) else int(self.bc)):
+            raise ValueError("checkpoint was written with boundary family %r, this run has %r" % (man["bc"], self.bc))
+        if np.float32(man["omega"]) != np.float32(self.omega):
+            raise ValueError("checkpoint has omega = %r, this run %r" % (man["omega"], self.omega))
+        for k, v in man["params"].items():
+            if k in self._engine_kw and np.float32(self._engine_kw[k]) != np.float32(v):
+                raise ValueError("checkpoint has %s = %r, this run %r" % (k, v, self._engine_kw[k]))
+        lo, hi = self.y0, self.y0 + self.h
+        out = {"f": np.zeros((self.nx, self.h, 9), np.float32, order="F")}
+        for k in ("rho", "u", "v"):
+            out[k] = np.zeros((self.nx, self.h), np.float32, order="F")
+        gmask = np.zeros((self.nx, self.ny), bool) if man["has_mask"] else None
+        for r, (y0, h) in enumerate(man["partition_rows"]):
+            a, b = max(lo, y0), min(hi, y0 + h)
+            if a >= b and gmask is None:
+                continue
+            with np.load(os.path.join(path, "shard_%04d.npz" % r)) as d:
+                if (int(d["y0"]), int(d["h"])) != (y0, h):
+                    raise ValueError("shard %d does not match the manifest" % r)
+                if gmask is not None and d["mask"].size:
+                    gmask[:, y0:y0 + h] = d["mask"] != 0
+                if a < b:
+                    for k in out:
+                        out[k][:, a - lo:b - lo] = d[k][:, a - y0:b - y0]
+        eng = self.engine
+        if hasattr(eng, "set_obstacle_mask"):
+            eng.set_obstacle_mask(None if gmask is None else self._cut(gmask, lo, self.h))
+            if gmask is not None and hasattr(eng, "set_obstacle_mask_halo"):
+                eng.set_obstacle_mask_halo(*self._mask_halo_rows(gmask, lo, self.h, self.ny, self.periodic))
+        elif gmask is not None or self._has_mask:
+            raise ValueError("this engine cannot change its obstacle mask")
+        self._has_mask = gmask is not None
+        self._mask_local = None if gmask is None else self._cut(gmask, lo, self.h)
+        if hasattr(eng, "set_fields"):
+            eng.set_fields(out["rho"], out["u"], out["v"])
+        eng.set_f(out["f"])
+        self._ghosts_valid = False
+        self._dist.barrier(group=self.group)
+
+    @classmethod
+    def from_checkpoint(cls, path, **kw):
+        """Build this rank's slab of a run continued from `path` on the CURRENT process group (any rank count)."""
+        man = cls.read_manifest(path)
+        params = dict(man["params"])
+        params.update(kw)
+        placeholder = np.zeros((man["nx"], man["ny"]), bool) if man["has_mask"] else None
+        slab = cls(man["nx"], man["ny"], man["omega"], bc=man["bc"], obstacle_mask=placeholder, **params)
+        slab.load_checkpoint(path)
+        return slab
 
     def get_fields(self, which=("f", "u", "v", "rho")):
         """Gather the slabs of every rank (all ranks receive the global arrays).  For tests and

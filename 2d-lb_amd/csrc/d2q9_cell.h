@@ -125,7 +125,7 @@ __device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
 // weights, then f (1-omega) + omega feq -- because the rounding of the weights is a *systematic*
 // mass bias (sum_k fl(w_k) = 1 + 7.5e-9); folding omega into the weights would change that bias
 // and make rho drift away from the reference's by ~3e-8 per step in a periodic box.
-__device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
+__device__ __forceinline__ void moments_cell(const Cell &c, float &rho, float &ux, float &uy)
 {
     rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
     // v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division: the three- and four-step kernels are
@@ -133,6 +133,10 @@ __device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, flo
     const float inv = __builtin_amdgcn_rcpf(rho);
     ux = (c.f1 - c.f3 + c.f5 - c.f6 - c.f7 + c.f8) * inv;
     uy = (c.f5 + c.f2 + c.f6 - c.f7 - c.f4 - c.f8) * inv;
+}
+
+__device__ __forceinline__ void equilibrate_cell(Cell &c, float omega, float rho, float ux, float uy)
+{
     const float usq = ux * ux + uy * uy;
     const float base = 1.f - 1.5f * usq;
     const float keep = 1.f - omega;
@@ -148,6 +152,63 @@ __device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, flo
     c.f7 = c.f7 * keep + omega * (r2 * (base - 3.f * p + 4.5f * p * p));
     c.f8 = c.f8 * keep + omega * (r2 * (base + 3.f * m + 4.5f * m * m));
     c.f6 = c.f6 * keep + omega * (r2 * (base - 3.f * m + 4.5f * m * m));
+}
+
+__device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)
+{
+    moments_cell(c, rho, ux, uy);
+    equilibrate_cell(c, omega, rho, ux, uy);
+}
+
+// ---- the reference's second rule set: imposed-speed inlet / outlet, north and south rows sharing their vertical
+// links (D2Q9.cl:263-374, `move_bcs_PeriodicBC_VelocityInlet` / `update_hydro_PeriodicBC_VelocityInlet`) -----------
+// In pull form.  The reference's push `move` never writes the links that would enter from outside the box; after
+// `copy_buffer` they hold whatever f_streamed held there ("stale").  The rules then set, with the post-stream values:
+//   inlet (x = 0, 1 <= y <= ny-2): f1, f5, f8 from the imposed speed;  outlet likewise;
+//   north row: f4, f8, f7 := the values ROW 0 received (streamed out of row 1);  south row: f2, f6, f5 := the values
+//   row ny-1 received (out of row ny-2) -- i.e. the pull of a wall row reads row 1 / ny-2 in place of the row outside
+//   (the kernels' source-row mapping, `wrap_y == 2`), except where THAT link itself entered from outside:
+// which leaves exactly eight links of the four corner cells that nothing ever writes.  They keep the values they had
+// when the populations were last set (lb_set_f / lb_init_pop copy them into `corner`):
+//   corner[0] = f1(0,0)  [1] = f8(0,0)  [2] = f1(0,ny-1)  [3] = f5(0,ny-1)
+//   corner[4] = f3(nx-1,0)  [5] = f7(nx-1,0)  [6] = f3(nx-1,ny-1)  [7] = f6(nx-1,ny-1)
+__device__ __forceinline__ void bc_vel_cell(Cell &c, bool w, bool e, bool s, bool n, float u_w, float u_e,
+                                            const float *corner)
+{
+    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    if (w && !s && !n) {                                   // inlet :290-295
+        const float rho_w = (1.f / (1.f - u_w)) * (f0 + f2 + f4 + 2.f * (f3 + f6 + f7));
+        const float h = 0.5f * (f2 - f4), t = (1.f / 6.f) * rho_w * u_w;
+        c.f1 = f3 + (2.f / 3.f) * rho_w * u_w;
+        c.f5 = f7 - h + t;
+        c.f8 = f6 + h + t;
+    }
+    if (e && !s && !n) {                                   // outlet :297-302
+        const float rho_e = (1.f / (1.f + u_e)) * (f0 + f2 + f4 + 2.f * (f1 + f5 + f8));
+        const float h = 0.5f * (f2 - f4), t = (1.f / 6.f) * rho_e * u_e;
+        c.f3 = f1 - (2.f / 3.f) * rho_e * u_e;
+        c.f6 = f5 + h - t;
+        c.f7 = f8 - h - t;
+    }
+    if (w && s) { c.f1 = corner[0]; c.f8 = corner[1]; c.f5 = corner[3]; }
+    if (w && n) { c.f1 = corner[2]; c.f5 = corner[3]; c.f8 = corner[1]; }
+    if (e && s) { c.f3 = corner[4]; c.f7 = corner[5]; c.f6 = corner[7]; }
+    if (e && n) { c.f3 = corner[6]; c.f6 = corner[7]; c.f7 = corner[5]; }
+}
+
+// D2Q9.cl:323-374: on the inlet / outlet columns the moments are not the plain sums.  rho: the rule's density on
+// the inlet / outlet cells proper (not the corners); u: the imposed speed there, and whatever the u array holds on
+// the corner cells (the kernel never writes it); v: whatever the v array holds, on the whole column (never written).
+// (c: the cell after the boundary rule and the obstacle swap; u_prev, v_prev: the stored fields at this cell.)
+__device__ __forceinline__ void vel_moments_cell(const Cell &c, bool w, bool s, bool n, float u_w, float u_e, float u_prev,
+                                                 float v_prev, float &rho, float &ux, float &uy)
+{
+    ux = u_prev;
+    uy = v_prev;
+    if (!s && !n) {
+        if (w) { rho = (1.f / (1.f - u_w)) * (c.f0 + c.f2 + c.f4 + 2.f * (c.f3 + c.f6 + c.f7)); ux = u_w; }
+        else   { rho = (1.f / (1.f + u_e)) * (c.f0 + c.f2 + c.f4 + 2.f * (c.f1 + c.f5 + c.f8)); ux = u_e; }
+    }
 }
 
 template <bool NT>

@@ -17,11 +17,14 @@ struct StepArgs {
     int nx, ny;            // global grid
     int y0, h;             // slab origin / height
     int row_begin, row_step, row_count;  // local rows visited: row_begin + i*row_step, i < row_count
-    int wrap_y;            // periodic in y inside one slab: wrap the source rows locally
+    int wrap_y;            // 1: periodic in y inside one slab: wrap the source rows locally; 2: VELOCITY_INLET: the wall
+                           //    rows pull from row 1 / ny-2 in place of the row outside (bc_vel_cell)
     int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
     int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
     int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
     float omega, rho_in, rho_out, lid_u, rho0;
+    float u_w, u_e;        // VELOCITY_INLET: imposed speeds
+    const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)
 };
 
 // Pull-stream gather for 4 consecutive cells (x4..x4+3) of local row yl: q[k] = f_k at (x - cx_k,
@@ -95,7 +98,7 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     // stragglers of every launch: -11 % at 8192^2, profiles/r01_ablation.txt.)
     if (BC != LB_BC_PERIODIC) {
         const bool south = (yg == 0), north = (yg == a.ny - 1);
-        bool wall_row = south || north;
+        bool wall_row = (BC != LB_BC_VELOCITY_INLET) && (south || north);   // (that family's wall rows need no rule: their pull is remapped)
         bool first = (x4 == 0);
         bool last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
         const int jl = (a.nx - 1) & 3;
@@ -110,6 +113,7 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
                     const bool w = first && j == 0, e = last && j == jl;
                     if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, south, north, a.rho_in, a.rho_out);
                     if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, south, north, a.lid_u, a.rho0);
+                    if (BC == LB_BC_VELOCITY_INLET) bc_vel_cell(c, w, e, south, north, a.u_w, a.u_e, a.corner);
                     q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
                     q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
                 }
@@ -125,7 +129,19 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
         Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
         if (MASK) bounce_cell(c, mk[j] != 0);
         float rho, ux, uy;
-        relax_cell(c, a.omega, rho, ux, uy);
+        if (BC == LB_BC_VELOCITY_INLET) {
+            // the cell on the inlet / outlet column takes its moments from the rule and the stored fields
+            // (one lane per row; D2Q9.cl:323-374)
+            moments_cell(c, rho, ux, uy);
+            const int x = x4 + j;
+            if (x == 0 || x == a.nx - 1) {
+                const long long o = (long long)(yg - a.y0) * a.pitch + x;
+                vel_moments_cell(c, x == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho, ux, uy);
+            }
+            equilibrate_cell(c, a.omega, rho, ux, uy);
+        } else {
+            relax_cell(c, a.omega, rho, ux, uy);
+        }
         r4[j] = rho; u4[j] = ux; v4[j] = uy;
         q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
         q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
@@ -163,9 +179,12 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
     const int yl = a.row_begin + ri * a.row_step;
     const int yg = a.y0 + yl;
     int ym = yl - 1, yp = yl + 1;          // source rows of the cy=+1 / cy=-1 links
-    if (a.wrap_y) {
+    if (a.wrap_y == 1) {
         if (ym < 0) ym = a.h - 1;
         if (yp >= a.h) yp = 0;
+    } else if (a.wrap_y == 2) {
+        if (ym < 0) ym = a.h - 2;
+        if (yp >= a.h) yp = 1;
     }
     const long long o0 = (long long)yl * a.pitch;       // row start, uniform
     f4a q[9], r4, u4, v4;
@@ -237,6 +256,14 @@ __device__ __forceinline__ f4a from_right(f4a v, float halo, int lane)
 __device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, int &ym, int &yp)
 {
     rr = r; ym = r - 1; yp = r + 1;
+    if (a.wrap_y == 2) {
+        // VELOCITY_INLET: rows 0 and h-1 share their vertical links, i.e. the rows beyond a wall row are the rows on
+        // the far side of the OTHER wall row: row -1 is row h-2, row h is row 1 (period h-1)
+        rr = r < 0 ? r + a.h - 1 : (r >= a.h ? r - a.h + 1 : r);
+        ym = rr - 1 < 0 ? a.h - 2 : rr - 1;
+        yp = rr + 1 >= a.h ? 1 : rr + 1;
+        return true;
+    }
     if (a.wrap_y) {
         rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
         ym = rr - 1 < 0 ? a.h - 1 : rr - 1;
@@ -250,18 +277,23 @@ __device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, in
 
 // Step 1 of the single cell (hx, row rr): the strip's halo cell, executed by one edge lane.  Same
 // arithmetic as collide_row, so the value equals what the neighbouring strip computes for that cell.
+// In two halves so that the loads can be issued a row ahead of their use (k_step4's prefetch):
+// halo_cell_load = the nine populations the cell pulls (+ its obstacle flag; xc = its wrapped column, -1 =
+// outside a walled box: zeros, don't-care), halo_cell_finish = boundary rule, obstacle swap, relaxation.
 template <int BC, bool MASK>
-__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c,
-                                                bool &solid)
+__device__ __forceinline__ void halo_cell_load(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c, bool &solid,
+                                               int &xc)
 {
     solid = false;
-    int xc = hx, xl = hx - 1, xg = hx + 1;
+    xc = hx;
+    int xl = hx - 1, xg = hx + 1;
     if (BC == LB_BC_PERIODIC) {
         xc = hx < 0 ? hx + a.nx : (hx >= a.nx ? hx - a.nx : hx);
         xl = xc - 1 < 0 ? a.nx - 1 : xc - 1;
         xg = xc + 1 >= a.nx ? 0 : xc + 1;
     } else if (hx < 0 || hx >= a.nx) {
         c = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // outside the box: don't-care
+        xc = -1;
         return;
     }
     const long long P = a.pitch, S = a.plane;
@@ -276,18 +308,41 @@ __device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int r
     c.f6 = *lane_ptr(rm + 6 * S, xg);
     c.f7 = *lane_ptr(rp + 7 * S, xg);
     c.f8 = *lane_ptr(rp + 8 * S, xl);
+    if (MASK) solid = *lane_ptr(a.mask + (long long)rr * P, xc) != 0;
+}
+
+template <int BC, bool MASK>
+__device__ __forceinline__ void halo_cell_finish(const StepArgs &a, int xc, int rr, Cell &c, bool solid)
+{
+    if (BC != LB_BC_PERIODIC && xc < 0) return;
     const int yg = a.y0 + rr;
     if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
         const bool w = (xc == 0), e = (xc == a.nx - 1), so = (yg == 0), no = (yg == a.ny - 1);
         if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
         if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
+        if (BC == LB_BC_VELOCITY_INLET && (w || e)) bc_vel_cell(c, w, e, so, no, a.u_w, a.u_e, a.corner);
     }
-    if (MASK) {
-        solid = *lane_ptr(a.mask + (long long)rr * P, xc) != 0;
-        bounce_cell(c, solid);
-    }
+    if (MASK) bounce_cell(c, solid);
     float rho, ux, uy;
-    relax_cell(c, a.omega, rho, ux, uy);
+    if (BC == LB_BC_VELOCITY_INLET) {
+        moments_cell(c, rho, ux, uy);
+        if (xc == 0 || xc == a.nx - 1) {
+            const long long o = (long long)rr * a.pitch + xc;
+            vel_moments_cell(c, xc == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho, ux, uy);
+        }
+        equilibrate_cell(c, a.omega, rho, ux, uy);
+    } else {
+        relax_cell(c, a.omega, rho, ux, uy);
+    }
+}
+
+template <int BC, bool MASK>
+__device__ __forceinline__ void halo_cell_step1(const StepArgs &a, int hx, int rr, int ym, int yp, Cell &c,
+                                                bool &solid)
+{
+    int xc;
+    halo_cell_load<BC, MASK>(a, hx, rr, ym, yp, c, solid, xc);
+    halo_cell_finish<BC, MASK>(a, xc, rr, c, solid);
 }
 
 // Segment i of a launch covers output rows [row_begin + i*seg_stride, +seg_rows) clipped to row_end:

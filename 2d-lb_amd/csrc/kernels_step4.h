@@ -104,6 +104,35 @@ __device__ __forceinline__ void stage_gather(const Window &w, const f4a (&q)[9],
 
 constexpr int STEP4_WAVES = 2;      // waves per workgroup: 2 x 2 windows x 9 KiB = 36 KiB of LDS
 
+// Everything step 1 of one row takes from memory: the nine gathered planes of my four cells, their obstacle
+// flags, and (halo lanes) the raw populations of my halo cell.
+struct Row1 {
+    f4a q[9];
+    uc4 mk;
+    Cell hc;
+    int hxc;            // wrapped column of the halo cell, -1 = outside a walled box
+    int rr;             // local row the data belongs to (wrapped where the box is periodic)
+    bool hsolid, have;
+};
+
+template <int BC, bool MASK>
+__device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool halo1, int hx, Row1 &o)
+{
+    int ym, yp;
+    o.have = step1_rows(a, r, o.rr, ym, yp);
+    o.mk = uc4{0, 0, 0, 0};
+    o.hsolid = false;
+    o.hxc = -1;
+    o.hc = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (o.have) {
+        gather_row<BC, MASK, false>(a, x4, o.rr, ym, yp, o.q, o.mk);
+        if (halo1) halo_cell_load<BC, MASK>(a, hx, o.rr, ym, yp, o.hc, o.hsolid, o.hxc);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.q[k] = f4a{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // Halo lanes.  The three cells beyond each end of the strip are spread over six lanes -- lanes 0,1,2 own
 // the cells at distance 1,2,3 on the left, lanes 63,62,61 those on the right -- so that one scalar-cell
 // call per stage serves all of them at once (six sequential calls by two lanes made the kernel bound by
@@ -112,6 +141,10 @@ constexpr int STEP4_WAVES = 2;      // waves per workgroup: 2 x 2 windows x 9 Ki
 // closer in (`lane_in`; for distance 1 that is the strip's own edge cell, in the same lane), through
 // ds_bpermute, which does not occupy the vector ALU.
 
+// (Hiding the gather's latency inside one wave was tried twice and is not done: loading the next row's 36 registers
+//  a row ahead spills -- the kernel already sits at 221-243 registers, two waves per SIMD -- and touching the next
+//  row's 90 cache lines a row ahead with two one-lane-per-line loads costs more in the texture addresser than the
+//  wait it saves: 243 -> 162 k MLUPS at 8192^2, profiles/r02_experiments.txt.)
 template <int BC, bool MASK, bool MACRO, bool NTS>
 __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a, int strips, int seg_rows, int nsegs,
                                                                int row_end)
@@ -155,23 +188,20 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
 
     for (int r = ya - 3; r <= yb + 2; ++r, ++it) {
         // ---- step 1 of row r (from memory) ---------------------------------------------------------------
-        f4a q1[9], r4, u4, v4;
-        uc4 mk = {0, 0, 0, 0};
-        int rr, ym, yp;
-        const bool have = step1_rows(a, r, rr, ym, yp);
+        Row1 cur;
+        row1_load<BC, MASK>(a, r, x4, halo1, hx, cur);
+        f4a (&q1)[9] = cur.q;
+        f4a r4, u4, v4;
+        const uc4 mk = cur.mk;
+        const bool hsolid = cur.hsolid;
         HaloCell9 n1 = {};                              // stage-1 links of my halo cell in row r
-        bool hsolid = false;
-        if (have) {
-            gather_row<BC, MASK, false>(a, x4, rr, ym, yp, q1, mk);
+        if (cur.have) {
             if (halo1) {
-                Cell c;
-                halo_cell_step1<BC, MASK>(a, hx, rr, ym, yp, c, hsolid);
+                Cell c = cur.hc;
+                halo_cell_finish<BC, MASK>(a, cur.hxc, cur.rr, c, hsolid);
                 n1 = halo_all(c, left);
             }
-            collide_row<BC, MASK>(a, x4, a.y0 + rr, q1, mk, r4, u4, v4);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) q1[k] = f4a{0.f, 0.f, 0.f, 0.f};
+            collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
         }
         // ---- step 2 of row r-1 (window 1, registers) -----------------------------------------------------
         f4a q2[9];

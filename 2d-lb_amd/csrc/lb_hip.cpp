@@ -134,6 +134,7 @@ struct lb_sim {
     int stepping = 0;           // 1 between lb_step_boundary and lb_step_finish
     float *feq = nullptr;       // raw allocation, lazily created
     float *rho = nullptr, *u = nullptr, *v = nullptr;
+    float *vi_corner = nullptr; // VELOCITY_INLET: the eight corner links nothing ever writes (bc_vel_cell), device
     uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
     bool has_mask = false;
     int cu_count = 256;
@@ -179,7 +180,8 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.plane = s->plane; a.pitch = (int)s->pitch;
     a.nx = s->p.nx; a.ny = s->p.ny; a.y0 = s->p.y0; a.h = s->H;
     a.row_begin = row_begin; a.row_step = row_step; a.row_count = row_count;
-    a.wrap_y = (s->p.bc_mode == LB_BC_PERIODIC && !s->multi_slab()) ? 1 : 0;
+    a.wrap_y = (s->p.bc_mode == LB_BC_PERIODIC && !s->multi_slab()) ? 1 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? 2 : 0);
+    a.u_w = s->p.inlet_u; a.u_e = s->p.outlet_u; a.corner = s->vi_corner;
     const bool periodic = (s->p.bc_mode == LB_BC_PERIODIC);
     a.ghost_s = (s->multi_slab() && (periodic || s->p.y0 > 0)) ? 1 : 0;
     a.ghost_n = (s->multi_slab() && (periodic || s->p.y0 + s->H < s->p.ny)) ? 1 : 0;
@@ -257,6 +259,7 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
     switch (s->p.bc_mode) {
     case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro, variant); break;
     case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro, variant); break;
+    case LB_BC_VELOCITY_INLET: launch_step_bc<LB_BC_VELOCITY_INLET>(s, a, grid, block, macro, variant); break;
     default: launch_step_bc<LB_BC_CAVITY>(s, a, grid, block, macro, variant); break;
     }
     HIP_TRY(hipGetLastError());
@@ -292,9 +295,28 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
 #undef LB_LAUNCH2
 }
 
+// The velocity-inlet family: its wall rows exchange links with each other, which one marching pass can follow for two
+// time steps (step 1 reads memory through the remapped source rows) but not for three -- k_step2 only.
+void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs,
+                      int row_end, bool macro, bool nts)
+{
+    const dim3 block(64, 4), grid((items + 3) / 4);
+#define LB_LAUNCHV(MASK, MACRO, NTS) \
+    hipLaunchKernelGGL((k_step2<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end)
+    if (s->has_mask) {
+        if (macro) { if (nts) LB_LAUNCHV(true, true, true); else LB_LAUNCHV(true, true, false); }
+        else       { if (nts) LB_LAUNCHV(true, false, true); else LB_LAUNCHV(true, false, false); }
+    } else {
+        if (macro) { if (nts) LB_LAUNCHV(false, true, true); else LB_LAUNCHV(false, true, false); }
+        else       { if (nts) LB_LAUNCHV(false, false, true); else LB_LAUNCHV(false, false, false); }
+    }
+#undef LB_LAUNCHV
+}
+
 // (h: the height the decision is taken on -- a slab's own, or the smallest of the slabs that must agree)
 bool step3_applicable(const lb_sim *s, int h = -1)
 {
+    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) return false;
     if (h < 0) h = s->H;
     if (s->p.nx < 512 || h < (s->multi_slab() ? 32 : 128)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
@@ -304,6 +326,7 @@ bool step3_applicable(const lb_sim *s, int h = -1)
 // four steps per pass on a whole-grid handle (slabs use it inside the eight-step halo cycle only: cycle_depth)
 bool step4_applicable(const lb_sim *s)
 {
+    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) return false;
     if (s->multi_slab() || s->p.nx < 512 || s->H < 128) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
@@ -312,7 +335,7 @@ bool step4_applicable(const lb_sim *s)
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
 {
-    return !s->multi_slab() && s->p.nx >= 64 && s->H >= 64;
+    return s->p.bc_mode != LB_BC_VELOCITY_INLET && !s->multi_slab() && s->p.nx >= 64 && s->H >= 64;
 }
 
 bool step2_applicable(const lb_sim *s, int h = -1)
@@ -360,6 +383,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     const int items = strips * segs;
     const bool nts = (variant & 1) != 0;
     switch (s->p.bc_mode) {
+    case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts); break;
     case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
@@ -776,7 +800,8 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
-    const Cand cands[] = {{4, 8}, {4, 4}, {4, -1}, {3, 8}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
+    // (k_step4 at 8192^2 on one box: 4 waves per CU 189 k MLUPS, 6: 243 k, 8: 232 k, 12: 210 k -- profiles/r02_experiments.txt)
+    const Cand cands[] = {{4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
     // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1; small grids: 36, so that the single-step candidate
     // runs the way it would (hipGraph replay of 16 launches)
     const int per = small_grid(s) ? 36 : 12;
@@ -837,12 +862,42 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     return used + 1;
 }
 
-// steps a quick (one-round) tuning pass consumes at most: 8 candidates x 2 samples x 12 (36) steps + 1
-int autotune_quick_cost(const lb_sim *s) { return 8 * 2 * (small_grid(s) ? 36 : 12) + 1; }
+// VELOCITY_INLET: where the eight never-written corner links live in a lattice (bc_vel_cell's order): {link, x, y}
+struct CornerLink { int k, x, y; };
+void corner_links(const lb_sim *s, CornerLink (&c)[8])
+{
+    const int X = s->p.nx - 1, Y = s->p.ny - 1;
+    const CornerLink t[8] = {{1, 0, 0}, {8, 0, 0}, {1, 0, Y}, {5, 0, Y}, {3, X, 0}, {7, X, 0}, {3, X, Y}, {6, X, Y}};
+    for (int i = 0; i < 8; ++i) c[i] = t[i];
+}
+// ... copied out of lattice `which` whenever the populations are set as a whole (the reference's f_streamed = f at
+// that moment, opencl_dim.py:323-327), and written back into it before the un-fused boundary phase reads them
+int corners_capture(lb_sim *s, int which)
+{
+    if (s->p.bc_mode != LB_BC_VELOCITY_INLET) return LB_OK;
+    CornerLink c[8];
+    corner_links(s, c);
+    for (int i = 0; i < 8; ++i)
+        HIP_TRY(hipMemcpyAsync(s->vi_corner + i, s->origin(which) + c[i].k * s->plane + (long long)c[i].y * s->pitch + c[i].x,
+                               sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    return LB_OK;
+}
+int corners_patch(lb_sim *s, int which)
+{
+    CornerLink c[8];
+    corner_links(s, c);
+    for (int i = 0; i < 8; ++i)
+        HIP_TRY(hipMemcpyAsync(s->origin(which) + c[i].k * s->plane + (long long)c[i].y * s->pitch + c[i].x, s->vi_corner + i,
+                               sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    return LB_OK;
+}
+
+// steps a quick (one-round) tuning pass consumes at most: 10 candidates x 2 samples x 12 (36) steps + 1
+int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 : 12) + 1; }
 
 bool autotune_applies(const lb_sim *s)
 {
-    return !s->multi_slab() && s->p.semantics == LB_SEM_OPENCL && s->p.bc_mode != LB_BC_VELOCITY_INLET &&
+    return !s->multi_slab() && s->p.semantics == LB_SEM_OPENCL &&
            (step2_applicable(s) || step3_applicable(s) || tile_applicable(s));
 }
 
@@ -939,6 +994,8 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipMalloc(&s->rho, fld_bytes));
     CREATE_TRY(hipMalloc(&s->u, fld_bytes));
     CREATE_TRY(hipMalloc(&s->v, fld_bytes));
+    CREATE_TRY(hipMalloc(&s->vi_corner, 8 * sizeof(float)));
+    CREATE_TRY(hipMemsetAsync(s->vi_corner, 0, 8 * sizeof(float), s->stream));
     CREATE_TRY(hipMalloc(&s->mask_raw, (size_t)s->pitch * (s->H + 2 * MASK_GHOST) + 2 * GUARD));
     s->mask = s->mask_raw + GUARD + MASK_GHOST * s->pitch;
     CREATE_TRY(hipMemsetAsync(s->rho, 0, fld_bytes, s->stream));
@@ -961,7 +1018,7 @@ int lb_destroy(lb_sim *s)
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     drop_graph(s);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf})
+    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
     for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_t0, s->ev_t1})
@@ -1046,6 +1103,8 @@ int lb_set_f(lb_sim *s, const float *f)
     // f_streamed = f (opencl_dim.py:323-327)
     HIP_TRY(hipMemcpyAsync(s->lat[s->cur ^ 1], s->lat[s->cur], sizeof(float) * s->lat_floats,
                            hipMemcpyDeviceToDevice, s->stream));
+    int rc = corners_capture(s, s->cur);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->ghost_depth = 0;
     return LB_OK;
@@ -1061,6 +1120,24 @@ int lb_get_f(lb_sim *s, float *f)
         int rc = copy_plane_d2h(s, f + k * host_plane, s->origin(s->cur) + k * s->plane);
         if (rc) return rc;
     }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LB_OK;
+}
+
+int lb_get_corner_state(lb_sim *s, float *out8)
+{
+    if (!s || !out8) return fail(LB_ERR_ARG, "null argument");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipMemcpyAsync(out8, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return LB_OK;
+}
+
+int lb_set_corner_state(lb_sim *s, const float *in8)
+{
+    if (!s || !in8) return fail(LB_ERR_ARG, "null argument");
+    DeviceGuard guard(s->p.device);
+    HIP_TRY(hipMemcpyAsync(s->vi_corner, in8, 8 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return LB_OK;
 }
@@ -1169,6 +1246,9 @@ int lb_move(lb_sim *s)
     // never-written entries of f_streamed behave exactly like the reference's)
     HIP_TRY(hipMemcpyAsync(s->lat[s->cur], s->lat[s->cur ^ 1], sizeof(float) * s->lat_floats,
                            hipMemcpyDeviceToDevice, s->stream));
+    // VELOCITY_INLET: the eight corner links no phase ever writes are kept apart (fused launches swap the lattices,
+    // so "whatever f_streamed held" would not survive them): put them where the boundary phase reads them
+    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) return corners_patch(s, s->cur);
     return LB_OK;
 }
 
@@ -1253,7 +1333,7 @@ int lb_init_pop(lb_sim *s)
         HIP_TRY(hipMemcpyAsync(s->lat[i], s->feq, sizeof(float) * s->lat_floats, hipMemcpyDeviceToDevice,
                                s->stream));
     s->ghost_depth = 0;
-    return LB_OK;
+    return corners_capture(s, s->cur);
 }
 
 // ---- fused stepping ----------------------------------------------------------------------
@@ -1262,7 +1342,7 @@ int lb_step_boundary(lb_sim *s, int write_macro)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_step_boundary called twice");
     if (s->p.bc_mode == LB_BC_VELOCITY_INLET || s->p.semantics == LB_SEM_CYTHON)
-        return fail(LB_ERR_STATE, "no fused kernel for this boundary family / semantics: use lb_run");
+        return fail(LB_ERR_STATE, "no split step for this boundary family / semantics: use lb_run");
     DeviceGuard guard(s->p.device);
     // local rows 0 and H-1 (one row when H == 1)
     int rc = launch_step(s, 0, s->H > 1 ? s->H - 1 : 1, s->H > 1 ? 2 : 1, write_macro != 0);
@@ -1327,15 +1407,6 @@ int lb_run(lb_sim *s, int n_steps)
     if (s->stepping) return fail(LB_ERR_STATE, "lb_run between lb_step_boundary and lb_step_finish");
     DeviceGuard guard(s->p.device);
     int rc;
-    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) {
-        // un-fused, in the reference's order (opencl_dim.py:380-387 with the overrides of OLD/opencl.py:290-327)
-        for (int it = 0; it < n_steps; ++it) {
-            if ((rc = lb_move(s)) || (rc = lb_move_bcs(s)) || (rc = lb_update_hydro(s)) || (rc = lb_update_feq(s)) ||
-                (rc = lb_collide_particles(s)))
-                return rc;
-        }
-        return LB_OK;
-    }
     if (s->p.semantics == LB_SEM_CYTHON) {
         // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles -- the boundary phase
         // in place (k1_bcs), the other four fused into one pass from the current lattice into the other (k1_step);
@@ -1643,7 +1714,6 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET"};
     const char *kernel = "k_step";
     if (s->p.semantics == LB_SEM_CYTHON) kernel = "k1_bcs + k1_step";
-    else if (s->p.bc_mode == LB_BC_VELOCITY_INLET) kernel = "un-fused phase kernels";
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";

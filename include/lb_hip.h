@@ -52,7 +52,8 @@ typedef enum {
     LB_BC_VELOCITY_INLET = 3  /* D2Q9.cl:263-374: imposed speed inlet_u at x=0 / outlet_u at x=nx-1, north and
                              south rows copy their missing links from the opposite wall row.  Dead code in
                              the reference's `dimensionless` package (only OLD/opencl.py:281-327 launches
-                             it); offered through the un-fused phase kernels only, whole-grid handles. */
+                             it).  Whole-grid handles; lb_run fuses it (one or two time steps per launch),
+                             the phase entry points run it un-fused. */
 } lb_bc_mode;
 
 /* Which of the reference's two (numerically different) paths the handle reproduces.
@@ -113,6 +114,13 @@ int lb_set_f(lb_sim *s, const float *f);       /* [9][H][nx]; also fills f_strea
 int lb_get_f(lb_sim *s, float *f);
 int lb_get_feq(lb_sim *s, float *feq);         /* [9][H][nx] */
 int lb_set_mask(lb_sim *s, const int32_t *mask); /* [H][nx], 1 = solid (opencl_dim.py:468, 502); NULL clears */
+/* VELOCITY_INLET only: the eight corner links that no kernel of that rule set ever writes (the reference's push
+ * `move` drops what would enter from outside the box, D2Q9.cl:151-169, and the rules skip them): they keep the
+ * values f had at the last lb_set_f / lb_init_pop -- in the reference inside its f_streamed buffer.  Order:
+ * f1(0,0), f8(0,0), f1(0,ny-1), f5(0,ny-1), f3(nx-1,0), f7(nx-1,0), f3(nx-1,ny-1), f6(nx-1,ny-1).  A checkpoint
+ * needs them next to f (lb_set_f resets them). */
+int lb_get_corner_state(lb_sim *s, float *out8);
+int lb_set_corner_state(lb_sim *s, const float *in8);
 
 /* ---- the reference's per-phase methods, one kernel each (slow, un-fused;
  *      API and test parity).  Single-slab handles only. ------------------- */
@@ -129,8 +137,8 @@ int lb_init_pop(lb_sim *s);             /* f = f_streamed = feq (device side of 
  *      as many host waits per step) by fused launches that advance one, two or three time steps each
  *      (k_step, k_step2, k_step3, k_step4; results bitwise independent of which) and no host wait.
  *      rho,u,v of the LAST step are stored (they are only observable through get_fields); feq is
- *      rebuilt from them on demand.  Handles with LB_SEM_CYTHON or LB_BC_VELOCITY_INLET run the
- *      un-fused phase kernels in their reference order instead.
+ *      rebuilt from them on demand.  LB_BC_VELOCITY_INLET fuses one or two steps per launch; handles with
+ *      LB_SEM_CYTHON run their boundary phase + one fused pass per step.
  *      Multi-slab handles exchange their halo rows inside lb_run when a communicator is attached
  *      (lb_comm_init), otherwise the caller drives lb_step_boundary / lb_halo_export /
  *      lb_halo_import / lb_step_interior. */
@@ -199,7 +207,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 int lb_autotune(lb_sim *s);
 /* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
  * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
- * variant automatic and the pass (193 steps; 577 on grids <= 768^2) fits into max_steps; returns the number
+ * variant automatic and the pass (241 steps; 721 on grids <= 768^2) fits into max_steps; returns the number
  * of steps advanced, 0 when it did nothing. */
 int lb_autotune_quick(lb_sim *s, int max_steps);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one

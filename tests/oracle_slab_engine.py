@@ -39,8 +39,12 @@ class OracleSlabEngine(object):
         self.feq = z3()
         self.rho, self.u, self.v = (np.zeros((self.rows, nx), np.float32) for _ in range(3))
         self.mask = None
+        self.set_obstacle_mask(obstacle_mask)
+
+    def set_obstacle_mask(self, obstacle_mask):
+        self.mask = None
         if obstacle_mask is not None:
-            m = np.zeros((self.rows, nx), np.int32)
+            m = np.zeros((self.rows, self.nx), np.int32)
             m[self.gs:self.gs + self.h] = (np.asarray(obstacle_mask) != 0).T
             self.mask = m
 

@@ -89,4 +89,6 @@ def test_config1_gpu_cython_path_256_poiseuille(lbhip, oracle):
     # the parabola (start-up profile)
     ua = startup_profile(sim.ny, sim.nx, sim.inlet_rho, sim.lb_viscosity, STEPS)
     assert md(g["u"].mean(axis=0), ua) <= 2e-5
-    assert np.all(g["u"][:, 0] == 0) and np.all(g["u"][:, -1] == 0)          # wall rows: u = v = 0 (cython_dim.pyx:318-321)
+    # wall rows: u = v = 0 (cython_dim.pyx:318-321); the four corner cells then take the inlet / outlet formula (:326-333)
+    assert np.all(g["u"][1:-1, 0] == 0) and np.all(g["u"][1:-1, -1] == 0) and np.all(g["v"][:, 0] == 0)
+    assert md(g["u"][[0, -1]][:, [0, -1]], ref.u[[0, -1]][:, [0, -1]]) <= 5e-6

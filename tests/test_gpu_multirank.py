@@ -54,3 +54,38 @@ def test_bench_spawns_its_own_ranks(lbhip):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "halo via rccl" in line["config"]["workload"]
     assert 0 < line["roofline"]["frac"] <= 1.0
+
+
+def test_distributed_checkpoint_on_the_real_engine_single_rank(lbhip, tmp_path):
+    """DistributedSlab.save_checkpoint / from_checkpoint with the HIP engine behind it (one rank, gloo group,
+    python-driven halo exchange with itself): the resumed run continues bit for bit, obstacle rows of the
+    'neighbour' included.  (The re-cut onto another rank count runs under gloo in tests/test_slabs_gloo.py.)"""
+    import socket
+    import numpy as np
+    import torch.distributed as dist
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.slabs import DistributedSlab
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        nx, ny = 640, 96
+        rng = np.random.default_rng(11)
+        w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+        f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)
+        mask = rng.random((nx, ny)) < 0.03
+        one = Simulation(nx, ny, 1.35, bc="periodic", obstacle_mask=mask)
+        one.set_f(f0)
+        one.run(21)
+        a = DistributedSlab(nx, ny, 1.35, bc="periodic", obstacle_mask=mask, transport="torch", device=0)
+        a.set_f(f0)
+        a.run(9)
+        a.save_checkpoint(str(tmp_path / "ck"))
+        b = DistributedSlab.from_checkpoint(str(tmp_path / "ck"), transport="torch", device=0)
+        b.run(12)
+        g, h = b.get_local_fields(("f", "rho", "u", "v")), one.get_fields(("f", "rho", "u", "v"))
+        for k in g:
+            assert np.array_equal(g[k], h[k]), k
+    finally:
+        dist.destroy_process_group()

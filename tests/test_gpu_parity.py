@@ -548,6 +548,60 @@ def test_velocity_inlet_family_vs_reference_kernels(lbhip, oracle):
     assert_fields_close(c.get_fields(), o.get_fields(), TOLN)
 
 
+@pytest.mark.parametrize("nx,ny,masked", [(45, 23, False), (67, 31, True), (1024, 160, False), (1003, 131, True), (2048, 70, True)])
+def test_velocity_inlet_fused_kernels_vs_oracle_and_unfused(lbhip, oracle, nx, ny, masked):
+    """lb_run on the velocity-inlet family = fused kernels (k_step; k_step2 from nx >= 512, >= 64 rows): against the
+    oracle's restatement of D2Q9.cl:263-374 driven as OLD/opencl.py:281-327 drives it (pinned bit-exact to the executed
+    kernels by o2_velocity_inlet_45x23), against the engine's own un-fused phase sequence, and the two fused kernels
+    against each other bit for bit.  Random initial populations, so that the four corner cells' never-written links
+    (lb_get_corner_state) and the never-written u, v of the inlet / outlet columns matter."""
+    from LB_D2Q9.simulation import Simulation
+    rng = np.random.default_rng(nx + 3 * ny)
+    f0 = _random_state(rng, nx, ny)
+    mask = None
+    if masked:
+        mask = rng.random((nx, ny)) < 0.03
+        mask[0, :] = mask[-1, :] = False
+        mask[:, 0] = mask[:, -1] = False
+    uw, ue, omega = 0.03, 0.028, 1.25
+    u0 = (0.01 * rng.standard_normal((nx, ny))).astype(np.float32)
+    v0 = (0.01 * rng.standard_normal((nx, ny))).astype(np.float32)
+    o = oracle.O2Sim(nx, ny, omega, oracle.BC_VELOCITY_INLET, u_w=uw, u_e=ue, mask=mask)
+    o.set_macro(np.ones((nx, ny)), u0, v0)
+    o.set_f(f0)
+    outs = {}
+    for name, variant in (("single", 0), ("two", 33), ("auto", -1)):
+        s = Simulation(nx, ny, omega, bc="velocity_inlet", inlet_u=uw, outlet_u=ue, obstacle_mask=mask)
+        s.set_variant(variant)
+        if variant == 33 and nx >= 512 and ny >= 64:
+            assert s.steps_per_launch() == 2 and "k_step2" in s.hot_kernel()
+        s.set_fields(np.ones((nx, ny)), u0, v0)
+        s.set_f(f0)
+        s.run(1)
+        if name == "single":
+            o.run(1)
+            assert_fields_close(s.get_fields(), o.get_fields(), TOL1)
+        s.run(7); s.run(4)
+        outs[name] = s.get_fields(("f", "rho", "u", "v"))
+        assert np.array_equal(s.get_corner_state(), np.array([f0[0, 0, 1], f0[0, 0, 8], f0[0, -1, 1], f0[0, -1, 5],
+                                                              f0[-1, 0, 3], f0[-1, 0, 7], f0[-1, -1, 3], f0[-1, -1, 6]]))
+    o.run(11)
+    assert_fields_close(outs["single"], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
+    for k in ("f", "rho", "u", "v"):
+        assert np.array_equal(outs["single"][k], outs["two"][k]), k
+        assert np.array_equal(outs["single"][k], outs["auto"][k]), k
+    # the un-fused phase sequence (opencl_dim.py:380-387 order), also after fused steps have swapped the lattices
+    u = Simulation(nx, ny, omega, bc="velocity_inlet", inlet_u=uw, outlet_u=ue, obstacle_mask=mask)
+    u.set_fields(np.ones((nx, ny)), u0, v0)
+    u.set_f(f0)
+    u.run(3)
+    for _ in range(9):
+        u.move(); u.move_bcs(); u.update_hydro(); u.update_feq(); u.collide_particles()
+    g = u.get_fields(("f", "rho", "u", "v"))
+    for k in g:
+        assert maxdiff(g[k], outs["single"][k]) <= 2e-6, k
+
+
 def test_autotune_is_transparent(lbhip, oracle):
     """lb_autotune times the candidate fused-kernel configurations on live steps; whatever it picks, the
     trajectory is the one the single-step kernel produces (bitwise), also when a long run triggers it."""
@@ -572,9 +626,9 @@ def test_autotune_is_transparent(lbhip, oracle):
     assert np.array_equal(a.get_fields(("f",))["f"], ref.get_fields(("f",))["f"])
     b = Simulation(nx, ny, 1.3, bc="pipe", inlet_rho=1.002, obstacle_mask=mask)
     b.set_f(f0)
-    b.run(600)                                    # long first run (a small grid: >= 584 steps): tunes itself on the way
+    b.run(760)                                    # long blocking first run (a small grid: >= 728 steps): tunes itself on the way
     assert b.steps_per_launch() in (1, 2, 3, 4)
     ref2 = Simulation(nx, ny, 1.3, bc="pipe", inlet_rho=1.002, obstacle_mask=mask)
-    ref2.set_variant(0); ref2.set_f(f0); ref2.run(600)
+    ref2.set_variant(0); ref2.set_f(f0); ref2.run(760)
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(b.get_fields((k,))[k], ref2.get_fields((k,))[k]), k
