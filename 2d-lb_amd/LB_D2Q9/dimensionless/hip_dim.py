@@ -74,19 +74,7 @@ class Pipe_Flow(object):
         self.set_characteristic_length_time()
         self._say('Characteristic L:', self.L)
         self._say('Characteristic T:', self.T)
-        self.W = (np.abs(self.phys_pressure_grad_div_rho) * self.L * self.T) / self.phys_visc
-        self._say('Weinstein number:', self.W)
-
-        # lattice units (:106-120)
-        self.N = N
-        self.delta_x = 1. / N
-        self.delta_t = time_prefactor * self.delta_x ** 2
-        self.ulb = self.delta_t / self.delta_x
-        self._say('u_lb:', self.ulb)
-        self.lb_viscosity = (self.delta_t / self.delta_x ** 2) * (1. / self.W)
-        self.omega = (3 * self.lb_viscosity + 0.5) ** -1.
-        self._say('omega', self.omega)
-        assert self.omega < 2.
+        self._derive_lattice_parameters(N, time_prefactor)
 
         self.lx = self.ly = self.nx = self.ny = None
         self.initialize_grid_dims()
@@ -116,6 +104,22 @@ class Pipe_Flow(object):
         self.init_pop()
 
     # ---- helpers ------------------------------------------------------------------------------
+    def _derive_lattice_parameters(self, N, time_prefactor):
+        """The dimensionless group and the lattice units of the OpenCL class (opencl_dim.py:102-120)."""
+        self.W = (np.abs(self.phys_pressure_grad_div_rho) * self.L * self.T) / self.phys_visc
+        self._say('Weinstein number:', self.W)
+
+        # lattice units (:106-120)
+        self.N = N
+        self.delta_x = 1. / N
+        self.delta_t = time_prefactor * self.delta_x ** 2
+        self.ulb = self.delta_t / self.delta_x
+        self._say('u_lb:', self.ulb)
+        self.lb_viscosity = (self.delta_t / self.delta_x ** 2) * (1. / self.W)
+        self.omega = (3 * self.lb_viscosity + 0.5) ** -1.
+        self._say('omega', self.omega)
+        assert self.omega < 2.
+
     def _say(self, *args):
         if self.verbose:
             print(*args)
@@ -258,7 +262,7 @@ class Pipe_Flow_PeriodicBC_VelocityInlet(Pipe_Flow):
     outlet, north/south rows fed from the opposite wall row.  In the reference only
     ``LB_D2Q9/OLD/opencl.py:281-327`` drives these kernels (its callers in ``dimensionless`` are commented
     out); this class puts the same overrides (``move_bcs``, ``init_hydro``: rho=1, u=u_w, v=0,
-    ``update_hydro``) on the dimensionless constructor.  Runs on the un-fused phase kernels."""
+    ``update_hydro``) on the dimensionless constructor.  ``run`` is fused (one or two time steps per launch)."""
 
     def __init__(self, u_w=0.1, **kwargs):
         self.u_w = u_w

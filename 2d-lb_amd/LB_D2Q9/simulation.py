@@ -63,8 +63,9 @@ class Simulation(object):
         :param obstacle_mask: optional (nx, ny) array, non-zero = solid (bounce-back, D2Q9.cl:398-433).
         :param y0, local_ny: the row slab this object owns (multi-GPU); default = whole grid.
         :param halo: fill the ghost rows through the halo interface even for a whole-grid handle.
-        :param semantics: 'opencl' (D2Q9.cl, fused fast path) or 'cython' (cython_dim.pyx: pipe family,
-               whole grid, un-fused compatibility path); the two reference paths differ at walls and inlets.
+        :param semantics: 'opencl' (D2Q9.cl, fused fast path), 'cython' (cython_dim.pyx: pipe family, whole grid,
+               compatibility path; the two reference paths differ at walls and inlets) or 'd2q9i' (the reference's
+               D2Q9i.cl fork of the OpenCL path: pipe family, whole grid, fused).
         """
         if isinstance(bc, str):
             if bc not in _native.BC_NAMES:
@@ -83,9 +84,10 @@ class Simulation(object):
         p.nx, p.ny, p.y0, p.local_ny = self.nx, self.ny, self.y0, self.local_ny
         p.bc_mode, p.device = bc, self.device
         p.flags = _native.LB_FLAG_HALO if halo else 0
-        if semantics not in ("opencl", "cython"):
-            raise ValueError("semantics must be 'opencl' or 'cython'")
-        p.semantics = _native.LB_SEM_CYTHON if semantics == "cython" else _native.LB_SEM_OPENCL
+        sem = {"opencl": _native.LB_SEM_OPENCL, "cython": _native.LB_SEM_CYTHON, "d2q9i": _native.LB_SEM_OPENCL_D2Q9I}
+        if semantics not in sem:
+            raise ValueError("semantics must be one of %s" % sorted(sem))
+        p.semantics = sem[semantics]
         self.semantics = semantics
         self._halo = bool(halo)
         p.omega = np.float32(omega)

@@ -211,6 +211,54 @@ __device__ __forceinline__ void vel_moments_cell(const Cell &c, bool w, bool s, 
     }
 }
 
+// ---- the reference's "incompressible" fork, LB_D2Q9/D2Q9i.cl (host: dimensionless/opencl_dim_D2Q9i.py) -------------
+// Three routines differ from D2Q9.cl: the inlet / outlet of `move_bcs` (D2Q9i.cl:194-205), `update_hydro` (:90-94:
+// momentum, not divided by rho) and `update_feq` (:58: inner = rho + 3 cu + 4.5 cu^2 - 1.5 usq, still multiplied by
+// w rho).  Restated as the fork has them -- executed faithfully it is unstable (|u| grows ~10x in ten steps from a 2e-4
+// density drop, tests/golden/o2_d2q9i_53x27) --; float arithmetic where the fork's literals are double.
+__device__ __forceinline__ void bc_pipe_i_cell(Cell &c, bool w, bool e, bool s, bool n, float rin, float rout)
+{
+    const float f0 = c.f0, f1 = c.f1, f2 = c.f2, f3 = c.f3, f4 = c.f4, f5 = c.f5, f6 = c.f6, f7 = c.f7, f8 = c.f8;
+    if (w && !s && !n) {                                   // inlet :194-198
+        const float uu = -f0 - f2 - 2.f * f3 - f4 - 2.f * f6 - 2.f * f7 + rin;
+        c.f1 = (1.f / 3.f) * (3.f * f3 + 2.f * uu);
+        c.f5 = (1.f / 6.f) * (-3.f * f2 + 3.f * f4 + 6.f * f7 + uu);
+        c.f8 = (1.f / 6.f) * (3.f * f2 - 3.f * f4 + 6.f * f6 + uu);
+    } else if (e && !s && !n) {                            // outlet :201-205
+        const float uu = f0 + 2.f * f1 + f2 + f4 + 2.f * f5 + 2.f * f8 - rout;
+        c.f3 = (1.f / 3.f) * (3.f * f1 - 2.f * uu);
+        c.f6 = (1.f / 6.f) * (-3.f * f2 + 3.f * f4 + 6.f * f8 - uu);
+        c.f7 = (1.f / 6.f) * (3.f * f2 - 3.f * f4 + 6.f * f5 - uu);
+    } else {
+        bc_pipe_cell(c, w, e, s, n, rin, rout);            // walls and corners: as D2Q9.cl
+    }
+}
+
+__device__ __forceinline__ void moments_i_cell(const Cell &c, float &rho, float &ux, float &uy)
+{
+    rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
+    ux = (c.f1 + c.f5 + c.f8 - c.f6 - c.f3 - c.f7);
+    uy = (c.f6 + c.f2 + c.f5 - c.f7 - c.f4 - c.f8);
+}
+
+__device__ __forceinline__ void equilibrate_i_cell(Cell &c, float omega, float rho, float ux, float uy)
+{
+    const float usq = ux * ux + uy * uy;
+    const float base = rho - 1.5f * usq;
+    const float keep = 1.f - omega;
+    const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+    c.f0 = c.f0 * keep + omega * (r0 * base);
+    c.f1 = c.f1 * keep + omega * (r1 * (base + 3.f * ux + 4.5f * ux * ux));
+    c.f3 = c.f3 * keep + omega * (r1 * (base - 3.f * ux + 4.5f * ux * ux));
+    c.f2 = c.f2 * keep + omega * (r1 * (base + 3.f * uy + 4.5f * uy * uy));
+    c.f4 = c.f4 * keep + omega * (r1 * (base - 3.f * uy + 4.5f * uy * uy));
+    const float p = ux + uy, m = ux - uy;
+    c.f5 = c.f5 * keep + omega * (r2 * (base + 3.f * p + 4.5f * p * p));
+    c.f7 = c.f7 * keep + omega * (r2 * (base - 3.f * p + 4.5f * p * p));
+    c.f8 = c.f8 * keep + omega * (r2 * (base + 3.f * m + 4.5f * m * m));
+    c.f6 = c.f6 * keep + omega * (r2 * (base - 3.f * m + 4.5f * m * m));
+}
+
 template <bool NT>
 __device__ __forceinline__ f4a load4(const float *p)
 {

@@ -27,6 +27,45 @@ struct StepArgs {
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)
 };
 
+// Template value of the PIPE family run with the kernels of the reference's D2Q9i.cl fork (lb_params.semantics =
+// LB_SEM_OPENCL_D2Q9I); not a public lb_bc_mode.
+constexpr int LB_BC_PIPE_I = 4;
+
+// The family's boundary rule for one cell (w, e, s, n: it lies in column 0 / nx-1, row 0 / ny-1).
+template <int BC>
+__device__ __forceinline__ void boundary_rule(const StepArgs &a, Cell &c, bool w, bool e, bool s, bool n)
+{
+    if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, s, n, a.rho_in, a.rho_out);
+    if (BC == LB_BC_PIPE_I) bc_pipe_i_cell(c, w, e, s, n, a.rho_in, a.rho_out);
+    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, s, n, a.lid_u, a.rho0);
+    if (BC == LB_BC_VELOCITY_INLET && (w || e)) bc_vel_cell(c, w, e, s, n, a.u_w, a.u_e, a.corner);
+}
+
+// Obstacle swap, moments (with the family's overrides), equilibrium and relaxation of the cell at column x (wrapped
+// into the box), local row yl -- the one sequence every fused kernel runs on every cell, vector or scalar.
+template <int BC, bool MASK>
+__device__ __forceinline__ void finish_cell(const StepArgs &a, int x, int yl, Cell &c, bool solid, float &rho, float &ux,
+                                            float &uy)
+{
+    if (MASK) bounce_cell(c, solid);
+    if (BC == LB_BC_VELOCITY_INLET) {
+        // the cell on the inlet / outlet column takes its moments from the rule and the stored fields (D2Q9.cl:323-374)
+        moments_cell(c, rho, ux, uy);
+        if (x == 0 || x == a.nx - 1) {
+            const long long o = (long long)yl * a.pitch + x;
+            const int yg = a.y0 + yl;
+            vel_moments_cell(c, x == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho, ux, uy);
+        }
+        equilibrate_cell(c, a.omega, rho, ux, uy);
+    } else if (BC == LB_BC_PIPE_I) {
+        moments_i_cell(c, rho, ux, uy);
+        if (MASK && solid) { ux = 0.f; uy = 0.f; }      // opencl_dim_D2Q9i.py:494-503: u, v re-zeroed in the obstacle every step
+        equilibrate_i_cell(c, a.omega, rho, ux, uy);
+    } else {
+        relax_cell(c, a.omega, rho, ux, uy);
+    }
+}
+
 // Pull-stream gather for 4 consecutive cells (x4..x4+3) of local row yl: q[k] = f_k at (x - cx_k,
 // y - cy_k) of the source lattice.  ym / yp are the source rows of the cy=+1 / cy=-1 links (already
 // wrapped by the caller where the box is periodic in y within this slab).
@@ -111,9 +150,7 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
                 if (wall_row || (first && j == 0) || (last && j == jl)) {
                     Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
                     const bool w = first && j == 0, e = last && j == jl;
-                    if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, south, north, a.rho_in, a.rho_out);
-                    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, south, north, a.lid_u, a.rho0);
-                    if (BC == LB_BC_VELOCITY_INLET) bc_vel_cell(c, w, e, south, north, a.u_w, a.u_e, a.corner);
+                    boundary_rule<BC>(a, c, w, e, south, north);
                     q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
                     q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
                 }
@@ -127,21 +164,8 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-        if (MASK) bounce_cell(c, mk[j] != 0);
         float rho, ux, uy;
-        if (BC == LB_BC_VELOCITY_INLET) {
-            // the cell on the inlet / outlet column takes its moments from the rule and the stored fields
-            // (one lane per row; D2Q9.cl:323-374)
-            moments_cell(c, rho, ux, uy);
-            const int x = x4 + j;
-            if (x == 0 || x == a.nx - 1) {
-                const long long o = (long long)(yg - a.y0) * a.pitch + x;
-                vel_moments_cell(c, x == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho, ux, uy);
-            }
-            equilibrate_cell(c, a.omega, rho, ux, uy);
-        } else {
-            relax_cell(c, a.omega, rho, ux, uy);
-        }
+        finish_cell<BC, MASK>(a, x4 + j, yg - a.y0, c, mk[j] != 0, rho, ux, uy);
         r4[j] = rho; u4[j] = ux; v4[j] = uy;
         q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
         q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
@@ -316,24 +340,10 @@ __device__ __forceinline__ void halo_cell_finish(const StepArgs &a, int xc, int 
 {
     if (BC != LB_BC_PERIODIC && xc < 0) return;
     const int yg = a.y0 + rr;
-    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1)) {
-        const bool w = (xc == 0), e = (xc == a.nx - 1), so = (yg == 0), no = (yg == a.ny - 1);
-        if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
-        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
-        if (BC == LB_BC_VELOCITY_INLET && (w || e)) bc_vel_cell(c, w, e, so, no, a.u_w, a.u_e, a.corner);
-    }
-    if (MASK) bounce_cell(c, solid);
+    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || xc == 0 || xc == a.nx - 1))
+        boundary_rule<BC>(a, c, xc == 0, xc == a.nx - 1, yg == 0, yg == a.ny - 1);
     float rho, ux, uy;
-    if (BC == LB_BC_VELOCITY_INLET) {
-        moments_cell(c, rho, ux, uy);
-        if (xc == 0 || xc == a.nx - 1) {
-            const long long o = (long long)rr * a.pitch + xc;
-            vel_moments_cell(c, xc == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho, ux, uy);
-        }
-        equilibrate_cell(c, a.omega, rho, ux, uy);
-    } else {
-        relax_cell(c, a.omega, rho, ux, uy);
-    }
+    finish_cell<BC, MASK>(a, xc, rr, c, solid, rho, ux, uy);
 }
 
 template <int BC, bool MASK>
@@ -610,14 +620,10 @@ __global__ __launch_bounds__(256, 2) void k_step3(const StepArgs a, int strips, 
                 c.f8 = left ? am : bm; c.f7 = left ? bm : am;
                 if (hxi_in) {
                     const int yg = a.y0 + r2;
-                    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1)) {
-                        const bool w = (hxi_c == 0), e = (hxi_c == a.nx - 1), so = (yg == 0), no = (yg == a.ny - 1);
-                        if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
-                        if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
-                    }
-                    if (MASK) bounce_cell(c, (mhist & 0x40u) != 0);
+                    if (BC != LB_BC_PERIODIC && (yg == 0 || yg == a.ny - 1 || hxi_c == 0 || hxi_c == a.nx - 1))
+                        boundary_rule<BC>(a, c, hxi_c == 0, hxi_c == a.nx - 1, yg == 0, yg == a.ny - 1);
                     float rho, ux, uy;
-                    relax_cell(c, a.omega, rho, ux, uy);
+                    finish_cell<BC, MASK>(a, hxi_c, r2, c, (mhist & 0x40u) != 0, rho, ux, uy);
                 }
                 h2_new = halo_links(c, left);
             }

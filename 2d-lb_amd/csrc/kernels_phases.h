@@ -46,6 +46,7 @@ __global__ void k_bcs(const PhaseArgs a)
     if (x == 0 || x == a.nx - 1 || y == 0 || y == a.ny - 1) {
         const bool w = (x == 0), e = (x == a.nx - 1), so = (y == 0), no = (y == a.ny - 1);
         if (a.bc == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
+        if (a.bc == LB_BC_PIPE_I) bc_pipe_i_cell(c, w, e, so, no, a.rho_in, a.rho_out);
         if (a.bc == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
     }
     bounce_cell(c, a.mask && a.mask[o]);
@@ -66,6 +67,32 @@ __global__ void k_hydro(const PhaseArgs a)   // D2Q9.cl:67-100
     a.rho[o] = rho;
     a.u[o] = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) * inv;
     a.v[o] = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
+}
+
+__global__ void k_hydro_i(const PhaseArgs a)   // D2Q9i.cl:67-97
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    const float *f = a.f + o;
+    const Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
+    float rho, ux, uy;
+    moments_i_cell(c, rho, ux, uy);
+    a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+}
+
+__global__ void k_feq_i(const PhaseArgs a)     // D2Q9i.cl:2-64
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const long long o = (long long)y * a.pitch + x;
+    const float rho = a.rho[o], ux = a.u[o], uy = a.v[o];
+    const float usq = ux * ux + uy * uy;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float cu = d_cx[k] * ux + d_cy[k] * uy;
+        a.feq[k * a.plane + o] = d_w[k] * rho * (rho + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
+    }
 }
 
 // equilibrium of link k (one expression, shared by k_feq and the fused Cython-path step so that both round alike)

@@ -61,14 +61,10 @@ __device__ __forceinline__ void halo_cell_next(const StepArgs &a, int hx, int yg
     else if (hx < 0 || hx >= a.nx) return;              // outside the box: don't-care
     if (BC != LB_BC_PERIODIC) {
         const bool w = (xc == 0), e = (xc == a.nx - 1), so = (yg == 0), no = (yg == a.ny - 1);
-        if (w || e || so || no) {
-            if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, so, no, a.rho_in, a.rho_out);
-            if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
-        }
+        if (w || e || so || no) boundary_rule<BC>(a, c, w, e, so, no);
     }
-    if (MASK) bounce_cell(c, solid);
     float rho, ux, uy;
-    relax_cell(c, a.omega, rho, ux, uy);
+    finish_cell<BC, MASK>(a, xc, yg - a.y0, c, solid, rho, ux, uy);
 }
 
 // the LDS-resident window: slots 0,1,2 = links 0,1,3 of the previous row; 3..5 / 6..8 = links 2,5,6 of the

@@ -118,12 +118,10 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         q.f8 = lds[8][c + TILE_L - 1];
         if (decltype(wall)::value) {
             const bool w = (gx == 0), e = (gx == a.nx - 1), so = (gy == 0), no = (gy == a.ny - 1);
-            if (BC == LB_BC_PIPE) bc_pipe_cell(q, w, e, so, no, a.rho_in, a.rho_out);
-            if (BC == LB_BC_CAVITY) bc_cavity_cell(q, w, e, so, no, a.lid_u, a.rho0);
+            boundary_rule<BC>(a, q, w, e, so, no);
         }
-        if (MASK) bounce_cell(q, lmask[c] != 0);
         float rho, ux, uy;
-        relax_cell(q, a.omega, rho, ux, uy);
+        finish_cell<BC, MASK>(a, gx, gy - a.y0, q, MASK && lmask[c] != 0, rho, ux, uy);
         if (last && mine) {
             const long long o = (long long)gy * P + gx;
             float *d = a.dst + o;

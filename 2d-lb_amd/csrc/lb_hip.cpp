@@ -170,6 +170,9 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// boundary family as the kernels' template argument (the D2Q9i fork is the PIPE family with its own cell routines)
+int kernel_bc(const lb_sim *s) { return s->p.semantics == LB_SEM_OPENCL_D2Q9I ? LB_BC_PIPE_I : s->p.bc_mode; }
+
 StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
 {
     StepArgs a;
@@ -256,7 +259,8 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
     dim3 block(64 * waves_x, rows_per_block);
     const int lanes_x = (int)(s->pitch / 4);
     dim3 grid((lanes_x + block.x - 1) / block.x, (row_count + rows_per_block - 1) / rows_per_block);
-    switch (s->p.bc_mode) {
+    switch (kernel_bc(s)) {
+    case LB_BC_PIPE_I: launch_step_bc<LB_BC_PIPE_I>(s, a, grid, block, macro, variant); break;
     case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro, variant); break;
     case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro, variant); break;
     case LB_BC_VELOCITY_INLET: launch_step_bc<LB_BC_VELOCITY_INLET>(s, a, grid, block, macro, variant); break;
@@ -335,7 +339,8 @@ bool step4_applicable(const lb_sim *s)
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
 {
-    return s->p.bc_mode != LB_BC_VELOCITY_INLET && !s->multi_slab() && s->p.nx >= 64 && s->H >= 64;
+    return s->p.bc_mode != LB_BC_VELOCITY_INLET && s->p.semantics != LB_SEM_OPENCL_D2Q9I && !s->multi_slab() &&
+           s->p.nx >= 64 && s->H >= 64;
 }
 
 bool step2_applicable(const lb_sim *s, int h = -1)
@@ -382,7 +387,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     }
     const int items = strips * segs;
     const bool nts = (variant & 1) != 0;
-    switch (s->p.bc_mode) {
+    switch (kernel_bc(s)) {
+    case LB_BC_PIPE_I: launch_step2_bc<LB_BC_PIPE_I>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts); break;
     case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
@@ -487,7 +493,7 @@ PhaseArgs phase_args(const lb_sim *s)
     a.feq = s->feq ? s->feq_origin() : nullptr;
     a.rho = s->rho; a.u = s->u; a.v = s->v;
     a.mask = s->has_mask ? s->mask : nullptr;
-    a.plane = s->plane; a.pitch = (int)s->pitch; a.nx = s->p.nx; a.ny = s->p.ny; a.bc = s->p.bc_mode;
+    a.plane = s->plane; a.pitch = (int)s->pitch; a.nx = s->p.nx; a.ny = s->p.ny; a.bc = kernel_bc(s);
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     a.u_w = s->p.inlet_u; a.u_e = s->p.outlet_u;
@@ -897,7 +903,7 @@ int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 :
 
 bool autotune_applies(const lb_sim *s)
 {
-    return !s->multi_slab() && s->p.semantics == LB_SEM_OPENCL &&
+    return !s->multi_slab() && s->p.semantics != LB_SEM_CYTHON &&
            (step2_applicable(s) || step3_applicable(s) || tile_applicable(s));
 }
 
@@ -934,8 +940,11 @@ int lb_create(const lb_params *p, lb_sim **out)
     for (int r : p->reserved)
         if (r != 0) return fail(LB_ERR_ARG, "reserved fields must be zero");
     if (p->flags & ~LB_FLAG_HALO) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
-    if (p->semantics != LB_SEM_OPENCL && p->semantics != LB_SEM_CYTHON)
+    if (p->semantics != LB_SEM_OPENCL && p->semantics != LB_SEM_CYTHON && p->semantics != LB_SEM_OPENCL_D2Q9I)
         return fail(LB_ERR_ARG, "unknown semantics %d", p->semantics);
+    if (p->semantics == LB_SEM_OPENCL_D2Q9I &&
+        (p->bc_mode != LB_BC_PIPE || p->local_ny != p->ny || (p->flags & LB_FLAG_HALO)))
+        return fail(LB_ERR_ARG, "the D2Q9i fork exists for whole-grid pipe-flow handles only");
     if (p->semantics == LB_SEM_CYTHON &&
         (p->bc_mode != LB_BC_PIPE || p->local_ny != p->ny || (p->flags & LB_FLAG_HALO)))
         return fail(LB_ERR_ARG, "Cython-path semantics exist for whole-grid pipe-flow handles only");
@@ -1280,7 +1289,12 @@ int lb_update_hydro(lb_sim *s)
         hipLaunchKernelGGL(k1_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     else if (s->p.bc_mode == LB_BC_VELOCITY_INLET)
         hipLaunchKernelGGL(k_hydro_vel, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
-    else
+    else if (s->p.semantics == LB_SEM_OPENCL_D2Q9I) {
+        // D2Q9i.cl:67-97 + the cylinder class's override (opencl_dim_D2Q9i.py:494-503): u, v zeroed in the obstacle
+        hipLaunchKernelGGL(k_hydro_i, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+        HIP_TRY(hipGetLastError());
+        if (s->has_mask) hipLaunchKernelGGL(k_zero_vel, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+    } else
         hipLaunchKernelGGL(k_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
     return LB_OK;   // feq keeps its previous content, as the reference's feq buffer does
@@ -1294,7 +1308,10 @@ int lb_update_feq(lb_sim *s)
     if (rc) return rc;
     PhaseArgs a = phase_args(s);
     a.ny = s->H;   // rho,u,v are local: valid for slabs too
-    hipLaunchKernelGGL(k_feq, dim3((s->p.nx + 255) / 256, s->H, 1), dim3(256), 0, s->stream, a);
+    if (s->p.semantics == LB_SEM_OPENCL_D2Q9I)
+        hipLaunchKernelGGL(k_feq_i, dim3((s->p.nx + 255) / 256, s->H, 1), dim3(256), 0, s->stream, a);
+    else
+        hipLaunchKernelGGL(k_feq, dim3((s->p.nx + 255) / 256, s->H, 1), dim3(256), 0, s->stream, a);
     HIP_TRY(hipGetLastError());
     s->feq_valid = true;
     return LB_OK;
@@ -1711,7 +1728,7 @@ int lb_autotune_quick(lb_sim *s, int max_steps)
 int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
 {
     if (!s || !buf || buflen < 1) return fail(LB_ERR_ARG, "bad argument");
-    static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET"};
+    static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET", "PIPE, D2Q9i"};
     const char *kernel = "k_step";
     if (s->p.semantics == LB_SEM_CYTHON) kernel = "k1_bcs + k1_step";
     else {
@@ -1722,7 +1739,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
         else if (spl == 2) kernel = "k_step2 (marching strips, register window)";
         else kernel = "k_step (one fused pull-stream + collide pass)";
     }
-    snprintf(buf, (size_t)buflen, "%s<%s%s>", kernel, bc_names[s->p.bc_mode], s->has_mask ? ", MASK" : "");
+    snprintf(buf, (size_t)buflen, "%s<%s%s>", kernel, bc_names[kernel_bc(s)], s->has_mask ? ", MASK" : "");
     return LB_OK;
 }
 

@@ -61,10 +61,16 @@ typedef enum {
  * CYTHON: LB_D2Q9/dimensionless/cython_dim.pyx:160-359 -- boundary rules before streaming, bounce-back
  *         walls, restricted in-place streaming, moment overrides; PIPE family, whole-grid handles
  *         (a compatibility path for users of the reference's CPU classes: lb_run launches the boundary
- *         phase + one fused pass per step, the phase entry points one kernel each). */
+ *         phase + one fused pass per step, the phase entry points one kernel each).
+ * OPENCL_D2Q9I: see below. */
 typedef enum {
     LB_SEM_OPENCL = 0,
-    LB_SEM_CYTHON = 1
+    LB_SEM_CYTHON = 1,
+    LB_SEM_OPENCL_D2Q9I = 2   /* LB_D2Q9/D2Q9i.cl driven as dimensionless/opencl_dim_D2Q9i.py does: the "incompressible"
+                                 fork of the OpenCL path -- momentum in place of velocity (D2Q9i.cl:90-94), inner =
+                                 rho + 3 cu + 4.5 cu^2 - 1.5 usq (:58), re-derived inlet / outlet (:194-205), u, v
+                                 re-zeroed in the obstacle every step.  PIPE family, whole-grid handles; fused like the
+                                 OpenCL path.  Restated as the fork has it: it is unstable (tests/golden/o2_d2q9i_53x27). */
 } lb_semantics;
 
 typedef struct {
