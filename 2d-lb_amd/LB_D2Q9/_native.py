@@ -24,7 +24,7 @@ EXPORTS = (
     "lb_move", "lb_move_bcs", "lb_update_hydro", "lb_update_feq", "lb_collide_particles",
     "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_run",
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
-    "lb_halo_floats", "lb_set_mask_halo", "lb_run_group",
+    "lb_halo_floats", "lb_set_mask_halo", "lb_run_group", "lb_run_batch",
     "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
     "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state",
 )
@@ -76,6 +76,7 @@ def lib():
     L.lb_halo_floats.argtypes = [h]
     L.lb_set_mask_halo.argtypes = [h, vp, vp]
     L.lb_run_group.argtypes = [ct.POINTER(h), I, I]
+    L.lb_run_batch.argtypes = [ct.POINTER(h), I, I]
     L.lb_comm_unique_id.argtypes = [vp]
     L.lb_comm_init.argtypes = [h, vp, I, I]
     L.lb_timer_stop.argtypes = [h, fp]

@@ -184,7 +184,7 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
 // FETCH_SIZE = 6/9 planes x 1/8).  Remapping the linear workgroup id so that every XCD sweeps its own
 // contiguous band of rows keeps x-neighbours on one L2.  Only speed depends on it, never results.
 template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS, bool XCD>
-__global__ __launch_bounds__(256) void k_step(const StepArgs a)
+__device__ __forceinline__ void step_body(const StepArgs &a)
 {
     int bx = blockIdx.x, by = blockIdx.y;
     if (XCD) {
@@ -228,6 +228,26 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
         store4<false>(lane_ptr(a.u + o0, x4), u4);
         store4<false>(lane_ptr(a.v + o0, x4), v4);
     }
+}
+
+template <int BC, bool MASK, bool MACRO, bool NTL, bool NTS, bool XCD>
+__global__ __launch_bounds__(256) void k_step(const StepArgs a)
+{
+    step_body<BC, MASK, MACRO, NTL, NTS, XCD>(a);
+}
+
+// Several lattices of one geometry advanced by ONE launch, blockIdx.z = which: the periodic multi-population sets of the
+// reference's research forks (porous_media/single_component.cl:338-375 `move_periodic` streams population `cur_field`
+// of a [jumper][population][y][x] array; here every population is a lattice of its own with its own relaxation rate,
+// and stream + collide are fused as everywhere).  Same cell code as k_step: bitwise equal to separate launches.
+constexpr int BATCH_MAX = 8;
+struct BatchArgs {
+    StepArgs a[BATCH_MAX];
+};
+template <int BC, bool MASK, bool MACRO>
+__global__ __launch_bounds__(256) void k_step_batch(const BatchArgs b)
+{
+    step_body<BC, MASK, MACRO, false, false, false>(b.a[blockIdx.z]);
 }
 
 // ---- two time steps per pass ------------------------------------------------------------------

@@ -1645,6 +1645,57 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
     return LB_OK;
 }
 
+// Population sets: `count` periodic whole-grid lattices of one geometry (one per population of a multi-population
+// model, each with its own omega / mask content) advanced in lock step, ONE launch per time step for all of them.
+int lb_run_batch(lb_sim **sims, int count, int n_steps)
+{
+    if (!sims || count < 1 || count > BATCH_MAX || n_steps < 0)
+        return fail(LB_ERR_ARG, "lb_run_batch takes 1..%d handles and a non-negative step count", BATCH_MAX);
+    for (int i = 0; i < count; ++i) {
+        lb_sim *s = sims[i];
+        if (!s) return fail(LB_ERR_ARG, "null handle in batch");
+        if (s->multi_slab() || s->p.bc_mode != LB_BC_PERIODIC || s->p.semantics != LB_SEM_OPENCL)
+            return fail(LB_ERR_ARG, "batch members must be whole-grid periodic OpenCL-path handles");
+        if (s->p.nx != sims[0]->p.nx || s->p.ny != sims[0]->p.ny || s->p.device != sims[0]->p.device ||
+            s->has_mask != sims[0]->has_mask)
+            return fail(LB_ERR_ARG, "batch members must share grid, device and obstacle-mask presence");
+        if (s->stepping) return fail(LB_ERR_STATE, "lb_run_batch inside a split step");
+        for (int j = 0; j < i; ++j)
+            if (sims[j] == s) return fail(LB_ERR_ARG, "a handle appears twice in the batch");
+    }
+    if (n_steps == 0) return LB_OK;
+    lb_sim *s0 = sims[0];
+    DeviceGuard guard(s0->p.device);
+    // everything is enqueued on the first member's stream, behind whatever the others still have in flight
+    for (int i = 1; i < count; ++i) {
+        HIP_TRY(hipEventRecord(sims[i]->ev_interior, sims[i]->stream));
+        HIP_TRY(hipStreamWaitEvent(s0->stream, sims[i]->ev_interior, 0));
+    }
+    const dim3 block(256, 1);
+    const dim3 grid((unsigned)((s0->pitch / 4 + 255) / 256), (unsigned)s0->H, (unsigned)count);
+    for (int it = 0; it < n_steps; ++it) {
+        BatchArgs b;
+        for (int i = 0; i < count; ++i) b.a[i] = step_args(sims[i], 0, 1, sims[i]->H);
+        const bool macro = (it == n_steps - 1);
+        if (s0->has_mask) {
+            if (macro) hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, true, true>), grid, block, 0, s0->stream, b);
+            else hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, true, false>), grid, block, 0, s0->stream, b);
+        } else {
+            if (macro) hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, false, true>), grid, block, 0, s0->stream, b);
+            else hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, false, false>), grid, block, 0, s0->stream, b);
+        }
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < count; ++i) sims[i]->cur ^= 1;
+    }
+    // the other members' streams see the result
+    HIP_TRY(hipEventRecord(s0->ev_interior, s0->stream));
+    for (int i = 0; i < count; ++i) {
+        if (i) HIP_TRY(hipStreamWaitEvent(sims[i]->stream, s0->ev_interior, 0));
+        sims[i]->feq_valid = false;
+    }
+    return LB_OK;
+}
+
 // ---- RCCL --------------------------------------------------------------------------------
 int lb_comm_available(void) { return rccl_load(); }
 

@@ -180,6 +180,13 @@ int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_
  * device-to-device copies: the multi-GPU schedule and kernels without a second GPU (verification). */
 int lb_run_group(lb_sim **sims, int count, int n_steps);
 
+/* Population sets (the periodic multi-population lattices of the reference's research forks: porous_media/
+ * single_component.cl:338-375 `move_periodic` streams population `cur_field` of a [jumper][population][y][x] array with
+ * periodic wrap; single_component.py:679-751 steps every population per iteration).  `count` (<= 8) whole-grid PERIODIC
+ * handles of one geometry on one device, one per population, each with its own omega, advance n_steps in lock step
+ * with ONE fused launch per time step for all of them.  Bitwise equal to lb_run on each handle. */
+int lb_run_batch(lb_sim **sims, int count, int n_steps);
+
 /* RCCL point-to-point halo exchange over xGMI, one rank per GPU.  Rank r owns
  * slab r; neighbours are r-1 (south) and r+1 (north), wrapping for PERIODIC.
  * unique_id is the 128-byte ncclUniqueId: rank 0 obtains it with
