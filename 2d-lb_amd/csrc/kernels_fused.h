@@ -22,6 +22,7 @@ struct StepArgs {
     int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
     int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
     int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
+    int prio_turns;        // k_step4: the two waves of a SIMD alternate their issue priority row by row
     float omega, rho_in, rho_out, lid_u, rho0;
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)
@@ -96,6 +97,24 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
         return;
     }
 #endif
+    // Periodic x wrap: the lane holding x = 0 / x = nx-1 fetches the one element per plane that its displaced load takes
+    // from the row padding.  These loads are ISSUED FIRST, into temporaries, and merged after the nine plane loads: written
+    // as a patch behind them (q[1].x = ...), each waited for the plane load it overwrites and then cost the wave a second,
+    // serial memory round trip per row -- the strip holding x = nx-1 was the last to finish in every launch of the
+    // marching kernels (tools/wave_timeline.py: 1263 us against 950 us for its neighbours).
+    float p1 = 0.f, p5 = 0.f, p8 = 0.f, w3 = 0.f, w6 = 0.f, w7 = 0.f;
+    const int c = a.nx - 1 - x4;
+    const bool wrap_w = (BC == LB_BC_PERIODIC) && x4 == 0, wrap_e = (BC == LB_BC_PERIODIC) && c >= 0 && c < 4;
+    if (wrap_w) {
+        p1 = s[1 * S + (long long)yl * P + a.nx - 1];
+        p5 = s[5 * S + (long long)ym * P + a.nx - 1];
+        p8 = s[8 * S + (long long)yp * P + a.nx - 1];
+    }
+    if (wrap_e) {
+        w3 = s[3 * S + (long long)yl * P];
+        w6 = s[6 * S + (long long)ym * P];
+        w7 = s[7 * S + (long long)yp * P];
+    }
     q[0] = load4<NTL>(lane_ptr(r0, x4));
     q[1] = load4u<NTL>(lane_ptr(r0 + 1 * S - 1, x4));
     q[2] = load4<NTL>(lane_ptr(rm + 2 * S, x4));
@@ -108,20 +127,15 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
     mk = uc4{0, 0, 0, 0};
     if (MASK) mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)yl * P, x4));
     if (BC == LB_BC_PERIODIC) {
-        // x wrap: the lane holding x=0 / x=nx-1 re-reads the one element that came from the
-        // row padding (wave-divergent, one lane per row).
-        if (x4 == 0) {
-            q[1].x = s[1 * S + (long long)yl * P + a.nx - 1];
-            q[5].x = s[5 * S + (long long)ym * P + a.nx - 1];
-            q[8].x = s[8 * S + (long long)yp * P + a.nx - 1];
-        }
-        const int c = a.nx - 1 - x4;
-        if (c >= 0 && c < 4) {
-            const float w3 = s[3 * S + (long long)yl * P], w6 = s[6 * S + (long long)ym * P],
-                        w7 = s[7 * S + (long long)yp * P];
+        q[1].x = wrap_w ? p1 : q[1].x;
+        q[5].x = wrap_w ? p5 : q[5].x;
+        q[8].x = wrap_w ? p8 : q[8].x;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j == c) { q[3][j] = w3; q[6][j] = w6; q[7][j] = w7; }
+        for (int j = 0; j < 4; ++j) {
+            const bool hit = wrap_e && j == c;
+            q[3][j] = hit ? w3 : q[3][j];
+            q[6][j] = hit ? w6 : q[6][j];
+            q[7][j] = hit ? w7 : q[7][j];
         }
     }
 }

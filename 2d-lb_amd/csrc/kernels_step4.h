@@ -141,14 +141,18 @@ __device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool
 //  a row ahead spills -- the kernel already sits at 221-243 registers, two waves per SIMD -- and touching the next
 //  row's 90 cache lines a row ahead with two one-lane-per-line loads costs more in the texture addresser than the
 //  wait it saves: 243 -> 162 k MLUPS at 8192^2, profiles/r02_experiments.txt.)
-template <int BC, bool MASK, bool MACRO, bool NTS>
+template <int BC, bool MASK, bool MACRO, bool NTS, bool PF>
 __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a, int strips, int seg_rows, int nsegs,
                                                                int row_end)
 {
     __shared__ f4a lds_win[STEP4_WAVES][2][9][64];
     const int lane = threadIdx.x;
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int item = xcd_item(blockIdx.x, gridDim.x) * STEP4_WAVES + wy;   // (XCD-transposed order, as k_step3)
+    int item_ = xcd_item(blockIdx.x, gridDim.x) * STEP4_WAVES + wy;         // (XCD-transposed order, as k_step3)
+#ifdef LB_DIAG
+    if (a.diag & 8192) item_ ^= 1;                      // experiment: wave 0 of the workgroup takes the odd strip
+#endif
+    const int item = item_;
     const int sx = item % strips, sy = item / strips;
     if (sy >= nsegs) return;
     const int ya = a.row_begin + sy * a.seg_stride;
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     const int lane_in = left ? max(lane - 1, 0) : min(lane + 1, 63);      // owner of the cell one closer in
     const long long S = a.plane;
 
+#ifdef LB_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+#endif
     f4a(*W2)[64] = lds_win[wy][0];
     f4a(*W3)[64] = lds_win[wy][1];
     {
@@ -182,21 +189,48 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     unsigned mhist = 0, hmask = 0;
     int it = 0;
 
+    // PF: the gather of row r+1 is issued before row r is computed, so that a wave does not wait a full memory
+    // latency per row (it spent 25 % of its cycles there: profiles/r02_experiments.txt).  46 more registers: only the
+    // instantiations that stay under 256 without spilling are launched with it (launch_step2_bc).
+    Row1 nxt;
+    if (PF) row1_load<BC, MASK>(a, ya - 3, x4, halo1, hx, nxt);
+    // Two waves share a SIMD, and its arbiters serve the OLDER one first: measured per wave (tools/wave_timeline.py), the
+    // wave in slot 0 of every SIMD finished its 134 rows after ~945 us, the one in slot 1 after ~1190 us, i.e. for the last
+    // fifth of the launch every SIMD ran a single wave.  Priority outranks age, so the two take turns: both read the same
+    // 100 MHz clock at the top of every row and the wave whose slot parity matches bit 13 of it (82 us per turn, ten
+    // rows or so) raises its priority -- complementary at (almost) all times without the waves knowing of each other.
+    const unsigned slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u;       // HW_REG_HW_ID wave_id bit 0
     for (int r = ya - 3; r <= yb + 2; ++r, ++it) {
+        if (a.prio_turns) {
+            const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> a.prio_turns) & 1u;
+            if (turn == slot) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // ---- step 1 of row r (from memory) ---------------------------------------------------------------
         Row1 cur;
-        row1_load<BC, MASK>(a, r, x4, halo1, hx, cur);
+        if (PF) {
+            cur = nxt;
+            if (r < yb + 2) row1_load<BC, MASK>(a, r + 1, x4, halo1, hx, nxt);
+        } else {
+            row1_load<BC, MASK>(a, r, x4, halo1, hx, cur);
+        }
         f4a (&q1)[9] = cur.q;
         f4a r4, u4, v4;
         const uc4 mk = cur.mk;
         const bool hsolid = cur.hsolid;
         HaloCell9 n1 = {};                              // stage-1 links of my halo cell in row r
         if (cur.have) {
+#ifdef LB_DIAG
+            if (!(a.diag & 1024))
+#endif
             if (halo1) {
                 Cell c = cur.hc;
                 halo_cell_finish<BC, MASK>(a, cur.hxc, cur.rr, c, hsolid);
                 n1 = halo_all(c, left);
             }
+#ifdef LB_DIAG
+            if (!(a.diag & 1))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
         }
         // ---- step 2 of row r-1 (window 1, registers) -----------------------------------------------------
@@ -206,20 +240,31 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
             int r2, t0_, t1_;
             (void)step1_rows(a, r - 1, r2, t0_, t1_);
             stage_gather(w1, q1, s1t, n1.tm, lane, q2);   // (lanes 0 / 63 own the innermost cells)
+            const float w1_d3x = w1.d3.x, w1_d1w = w1.d1.w, w1_g6x = w1.g6.x, w1_g5w = w1.g5.w;   // the halo stage's share
+            // every window takes its new row as soon as its old one has been gathered from, not at the end of the
+            // iteration: q1 / q2 / q3 (36 registers each) then die here instead of living through the stages below
+            window_push(w1, q1);
             // toward links of the cell farther out, away links of the cell closer in (all lanes take part)
             Tri tw = {__shfl(s1t.d, lane_out), 0.f, __shfl(s1t.g, lane_out)};
             const float tm_new = __shfl(n1.tm, lane_out);
             float a0 = __shfl(s1a.d, lane_in), ap = __shfl(s1a.g, lane_in), am = __shfl(n1.am, lane_in);
             if (hd == 1) {                              // closer in = my own edge cell
-                a0 = left ? w1.d3.x : w1.d1.w; ap = left ? w1.g6.x : w1.g5.w; am = left ? q1[7].x : q1[8].w;
+                a0 = left ? w1_d3x : w1_d1w; ap = left ? w1_g6x : w1_g5w; am = left ? q1[7].x : q1[8].w;
             }
+#ifdef LB_DIAG
+            if (!(a.diag & 1024))
+#endif
             if (halo2) {
                 Cell c;
                 halo_cell_next<BC, MASK>(a, hx, a.y0 + r2, left, (hmask & 2u) != 0, s1c, n1.cm, tw, tm_new, a0, ap, am, c);
                 n2 = halo_all(c, left);
             }
+#ifdef LB_DIAG
+            if (!(a.diag & 2))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(mhist, 1), r4, u4, v4);
         } else {
+            window_push(w1, q1);
 #pragma unroll
             for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
         }
@@ -232,16 +277,24 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
             Window w2;
             lds_window_load(W2, lane, it, w2);
             stage_gather(w2, q2, s2t, n2.tm, lane, q3);
+            const float e0 = left ? w2.d3.x : w2.d1.w, ep = left ? w2.g6.x : w2.g5.w, em = left ? q2[7].x : q2[8].w;
+            lds_window_push(W2, lane, it, q2);
             Tri tw = {__shfl(s2t.d, lane_out), 0.f, __shfl(s2t.g, lane_out)};
             const float tm_new = __shfl(n2.tm, lane_out);
+#ifdef LB_DIAG
+            if (!(a.diag & 1024))
+#endif
             if (halo3) {
                 Cell c;
-                halo_cell_next<BC, MASK>(a, hx, a.y0 + r3, left, (hmask & 4u) != 0, s2c, n2.cm, tw, tm_new,
-                                         left ? w2.d3.x : w2.d1.w, left ? w2.g6.x : w2.g5.w, left ? q2[7].x : q2[8].w, c);
+                halo_cell_next<BC, MASK>(a, hx, a.y0 + r3, left, (hmask & 4u) != 0, s2c, n2.cm, tw, tm_new, e0, ep, em, c);
                 n3 = halo_all(c, left);
             }
+#ifdef LB_DIAG
+            if (!(a.diag & 4))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(mhist, 2), r4, u4, v4);
         } else {
+            lds_window_push(W2, lane, it, q2);
 #pragma unroll
             for (int k = 0; k < 9; ++k) q3[k] = f4a{0.f, 0.f, 0.f, 0.f};
         }
@@ -253,6 +306,10 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
             lds_window_load(W3, lane, it, w3);
             f4a t[9];
             stage_gather(w3, q3, s3t, n3.tm, lane, t);
+            lds_window_push(W3, lane, it, q3);
+#ifdef LB_DIAG
+            if (!(a.diag & 2048))
+#endif
             collide_row<BC, MASK>(a, x4, a.y0 + r4_, t, mask_bits(mhist, 3), r4, u4, v4);
             if (store_lane) {
                 const long long o = (long long)r4_ * a.pitch;   // row start, uniform
@@ -265,11 +322,10 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
                     store4<false>(lane_ptr(a.v + o, x4), v4);
                 }
             }
+        } else {
+            lds_window_push(W3, lane, it, q3);
         }
-        // ---- slide everything -------------------------------------------------------------------------------
-        window_push(w1, q1);
-        lds_window_push(W2, lane, it, q2);
-        lds_window_push(W3, lane, it, q3);
+        // ---- slide the halo cells' delay lines ---------------------------------------------------------------
         tri_push(s1c, n1.c0, n1.cp); tri_push(s1t, n1.t0, n1.tp); tri_push(s1a, n1.a0, n1.ap);
         tri_push(s2c, n2.c0, n2.cp); tri_push(s2t, n2.t0, n2.tp);
         tri_push(s3t, n3.t0, n3.tp);
@@ -278,6 +334,18 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
             hmask = ((hmask | (hsolid ? 1u : 0u)) << 1) & 0x6u;
         }
     }
+#ifdef LB_DIAG
+    if ((a.diag & 4096) && lane == 0) {
+        // per-wave timeline into the (otherwise unused) rho array: start, end (100 MHz ticks), XCC id, HW id, item
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned *o = reinterpret_cast<unsigned *>(a.rho) + 8 * item;
+        o[0] = (unsigned)diag_t0; o[1] = (unsigned)(diag_t0 >> 32); o[2] = (unsigned)t1; o[3] = (unsigned)(t1 >> 32);
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+        o[6] = (unsigned)item; o[7] = (unsigned)(yb - ya);
+    }
+#endif
 }
 
 }  // namespace

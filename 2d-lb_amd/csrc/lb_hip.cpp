@@ -190,6 +190,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.ghost_n = (s->multi_slab() && (periodic || s->p.y0 + s->H < s->p.ny)) ? 1 : 0;
     a.seg_stride = 0;
     a.diag = s->diag;
+    a.prio_turns = 0;      // (set by launch_step2 from the variant)
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     return a;
@@ -276,12 +277,19 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
                      int nsegs, int row_end, bool macro, bool nts, int depth)
 {
     const int waves = (depth == 4) ? STEP4_WAVES : 4;      // wave-items per workgroup
+    // k_step4 gathers one row ahead where that fits in 256 registers without scratch: the instantiations without an obstacle
+    // mask (+3 % periodic 8192^2, +-0 pipe; with a mask it spills 20-44 B per lane and loses 10 %: profiles/r02_experiments.txt).
+    // Variant bit 10 switches it off (A/B runs).
+    const bool pf = !s->has_mask && !(effective_variant(s) & 1024);
     const dim3 block(64, waves), grid((items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
-        if (depth == 4)                                                                                          \
-            hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
-                               row_end);                                                                         \
+        if (depth == 4 && pf)                                                                                    \
+            hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, true>), grid, block, 0, st, a, strips, seg_rows,   \
+                               nsegs, row_end);                                                                  \
+        else if (depth == 4)                                                                                     \
+            hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips, seg_rows,  \
+                               nsegs, row_end);                                                                  \
         else if (depth == 3)                                                                                     \
             hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
                                row_end);                                                                         \
@@ -387,6 +395,9 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     }
     const int items = strips * segs;
     const bool nts = (variant & 1) != 0;
+    // k_step4: the two waves of a SIMD take turns at the higher issue priority (see the kernel); variant bit 11 = off
+    static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
+    a.prio_turns = (variant & 2048) ? 0 : turn_bit;
     switch (kernel_bc(s)) {
     case LB_BC_PIPE_I: launch_step2_bc<LB_BC_PIPE_I>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts); break;

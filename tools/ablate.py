@@ -28,6 +28,16 @@ def main():
     configs = ((33, "k_step2"), (9, "k_step"))
     if "--step3" in sys.argv:
         configs = ((97, "k_step3"),)
+    if "--step4" in sys.argv:
+        # k_step4 hooks: 1 / 2 / 4 / 2048 = skip the collide of stage 1 / 2 / 3 / 4, 1024 = skip the halo cells' stages
+        pf = 1024 if "--pf" in sys.argv else 0
+        for diag, what in ((0, "full"), (1024, "no halo-cell stages"), (2055, "no collide in any stage"),
+                           (3079, "no collide, no halo cells"), (1, "no stage-1 collide"), (0, "full again")):
+            env = dict(os.environ, LB_LIB=lib, LB_DIAG=str(diag))
+            out = subprocess.run([sys.executable, "-c", CHILD, str(n), str(353 | pf)], env=env, capture_output=True, text=True)
+            val = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "ERR " + out.stderr[-200:]
+            print("%-8s diag=%4d %-28s %s MLUPS-equivalent" % ("k_step4" + ("+pf" if pf else ""), diag, what, val), flush=True)
+        return
     for variant, name in configs:
         for diag, what in ((0, "full"), (1, "no step-1 collide"), (2, "no step-2 collide"), (3, "no collide at all"),
                            (4, "no stores"), (8, "aligned loads"), (11, "no collide, aligned loads"),

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of one k_step4 launch (diagnostic build, LB_DIAG bit 12): when each wave started and ended, on which
+XCD / CU.  Usage (GPU box): python tools/wave_timeline.py [n] [waves_per_cu]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
+os.environ["LB_LIB"] = os.path.join(ROOT, "2d-lb_amd", "LB_D2Q9", "liblbhip_diag.so")
+os.environ["LB_DIAG"] = os.environ.get("LB_DIAG", "4096")
+if len(sys.argv) > 2:
+    os.environ["LB_STEP2_WAVES_PER_CU"] = sys.argv[2]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    from LB_D2Q9.simulation import Simulation
+    from bench import shear_layer
+    sim = Simulation(n, n, 1.7, bc="periodic")
+    sim.set_variant(353)
+    sim.init_equilibrium(*shear_layer(n, n, 0, n))
+    sim.run(8)
+    sim.run(4)                                    # the launch whose timeline is read (no MACRO in the diag build's path: variant 353, 4 = one launch with MACRO though)
+    raw = sim.get_fields(("rho",))["rho"]
+    u = np.ascontiguousarray(raw.T).view(np.uint32).reshape(-1)          # device order: [y][x]
+    # device rows are pitch floats long; host rows nx: with nx % 64 == 0 they coincide
+    strips = (n + 255) // 256
+    wpc = int(os.environ.get("LB_STEP2_WAVES_PER_CU", "8"))
+    cap = 256 * wpc
+    segs = max(cap // strips, 1)
+    seg_rows = max(-(-n // segs), 4)
+    segs = -(-n // seg_rows)
+    items = strips * segs
+    rec = u[:8 * items].reshape(items, 8).astype(np.int64)
+    t0 = rec[:, 0] | (rec[:, 1] << 32)
+    t1 = rec[:, 2] | (rec[:, 3] << 32)
+    ok = (rec[:, 6] == np.arange(items)) & (t1 > t0)
+    print("items", items, "valid records", int(ok.sum()), "segments", segs, "rows per segment", seg_rows)
+    t0, t1, rec = t0[ok], t1[ok], rec[ok]
+    base = t0.min()
+    start, end = (t0 - base) / 100.0, (t1 - base) / 100.0            # microseconds
+    xcc = rec[:, 4] & 15
+    print("launch span %.1f us; wave start: median %.1f max %.1f us; wave end: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f us"
+          % (end.max(), np.median(start), start.max(), end.min(), np.percentile(end, 10), np.median(end),
+             np.percentile(end, 90), end.max()))
+    print("mean residency of a wave slot: %.1f %% of the launch" % (100 * (end - start).mean() / end.max()))
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            print("XCD %d: %4d waves, end median %.1f  p90 %.1f  max %.1f us" % (x, m.sum(), np.median(end[m]), np.percentile(end[m], 90), end[m].max()))
+    hw = rec[:, 5]
+    simd, wave_slot, cu = (hw >> 4) & 3, hw & 15, (hw >> 8) & 15          # HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh[12] se[15:13]
+    for sd in range(4):
+        m = simd == sd
+        if m.any():
+            print("SIMD %d: %4d waves, end median %.1f us; strip parity of its waves: %.2f odd" % (sd, m.sum(), np.median(end[m]), (rec[m, 6] % 2).mean()))
+    for ws in sorted(set(wave_slot.tolist())):
+        m = wave_slot == ws
+        print("wave slot %d: %4d waves, end median %.1f us" % (ws, m.sum(), np.median(end[m])))
+    sx, sy = rec[:, 6] % strips, rec[:, 6] // strips
+    print("end by strip (median us):", " ".join("%.0f" % np.median(end[sx == i]) for i in range(strips)))
+    print("end by segment (median us), first 16:", " ".join("%.0f" % np.median(end[sy == i]) for i in range(min(segs, 16))))
+
+
+if __name__ == "__main__":
+    main()
