@@ -702,30 +702,17 @@ __global__ __launch_bounds__(256, 2) void k_step3(const StepArgs a, int strips, 
     }
 }
 
-// Calibration kernel: plain 16-byte-per-lane copy of n4 float4s.  Known byte count in the same
-// access shape as the fused step, used to (a) correct rocprofv3's FETCH_SIZE on gfx950 and
-// (b) measure the streaming ceiling of the device the bench runs on.
+// Calibration kernel: plain 16-byte-per-lane copy of n4 float4s, ONE float4 per thread and no loop -- the shape that
+// reaches the device's streaming ceiling (6.3 TB/s; grid-stride loops with 8 loads in flight per lane stop at 5.2-5.8 TB/s
+// whatever the grid: tools/copy_bench.hip, profiles/r02_experiments.txt).  Known byte count, used to (a) correct rocprofv3's
+// FETCH_SIZE on gfx950 and (b) measure the streaming ceiling of the device the bench runs on.
 template <bool NT>
 __global__ __launch_bounds__(256) void k_copy4(const f4a *__restrict__ src, f4a *__restrict__ dst, long long n4)
 {
-    // 8 independent 16-byte loads in flight per lane (the fused step has 9)
-    const long long tile = 8LL * blockDim.x;
-    for (long long base = (long long)blockIdx.x * tile; base < n4; base += (long long)gridDim.x * tile) {
-        f4a v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
-            if (i < n4) v[j] = NT ? __builtin_nontemporal_load(src + i) : src[i];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
-            if (i < n4) {
-                if (NT) __builtin_nontemporal_store(v[j], dst + i);
-                else dst[i] = v[j];
-            }
-        }
-    }
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    else dst[i] = src[i];
 }
 
 }  // namespace

@@ -396,8 +396,9 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     }
     int items = strips * segs;
     const bool nts = (variant & 1) != 0;
-    if (depth == 4 && nsegs_fixed == 0 && !(variant & 4096) && segs >= 2 && seg_rows >= 16) {
-        // uneven pairs (k_step4): one workgroup = one strip x two segments, cut at `share` of their rows (variant bit 12 = off)
+    if (depth == 4 && nsegs_fixed == 0 && !(variant & 4096) && segs >= 2 && seg_rows >= 96) {
+        // uneven pairs (k_step4): one workgroup = one strip x two segments, cut at `share` of their rows (variant bit 12 = off).
+        // Long segments only: 8192^2 (128 rows) +2.5..5 %, 4096^2 (32 rows) -5 % (profiles/r02_experiments.txt).
         static const int share_pct = getenv("LB_PAIR_SHARE") ? atoi(getenv("LB_PAIR_SHARE")) : 54;           // tuning knob
         segs = (segs + 1) / 2;                       // blocks of 2 seg_rows rows
         a.pair_big = std::max(1, std::min(2 * seg_rows - 1, (2 * seg_rows * share_pct + 50) / 100));
@@ -1821,7 +1822,7 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)
     const long long n4 = s->lat_floats / 4;
     const f4a *src = reinterpret_cast<const f4a *>(s->lat[s->cur]);
     f4a *dst = reinterpret_cast<f4a *>(s->lat[s->cur ^ 1]);
-    const int grid = 256 * 8;       // 256 CUs x 8 blocks, grid-stride over the rest
+    const unsigned grid = (unsigned)((n4 + 255) / 256);   // one float4 per thread
     if (nontemporal) hipLaunchKernelGGL(k_copy4<true>, dim3(grid), dim3(256), 0, s->stream, src, dst, n4);
     else hipLaunchKernelGGL(k_copy4<false>, dim3(grid), dim3(256), 0, s->stream, src, dst, n4);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,108 @@
+// Streaming-copy yardstick for the HBM roofline (tools/copy_bench.hip; build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 tools/copy_bench.hip -o /tmp/copy_bench && /tmp/copy_bench
+// Copies 2.4 GB (one 8192^2 lattice) with 16-byte-per-lane accesses in several shapes and prints GB/s (read + written).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// grid-stride, U independent 16-byte loads per lane in flight, then U stores
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy_u(const f4 *__restrict__ src, f4 *__restrict__ dst, long long n4)
+{
+    const long long tile = (long long)U * blockDim.x;
+    for (long long base = (long long)blockIdx.x * tile; base < n4; base += (long long)gridDim.x * tile) {
+        f4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            if (i < n4) v[j] = NTL ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            if (i < n4) { if (NTS) __builtin_nontemporal_store(v[j], dst + i); else dst[i] = v[j]; }
+        }
+    }
+}
+
+// the lattice step's shape without its arithmetic: a wave copies 1 KiB from each of 9 planes of one row, rows dealt to blocks
+template <bool NTS>
+__global__ __launch_bounds__(256) void copy_planes(const f4 *__restrict__ src, f4 *__restrict__ dst, long long plane4, int row4, int rows)
+{
+    const int lane4 = blockIdx.x * blockDim.x + threadIdx.x;     // float4 index inside the row
+    if (lane4 >= row4) return;
+    for (int y = blockIdx.y; y < rows; y += gridDim.y) {
+        f4 v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = src[k * plane4 + (long long)y * row4 + lane4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            f4 *p = dst + k * plane4 + (long long)y * row4 + lane4;
+            if (NTS) __builtin_nontemporal_store(v[k], p); else *p = v[k];
+        }
+    }
+}
+
+template <typename F>
+static double time_ms(F launch, int iters)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch(); launch();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(a));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float t; CK(hipEventElapsedTime(&t, a, b));
+        ms.push_back(t / iters);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[2];
+}
+
+int main()
+{
+    const int n = 8192;
+    const long long plane4 = (long long)n * n / 4, n4 = 9 * plane4;
+    const size_t bytes = (size_t)n4 * 16;
+    f4 *src, *dst;
+    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes));
+    CK(hipMemset(src, 1, bytes)); CK(hipMemset(dst, 0, bytes));
+    const double gb = 2.0 * bytes / 1e9;
+#define RUN(name, ...) do { double ms = time_ms([&] { __VA_ARGS__; }, 10); printf("%-58s %7.1f us  %7.1f GB/s\n", name, ms * 1e3, gb / (ms * 1e-3)); } while (0)
+    for (int blocks : {256 * 2, 256 * 4, 256 * 8, 256 * 16, 256 * 32}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "copy_u<8,plain,plain>   grid %5d", blocks);
+        RUN(nm, hipLaunchKernelGGL((copy_u<8, false, false>), dim3(blocks), dim3(256), 0, 0, src, dst, n4));
+        snprintf(nm, sizeof nm, "copy_u<8,plain,nt>      grid %5d", blocks);
+        RUN(nm, hipLaunchKernelGGL((copy_u<8, false, true>), dim3(blocks), dim3(256), 0, 0, src, dst, n4));
+        snprintf(nm, sizeof nm, "copy_u<8,nt,nt>         grid %5d", blocks);
+        RUN(nm, hipLaunchKernelGGL((copy_u<8, true, true>), dim3(blocks), dim3(256), 0, 0, src, dst, n4));
+        snprintf(nm, sizeof nm, "copy_u<4,plain,nt>      grid %5d", blocks);
+        RUN(nm, hipLaunchKernelGGL((copy_u<4, false, true>), dim3(blocks), dim3(256), 0, 0, src, dst, n4));
+        snprintf(nm, sizeof nm, "copy_u<16,plain,nt>     grid %5d", blocks);
+        RUN(nm, hipLaunchKernelGGL((copy_u<16, false, true>), dim3(blocks), dim3(256), 0, 0, src, dst, n4));
+        snprintf(nm, sizeof nm, "copy_u<2,plain,nt>      grid %5d", blocks);
+        RUN(nm, hipLaunchKernelGGL((copy_u<2, false, true>), dim3(blocks), dim3(256), 0, 0, src, dst, n4));
+    }
+    // one block per (256 float4 of a row, row): no grid-stride loop at all
+    RUN("copy_u<1,plain,nt>      grid = n4/256 (no loop)", hipLaunchKernelGGL((copy_u<1, false, true>), dim3((unsigned)(n4 / 256)), dim3(256), 0, 0, src, dst, n4));
+    RUN("copy_u<4,plain,nt>      grid = n4/1024 (no loop)", hipLaunchKernelGGL((copy_u<4, false, true>), dim3((unsigned)(n4 / 1024)), dim3(256), 0, 0, src, dst, n4));
+    for (int gy : {256, 1024, 8192}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "copy_planes<plain> (9 planes x 1 KiB per wave)  grid.y %4d", gy);
+        RUN(nm, hipLaunchKernelGGL((copy_planes<false>), dim3(n / 4 / 256, gy), dim3(256), 0, 0, src, dst, plane4, n / 4, n));
+        snprintf(nm, sizeof nm, "copy_planes<nt>    (9 planes x 1 KiB per wave)  grid.y %4d", gy);
+        RUN(nm, hipLaunchKernelGGL((copy_planes<true>), dim3(n / 4 / 256, gy), dim3(256), 0, 0, src, dst, plane4, n / 4, n));
+    }
+    RUN("hipMemcpyDtoD", CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
+    return 0;
+}
