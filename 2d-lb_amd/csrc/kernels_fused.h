@@ -23,7 +23,6 @@ struct StepArgs {
     int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
     int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
     int prio_turns;        // k_step4: the two waves of a SIMD alternate their issue priority (bit of the 100 MHz clock)
-    int pair_big;          // k_step4: > 0 = a workgroup cuts 2 seg_rows rows of one strip at this row (uneven pairs)
     float omega, rho_in, rho_out, lid_u, rho0;
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)

@@ -155,25 +155,7 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     const int item = item_;
     int sx = item % strips, ya, yb;
     const unsigned slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u;       // HW_REG_HW_ID wave_id bit 0: my slot on the SIMD
-    if (a.pair_big > 0) {
-        // Uneven pairs.  The two waves of a workgroup share a SIMD and the one placed first (slot 0) is served first by
-        // every arbiter: with equal shares it finished its rows at ~80 % of the other's time and the SIMD then ran one
-        // wave for the rest of the launch (tools/wave_timeline.py).  Here a workgroup owns ONE strip x 2 seg_rows rows and
-        // cuts them in two marches at pair_big rows: the bigger share goes to whichever of its waves sits in slot 0.
-        __shared__ unsigned slot_of_wave0;
-        if (wy == 0 && lane == 0) slot_of_wave0 = slot;
-        __syncthreads();
-        const int b = xcd_item(blockIdx.x, gridDim.x);
-        sx = b % strips;
-        const int y_lo = a.row_begin + (b / strips) * 2 * seg_rows;
-        if (b / strips >= nsegs || y_lo >= row_end) return;
-        const int y_hi = min(y_lo + 2 * seg_rows, row_end);
-        const bool big = (wy == 0) == (slot_of_wave0 == 0);
-        const int cut = min(y_lo + a.pair_big, y_hi);
-        ya = big ? y_lo : cut;
-        yb = big ? cut : y_hi;
-        if (ya >= yb) return;
-    } else {
+    {
         const int sy = item / strips;
         if (sy >= nsegs) return;
         ya = a.row_begin + sy * a.seg_stride;

@@ -191,7 +191,6 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.seg_stride = 0;
     a.diag = s->diag;
     a.prio_turns = 0;      // (set by launch_step2 from the variant)
-    a.pair_big = 0;
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     return a;
@@ -394,16 +393,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         segs = (rows + seg_rows - 1) / seg_rows;
         a.seg_stride = seg_rows;
     }
-    int items = strips * segs;
+    const int items = strips * segs;
     const bool nts = (variant & 1) != 0;
-    if (depth == 4 && nsegs_fixed == 0 && !(variant & 4096) && segs >= 2 && seg_rows >= 96) {
-        // uneven pairs (k_step4): one workgroup = one strip x two segments, cut at `share` of their rows (variant bit 12 = off).
-        // Long segments only: 8192^2 (128 rows) +2.5..5 %, 4096^2 (32 rows) -5 % (profiles/r02_experiments.txt).
-        static const int share_pct = getenv("LB_PAIR_SHARE") ? atoi(getenv("LB_PAIR_SHARE")) : 54;           // tuning knob
-        segs = (segs + 1) / 2;                       // blocks of 2 seg_rows rows
-        a.pair_big = std::max(1, std::min(2 * seg_rows - 1, (2 * seg_rows * share_pct + 50) / 100));
-        items = strips * segs * STEP4_WAVES;
-    }
     // k_step4: the two waves of a SIMD take turns at the higher issue priority (see the kernel); variant bit 11 = off
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
