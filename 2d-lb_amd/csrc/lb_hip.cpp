@@ -729,14 +729,17 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
     return rc;
 }
 
-// E1 + C1 (the caller flips cur afterwards); D = depth of the fused kernel (3 or 4)
-int slab_cycle_first(lb_sim *s, int D)
+// E1 + C1 (the caller flips cur afterwards); D = depth of the fused kernel (3 or 4).  last = this launch ends the run:
+// rho,u,v are stored and the ghost rows are not recomputed (nothing will consume them; the MACRO epilogue has no rows
+// outside the slab to write to).
+int slab_cycle_first(lb_sim *s, int D, bool last = false)
 {
     const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
     const StepArgs probe = step_args(s, 0, 1, 1);
-    int rc = launch_bands(s, s->edge_stream, probe.ghost_s ? -D : 0, D, H - D, probe.ghost_n ? H + D : H, false, D);
+    int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D, H - D, (probe.ghost_n && !last) ? H + D : H,
+                          last, D);
     if (rc) return rc;
-    if ((rc = launch_step2(s, s->stream, D, H - D, false, 0, 0, 0, 2 * strips, D))) return rc;
+    if ((rc = launch_step2(s, s->stream, D, H - D, last, 0, 0, 0, 2 * strips, D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
@@ -1466,10 +1469,15 @@ int lb_run(lb_sim *s, int n_steps)
     int left = n_steps;
     const int hmin = s->min_h > 0 ? s->min_h : s->H;     // all ranks decide on the same height
     const int D = cycle_depth(s, hmin);
-    if (D && left >= 2 * D) {
-        // 2D-step cycles (see slab_cycle_first); whatever is left over runs launch by launch below
+    if (D && left >= D) {
+        // 2D-step cycles (see slab_cycle_first), then -- D <= left < 2D -- one lone first half (D steps out of D-deep
+        // ghosts: e.g. 20 steps = two eight-step cycles + one four-step launch); what is left after that (< D steps) runs
+        // launch by launch below.  One deep exchange serves both.
         const HaloTables &T = cycle_halo(D);
-        if (s->ghost_depth < 2 * D && (rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
+        if (s->ghost_depth < (left >= 2 * D ? 2 * D : D)) {
+            if ((rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
+            s->ghost_depth = 2 * D;
+        }
         for (; left >= 2 * D; left -= 2 * D) {
             if ((rc = slab_cycle_first(s, D))) return rc;
             s->cur ^= 1;
@@ -1477,8 +1485,18 @@ int lb_run(lb_sim *s, int n_steps)
             s->cur ^= 1;
             if ((rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+            s->ghost_depth = 2 * D;
         }
-        s->ghost_depth = 2 * D;
+        if (left >= D) {
+            const bool last = (left == D);
+            if ((rc = slab_cycle_first(s, D, last))) return rc;
+            HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));      // the edge bands of the new lattice are complete
+            s->cur ^= 1;
+            left -= D;
+            s->ghost_depth = last ? 0 : D;          // rows [-D,0) and [H,H+D) of the new lattice were recomputed on the way
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+            HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
+        }
     }
     if (left > 0 && s->ghost_depth < 3) {
         // ghost rows of the current lattice: exchange once before the first step
@@ -1564,9 +1582,9 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         D = std::min(D, cycle_depth(sims[i], hmin));
     }
     int left = n_steps;
-    if (D && left >= 2 * D) {
+    if (D && left >= D) {
         const HaloTables &T = cycle_halo(D);
-        // The six-step cycle of lb_run with the transport replaced: every member packs its edges on its
+        // The halo cycle of lb_run (full cycles + a lone first half) with the transport replaced: every member packs its edges on its
         // edge stream, the receivers unpack straight from the senders' buffers.
         for (int i = 0; i < count; ++i)
             if (!sims[i]->halo_buf) {
@@ -1611,11 +1629,21 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
             if ((rc = exchange_deep())) return rc;
             for (int i = 0; i < count; ++i) HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_boundary, 0));
         }
+        int depth_after = 2 * D;
+        if (left >= D) {                            // the lone first half (see lb_run)
+            const bool last = (left == D);
+            for (int i = 0; i < count; ++i) {
+                if ((rc = slab_cycle_first(sims[i], D, last))) return rc;
+                sims[i]->cur ^= 1;
+            }
+            left -= D;
+            depth_after = last ? 0 : D;
+        }
         // (verification path: a plain join before whatever follows)
         for (int i = 0; i < count; ++i) {
             HIP_TRY(hipStreamSynchronize(sims[i]->edge_stream));
             HIP_TRY(hipStreamSynchronize(sims[i]->stream));
-            sims[i]->ghost_depth = 2 * D;
+            sims[i]->ghost_depth = depth_after;
             sims[i]->feq_valid = false;
         }
         if (left == 0) return LB_OK;

@@ -321,7 +321,7 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
     one = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask)
     one.set_variant(0)
     one.set_f(f0)
-    one.run(41)
+    one.run(61)
     for variant in (97 | 256, 97, 97 | 128):      # eight-step cycle, six-step cycle, no cycle
         two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
         two.set_variant(variant)
@@ -332,6 +332,7 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
         two.run(6)                                # 1 cycle
         two.run(12)                               # 2 cycles on valid 6-deep ghosts
         two.run(4)
+        two.run(20)                               # the bench block: two eight-step cycles + one lone four-step half (or 3 x 6 + 2)
         a, b = one.get_fields(("f", "rho", "u", "v")), two.get_fields(("f", "rho", "u", "v"))
         for k in a:
             assert np.array_equal(a[k], b[k]), (variant, k)
