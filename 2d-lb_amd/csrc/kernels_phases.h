@@ -358,28 +358,38 @@ struct HaloTable {
     int n;
 };
 
+// One wave moves 1 KiB of a row segment: 16 bytes per lane when nx is a multiple of 4 (row starts and buffer segments are
+// then 16-byte aligned: pitch % 64 == 0), a dword per lane otherwise.  grid = (ceil(nx / (256 * V)), segments, 2 edges).
+template <int V>
 __global__ void k_halo_pack(const float *origin, long long plane, int pitch, int h, int nx, float *buf_n, float *buf_s,
                             const HaloTable neg, const HaloTable pos)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * V, seg = blockIdx.y, north = (blockIdx.z == 0);
     if (x >= nx) return;
     float *buf = north ? buf_n : buf_s;
     if (!buf) return;
     const int k = north ? neg.k[seg] : pos.k[seg];
     const long long row = north ? h + neg.row[seg] : pos.row[seg];
-    buf[(long long)seg * nx + x] = origin[k * plane + row * pitch + x];
+    const float *src = origin + k * plane + row * pitch + x;
+    float *dst = buf + (long long)seg * nx + x;
+    if (V == 4) *reinterpret_cast<f4a *>(dst) = *reinterpret_cast<const f4a *>(src);
+    else *dst = *src;
 }
 
+template <int V>
 __global__ void k_halo_unpack(float *origin, long long plane, int pitch, int h, int nx, const float *buf_s,
                               const float *buf_n, const HaloTable neg, const HaloTable pos)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, seg = blockIdx.y, north = (blockIdx.z == 0);
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * V, seg = blockIdx.y, north = (blockIdx.z == 0);
     if (x >= nx) return;
     const float *buf = north ? buf_n : buf_s;
     if (!buf) return;
     const int k = north ? pos.k[seg] : neg.k[seg];
     const long long row = north ? h + pos.row[seg] : neg.row[seg];
-    origin[k * plane + row * pitch + x] = buf[(long long)seg * nx + x];
+    float *dst = origin + k * plane + row * pitch + x;
+    const float *src = buf + (long long)seg * nx + x;
+    if (V == 4) *reinterpret_cast<f4a *>(dst) = *reinterpret_cast<const f4a *>(src);
+    else *dst = *src;
 }
 
 }  // namespace

@@ -604,18 +604,28 @@ float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
 int halo_pack(lb_sim *s, int which, hipStream_t q, const HaloTables &T, bool to_north, bool to_south)
 {
     const size_t n = (size_t)T.n * s->p.nx;
-    const dim3 grid((s->p.nx + 255) / 256, T.n, 2);
-    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->pitch,
-                       s->H, s->p.nx, to_north ? s->halo_buf : nullptr, to_south ? s->halo_buf + n : nullptr,
-                       T.device(true), T.device(false));
+    const bool vec = (s->p.nx % 4) == 0;
+    const dim3 grid((s->p.nx + (vec ? 1023 : 255)) / (vec ? 1024 : 256), T.n, 2);
+    float *bn = to_north ? s->halo_buf : nullptr, *bs = to_south ? s->halo_buf + n : nullptr;
+    if (vec)
+        hipLaunchKernelGGL(k_halo_pack<4>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->pitch,
+                           s->H, s->p.nx, bn, bs, T.device(true), T.device(false));
+    else
+        hipLaunchKernelGGL(k_halo_pack<1>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->pitch,
+                           s->H, s->p.nx, bn, bs, T.device(true), T.device(false));
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
 int halo_unpack(lb_sim *s, int which, hipStream_t q, const HaloTables &T, const float *from_south, const float *from_north)
 {
-    const dim3 grid((s->p.nx + 255) / 256, T.n, 2);
-    hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch, s->H, s->p.nx,
-                       from_south, from_north, T.device(true), T.device(false));
+    const bool vec = (s->p.nx % 4) == 0;
+    const dim3 grid((s->p.nx + (vec ? 1023 : 255)) / (vec ? 1024 : 256), T.n, 2);
+    if (vec)
+        hipLaunchKernelGGL(k_halo_unpack<4>, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch, s->H, s->p.nx,
+                           from_south, from_north, T.device(true), T.device(false));
+    else
+        hipLaunchKernelGGL(k_halo_unpack<1>, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch, s->H, s->p.nx,
+                           from_south, from_north, T.device(true), T.device(false));
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
