@@ -137,10 +137,9 @@ __device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool
 // closer in (`lane_in`; for distance 1 that is the strip's own edge cell, in the same lane), through
 // ds_bpermute, which does not occupy the vector ALU.
 
-// (Hiding the gather's latency inside one wave was tried twice and is not done: loading the next row's 36 registers
-//  a row ahead spills -- the kernel already sits at 221-243 registers, two waves per SIMD -- and touching the next
-//  row's 90 cache lines a row ahead with two one-lane-per-line loads costs more in the texture addresser than the
-//  wait it saves: 243 -> 162 k MLUPS at 8192^2, profiles/r02_experiments.txt.)
+// (Touching the next row's 90 cache lines a row ahead with two one-lane-per-line loads, instead of the register prefetch
+//  PF below, costs more in the texture addresser than the wait it saves: 243 -> 162 k MLUPS at 8192^2,
+//  profiles/r02_experiments.txt.)
 template <int BC, bool MASK, bool MACRO, bool NTS, bool PF>
 __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a, int strips, int seg_rows, int nsegs,
                                                                int row_end)

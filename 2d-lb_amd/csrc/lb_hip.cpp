@@ -284,10 +284,11 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
     const dim3 block(64, waves), grid((items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
-        if (depth == 4 && pf)                                                                                    \
-            hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, true>), grid, block, 0, st, a, strips, seg_rows,   \
-                               nsegs, row_end);                                                                  \
-        else if (depth == 4)                                                                                     \
+        if (depth == 4 && pf) {                                                                                  \
+            if constexpr (!(MASK))    /* (the prefetching form is only built where it does not spill) */         \
+                hipLaunchKernelGGL((k_step4<BC, false, MACRO, NTS, true>), grid, block, 0, st, a, strips,        \
+                                   seg_rows, nsegs, row_end);                                                    \
+        } else if (depth == 4)                                                                                   \
             hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips, seg_rows,  \
                                nsegs, row_end);                                                                  \
         else if (depth == 3)                                                                                     \
