@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     // 100 MHz clock at the top of every row and the wave whose slot parity matches bit 13 of it (82 us per turn, ten
     // rows or so) raises its priority -- complementary at (almost) all times without the waves knowing of each other.
     for (int r = ya - 3; r <= yb + 2; ++r, ++it) {
-        if (a.prio_turns) {
+        if (a.prio_turns && (it & 3) == 0) {           // (every fourth row: reading the clock drains the wave's LDS queue)
             const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> a.prio_turns) & 1u;
             if (turn == slot) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);

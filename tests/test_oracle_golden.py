@@ -270,3 +270,27 @@ def test_o2_d2q9i_fork_bit_exact_and_unstable(oracle):
         assert exact(s.get_fields()[k], d["s10_" + k]), k
     assert np.abs(d["s10_u"]).max() > 10 * np.abs(d["s1_u"]).max()        # already running away
     assert np.isnan(d["s60_u"]).any()                                     # the reference execution blew up
+
+
+def test_periodic_family_taylor_green_decay_rate(oracle):
+    """The periodic family is build-defined (the reference's `dimensionless` package has no periodic streaming), so the
+    oracle's [BD] routine is anchored to physics instead: a Taylor-Green vortex must decay with the lattice viscosity
+    nu = (1/omega - 1/2)/3, energy ~ exp(-4 nu k^2 t) (same test on the GPU: tests/test_gpu_physics.py)."""
+    n, U, omega = 64, 0.02, 1.2
+    nu, k = (1. / omega - 0.5) / 3., 2 * np.pi / n
+    x = np.arange(n)[:, None] * np.ones((1, n))
+    y = np.ones((n, 1)) * np.arange(n)[None, :]
+    u0 = U * np.cos(k * x) * np.sin(k * y)
+    v0 = -U * np.sin(k * x) * np.cos(k * y)
+    rho0 = 1. - 0.75 * U * U * (np.cos(2 * k * x) + np.cos(2 * k * y))
+    s = oracle.O2Sim(n, n, omega, oracle.BC_PERIODIC)
+    s.set_macro(rho0, u0, v0)
+    s.update_feq(); s.init_pop()
+    e, t = [], []
+    for steps in (50, 100, 200, 400):
+        s.run(steps - (t[-1] if t else 0))
+        t.append(steps)
+        g = s.get_fields()
+        e.append(float((g["u"].astype(np.float64) ** 2 + g["v"].astype(np.float64) ** 2).mean()))
+    rate = -np.polyfit(np.array(t, float), np.log(np.array(e)), 1)[0]
+    assert rate == pytest.approx(4 * nu * k * k, rel=0.02)
