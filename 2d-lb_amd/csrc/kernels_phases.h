@@ -320,7 +320,9 @@ __global__ void k1_hydro(const PhaseArgs a)
 // One Cython-path time step after its boundary phase, fused: the restricted pull of k1_move, the moments of
 // k1_hydro, the equilibrium of k_feq and the relaxation of k_collide for one cell, from lattice a.f (already through
 // k1_bcs) into lattice a.fs -- the same expressions, hence the same bits as the five un-fused launches, at a
-// fifth of their traffic.  rho, u, v are stored every step (the next boundary phase reads the stored u).
+// fifth of their traffic.  rho, u, v are stored by the last step of a run (MACRO); every step stores u on the inlet /
+// outlet columns, which is all the next boundary phase reads (cython_dim.pyx:217-224).
+template <bool MACRO>
 __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
     const float f7 = a.f[7 * S + ((dn && ri) ? o + P + 1 : o)];
     float rho, ux, uy;
     c1_moments(a, x, y, a.mask && a.mask[o], f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
-    a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+    if (MACRO) { a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy; }
+    else if (x == 0 || x == lx) a.u[o] = ux;
     const float usq = ux * ux + uy * uy;
     const float fk[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
 #pragma unroll

@@ -1456,7 +1456,8 @@ int lb_run(lb_sim *s, int n_steps)
         for (int it = 0; it < n_steps; ++it) {
             hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k1_step, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+            if (it == n_steps - 1) hipLaunchKernelGGL(k1_step<true>, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+            else hipLaunchKernelGGL(k1_step<false>, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
             HIP_TRY(hipGetLastError());
             s->cur ^= 1;
         }

@@ -30,6 +30,27 @@ __global__ __launch_bounds__(256) void copy_u(const f4 *__restrict__ src, f4 *__
     }
 }
 
+// 8 bytes per lane, one float2 per thread, no loop (would narrower marching strips -- 2 cells per lane -- still stream?)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void copy_f2(const f2 *__restrict__ src, f2 *__restrict__ dst, long long n2)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n2) __builtin_nontemporal_store(src[i], dst + i);
+}
+// 9 planes x 512 B per wave (f2 per lane), rows dealt to blocks: the narrow strip's shape
+__global__ __launch_bounds__(256) void copy_planes_f2(const f2 *__restrict__ src, f2 *__restrict__ dst, long long plane2, int row2, int rows)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= row2) return;
+    for (int y = blockIdx.y; y < rows; y += gridDim.y) {
+        f2 v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = src[k * plane2 + (long long)y * row2 + l];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * plane2 + (long long)y * row2 + l);
+    }
+}
+
 // the lattice step's shape without its arithmetic: a wave copies 1 KiB from each of 9 planes of one row, rows dealt to blocks
 template <bool NTS>
 __global__ __launch_bounds__(256) void copy_planes(const f4 *__restrict__ src, f4 *__restrict__ dst, long long plane4, int row4, int rows)
@@ -103,6 +124,8 @@ int main()
         snprintf(nm, sizeof nm, "copy_planes<nt>    (9 planes x 1 KiB per wave)  grid.y %4d", gy);
         RUN(nm, hipLaunchKernelGGL((copy_planes<true>), dim3(n / 4 / 256, gy), dim3(256), 0, 0, src, dst, plane4, n / 4, n));
     }
+    RUN("copy_f2 (8 B per lane, one per thread, no loop)", hipLaunchKernelGGL(copy_f2, dim3((unsigned)(n4 * 2 / 256)), dim3(256), 0, 0, (const f2 *)src, (f2 *)dst, n4 * 2));
+    RUN("copy_planes_f2 (9 planes x 512 B per wave) grid.y 8192", hipLaunchKernelGGL(copy_planes_f2, dim3(n / 2 / 256, 8192), dim3(256), 0, 0, (const f2 *)src, (f2 *)dst, plane4 * 2, n / 2, n));
     RUN("hipMemcpyDtoD", CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
     return 0;
 }
