@@ -116,6 +116,33 @@ def test_config4_shear_layer_8192_four_step_kernel_equals_single_step_kernel_bit
     assert out[0].std() > 0
 
 
+@pytest.mark.parametrize("bc,masked", [("pipe", True), ("cavity", False), ("periodic", True)])
+def test_full_size_families_four_step_kernel_equals_single_step_kernel_bitwise(lbhip, bc, masked):
+    """8192 x 8192 in the other boundary families, with and without an obstacle mask (the instantiations of k_step4 the
+    periodic bench never runs: wall rules on the boundary cell, mask history registers, no one-row-ahead gather with a mask):
+    default kernel against the single-step kernel on the populations, bit for bit, 4 + 4 + 3 steps."""
+    from LB_D2Q9.simulation import Simulation
+    import bench
+    n = 8192
+    mask = None
+    if masked:
+        mask = np.random.default_rng(5).random((n, n)) < 0.01
+        if bc != "periodic":
+            mask[0, :] = mask[-1, :] = False
+            mask[:, 0] = mask[:, -1] = False
+    out = []
+    for variant in (-1, 9):
+        sim = Simulation(n, n, 1.6, bc=bc, inlet_rho=1.0005, lid_u=0.05, obstacle_mask=mask)
+        sim.set_variant(variant)
+        assert sim.steps_per_launch() == (4 if variant < 0 else 1)
+        sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
+        sim.run(8)
+        sim.run(3)
+        out.append(sim.get_fields(("f",))["f"])
+        sim.close()
+    assert np.all(np.isfinite(out[0])) and np.array_equal(out[0], out[1])
+
+
 def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
     """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, four-step kernel, 8-deep halo)
     executed as in-library virtual slabs on one device: bitwise equal to the undivided run."""
