@@ -116,3 +116,20 @@ def test_lid_driven_cavity_re1000_matches_ghia_centre_lines(lbhip):
     v_line = np.interp(GHIA_X, yc, g["v"][:, n // 2].astype(np.float64) / U)
     assert np.abs(u_line[:-1] - GHIA_U_1000[:-1]).max() < 0.025, np.abs(u_line - GHIA_U_1000)
     assert np.abs(v_line - GHIA_V_1000).max() < 0.025, np.abs(v_line - GHIA_V_1000)
+
+
+def test_reference_verification_study_poiseuille_convergence(lbhip):
+    """docs/opencl_dimensionless_verification.ipynb in full (N = 10, 50, 200 run to dimensionless time 10: 999, 25 000 and
+    400 000 steps; pictures/resolution_convergence.png): the deviation from the analytic parabola falls with resolution."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("poiseuille_convergence", os.path.join(ROOT, "examples", "poiseuille_convergence.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.study()
+    assert [r["steps"] for r in res] == [999, 25000, 400000] and [(r["nx"], r["ny"]) for r in res] == [(21, 11), (101, 51), (401, 201)]
+    assert all(r["peak"] == pytest.approx(0.5625) for r in res)           # the notebook's peak velocity
+    e10, e50, e200 = (r["rms"] / r["peak"] for r in res)
+    # measured: 1.23 %, 0.63 %, 0.045 % of the peak velocity
+    assert e10 < 0.02 and e50 < e10 and e200 < e50 / 4 and e200 < 0.002
