@@ -133,3 +133,27 @@ def test_reference_verification_study_poiseuille_convergence(lbhip):
     e10, e50, e200 = (r["rms"] / r["peak"] for r in res)
     # measured: 1.23 %, 0.63 %, 0.045 % of the peak velocity
     assert e10 < 0.02 and e50 < e10 and e200 < e50 / 4 and e200 < 0.002
+
+
+def test_cs205_movie_notebook_flow_runs_through_the_drop_in_classes(lbhip, tmp_path):
+    """docs/cs205_movie.ipynb (cells 7-23): cylinder class, obstacle swapped for the reference's TIFF image, re-initialised with
+    init_hydro / update_feq / init_pop, stepped and rendered.  A usage test: finite fields, fluid at rest inside the obstacle at
+    start, flow from inlet to outlet afterwards, PNG frames written."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from LB_D2Q9.frames import Frame_Dumper
+    spec = importlib.util.spec_from_file_location("cs205_obstacle_movie", os.path.join(ROOT, "examples", "cs205_obstacle_movie.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    np.random.seed(0)
+    sim = mod.build(N=10)
+    m = np.asarray(sim.obstacle_mask_host).astype(bool)
+    assert (sim.nx, sim.ny) == (301, 101) and 0.005 < m.mean() < 0.05
+    g = sim.get_fields()
+    assert np.all(g["u"][m] == 0)
+    d = Frame_Dumper(sim, sim.u, num_steps_per_draw=40, scaling_factor=sim.delta_x / sim.delta_t, max_magnitude=3.,
+                     render_folder=str(tmp_path))
+    d.run(3)
+    g = sim.get_nondim_fields()
+    assert np.all(np.isfinite(g["u"])) and g["u"][~m].mean() > 0 and len(d.frames_written) == 3
