@@ -69,6 +69,27 @@ __global__ __launch_bounds__(256) void copy_planes(const f4 *__restrict__ src, f
     }
 }
 
+// The marching kernels' access pattern without arithmetic: wave (strip s, segment g) walks its rows, 9 x 1 KiB loads then
+// 9 x 1 KiB stores per row.  LAYOUT 0: planes are [row][8192] (a wave's consecutive rows lie 32 KiB apart, x-neighbour strips
+// 1 KiB apart) -- the engine's layout;  LAYOUT 1: strip-major planes [strip][row][256] (a wave's rows are contiguous).
+template <int LAYOUT>
+__global__ __launch_bounds__(128) void march_copy(const f4 *__restrict__ src, f4 *__restrict__ dst, long long plane4, int n,
+                                                  int strips, int seg_rows)
+{
+    const int item = blockIdx.x * 2 + threadIdx.y, lane = threadIdx.x;
+    const int s = item % strips, g = item / strips;
+    const int y0 = g * seg_rows, y1 = min(y0 + seg_rows, n);
+    const long long row4 = n / 4;
+    for (int y = y0; y < y1; ++y) {
+        f4 v[9];
+        const long long o = LAYOUT == 0 ? (long long)y * row4 + s * 64 + lane : ((long long)s * n + y) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = src[k * plane4 + o];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * plane4 + o);
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int iters)
 {
@@ -126,6 +147,14 @@ int main()
     }
     RUN("copy_f2 (8 B per lane, one per thread, no loop)", hipLaunchKernelGGL(copy_f2, dim3((unsigned)(n4 * 2 / 256)), dim3(256), 0, 0, (const f2 *)src, (f2 *)dst, n4 * 2));
     RUN("copy_planes_f2 (9 planes x 512 B per wave) grid.y 8192", hipLaunchKernelGGL(copy_planes_f2, dim3(n / 2 / 256, 8192), dim3(256), 0, 0, (const f2 *)src, (f2 *)dst, plane4 * 2, n / 2, n));
+    for (int wpc : {4, 8, 16, 32}) {
+        const int strips = n / 256, segs = 256 * wpc / strips, seg_rows = (n + segs - 1) / segs, items = strips * segs;
+        char nm[128];
+        snprintf(nm, sizeof nm, "march_copy row-major planes,   %2d waves/CU, %3d-row segments", wpc, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy<0>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
+        snprintf(nm, sizeof nm, "march_copy strip-major planes, %2d waves/CU, %3d-row segments", wpc, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy<1>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
+    }
     RUN("hipMemcpyDtoD", CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
     return 0;
 }
