@@ -339,6 +339,37 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
         two.close()
 
 
+@pytest.mark.parametrize("bc", ["pipe", "cavity"])
+def test_slab_schedule_inside_lb_run_wall_families_single_rank(lbhip, bc):
+    """lb_run's own slab schedule (edge bands, halo cycles, the lone first half, launch-by-launch remainders, MACRO on the
+    last launch) for the walled families: a whole grid flagged as a slab with a 1-rank RCCL communicator has no neighbour
+    (the exchange degenerates to an empty group), so the result must equal the plain run bit for bit."""
+    from LB_D2Q9.simulation import Simulation, comm_unique_id
+    nx, ny = 1024, 200
+    rng = np.random.default_rng(31)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.02
+    mask[0, :] = mask[-1, :] = False
+    mask[:, 0] = mask[:, -1] = False
+    kw = dict(inlet_rho=1.004, lid_u=0.05)
+    one = Simulation(nx, ny, 1.4, bc=bc, obstacle_mask=mask, **kw)
+    one.set_variant(0)
+    one.set_f(f0)
+    one.run(20 + 7 + 4 + 9)
+    want = one.get_fields(("f", "rho", "u", "v"))
+    for variant in (97 | 256, 97, 33):
+        s = Simulation(nx, ny, 1.4, bc=bc, obstacle_mask=mask, halo=True, **kw)
+        s.set_variant(variant)
+        s.comm_init(comm_unique_id(), 0, 1)
+        s.set_f(f0)
+        for n in (20, 7, 4, 9):
+            s.run(n)
+        got = s.get_fields(("f", "rho", "u", "v"))
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (variant, k)
+        s.close()
+
+
 def test_rccl_self_exchange_single_rank(lbhip):
     """One rank, periodic box split as a 'slab' talking to itself over RCCL: exercises
     lb_comm_init + the in-run exchange path on a single GPU."""
