@@ -90,6 +90,24 @@ __global__ __launch_bounds__(128) void march_copy(const f4 *__restrict__ src, f4
     }
 }
 
+// the same march with 128-cell strips (8 bytes per lane: what a two-cells-per-lane marching kernel would issue)
+__global__ __launch_bounds__(256) void march_copy_f2(const f2 *__restrict__ src, f2 *__restrict__ dst, long long plane2, int n,
+                                                     int strips, int seg_rows)
+{
+    const int item = blockIdx.x * 4 + threadIdx.y, lane = threadIdx.x;
+    const int s = item % strips, g = item / strips;
+    const int y0 = g * seg_rows, y1 = min(y0 + seg_rows, n);
+    const long long row2 = n / 2;
+    for (int y = y0; y < y1; ++y) {
+        f2 v[9];
+        const long long o = (long long)y * row2 + s * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = src[k * plane2 + o];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * plane2 + o);
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int iters)
 {
@@ -154,6 +172,12 @@ int main()
         RUN(nm, hipLaunchKernelGGL(march_copy<0>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
         snprintf(nm, sizeof nm, "march_copy strip-major planes, %2d waves/CU, %3d-row segments", wpc, seg_rows);
         RUN(nm, hipLaunchKernelGGL(march_copy<1>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
+    }
+    for (int wpc : {8, 12, 16, 24}) {
+        const int strips = n / 128, segs = 256 * wpc / strips, seg_rows = (n + segs - 1) / segs, items = strips * segs;
+        char nm[128];
+        snprintf(nm, sizeof nm, "march_copy_f2 (128-cell strips), %2d waves/CU, %3d-row segments", wpc, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy_f2, dim3(items / 4), dim3(64, 4), 0, 0, (const f2 *)src, (f2 *)dst, plane4 * 2, n, strips, seg_rows));
     }
     RUN("hipMemcpyDtoD", CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
     return 0;
