@@ -108,6 +108,55 @@ __global__ __launch_bounds__(256) void march_copy_f2(const f2 *__restrict__ src,
     }
 }
 
+// k_step's launch shape without its arithmetic: blocks of (64 * WX) x RY threads, a wave = 256 cells of one row, nine planes;
+// DELAY dependent FMAs per loaded value between the loads and the stores (the collision's place)
+template <int DELAY>
+__global__ __launch_bounds__(256) void copy_step_shape(const f4 *__restrict__ src, f4 *__restrict__ dst, long long plane4, int row4, int rows)
+{
+    const int lane4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (lane4 >= row4 || y >= rows) return;
+    f4 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = src[k * plane4 + (long long)y * row4 + lane4];
+    if (DELAY) {
+        f4 acc = v[0];
+        for (int i = 0; i < DELAY; ++i)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = acc * 1.0000001f + v[k];
+        if (acc.x == 12345.678f) v[0] = acc;           // (never; keeps the loop)
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * plane4 + (long long)y * row4 + lane4);
+}
+
+// march_copy with other item -> (strip, segment) mappings.  MAP 0: a workgroup's two waves take x-adjacent strips of one segment
+// (k_step4's); 1: the same strip, two vertically adjacent segments; 2: column-major (consecutive workgroups walk down one strip's
+// segments); 3: as 0 with the 8 x 8 transposition of workgroup ids that keeps 8 consecutive items on one XCD (xcd_item)
+template <int MAP>
+__global__ __launch_bounds__(128) void march_copy_map(const f4 *__restrict__ src, f4 *__restrict__ dst, long long plane4, int n,
+                                                      int strips, int segs, int seg_rows)
+{
+    int wg = blockIdx.x;
+    if (MAP == 3) { const int blk = wg & ~63, i = wg & 63; if (blk + 64 <= (int)gridDim.x) wg = blk + (i & 7) * 8 + (i >> 3); }
+    const int wy = threadIdx.y, lane = threadIdx.x;
+    int s, g;
+    if (MAP == 1) { s = wg % strips; g = 2 * (wg / strips) + wy; }
+    else if (MAP == 2) { const int item = wg * 2 + wy; g = item % segs; s = item / segs; }
+    else { const int item = wg * 2 + wy; s = item % strips; g = item / strips; }
+    if (s >= strips || g >= segs) return;
+    const int y0 = g * seg_rows, y1 = min(y0 + seg_rows, n);
+    const long long row4 = n / 4;
+    for (int y = y0; y < y1; ++y) {
+        f4 v[9];
+        const long long o = (long long)y * row4 + s * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = src[k * plane4 + o];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * plane4 + o);
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int iters)
 {
@@ -178,6 +227,32 @@ int main()
         char nm[128];
         snprintf(nm, sizeof nm, "march_copy_f2 (128-cell strips), %2d waves/CU, %3d-row segments", wpc, seg_rows);
         RUN(nm, hipLaunchKernelGGL(march_copy_f2, dim3(items / 4), dim3(64, 4), 0, 0, (const f2 *)src, (f2 *)dst, plane4 * 2, n, strips, seg_rows));
+    }
+    for (int shape = 0; shape < 3; ++shape) {
+        const dim3 blk = shape == 0 ? dim3(256, 1) : (shape == 1 ? dim3(128, 2) : dim3(64, 4));
+        const dim3 grd(n / 4 / blk.x, n / blk.y);
+        char nm[128];
+        snprintf(nm, sizeof nm, "copy_step_shape block %3d x %d, no delay", blk.x, blk.y);
+        RUN(nm, hipLaunchKernelGGL(copy_step_shape<0>, grd, blk, 0, 0, src, dst, plane4, n / 4, n));
+        snprintf(nm, sizeof nm, "copy_step_shape block %3d x %d, 4 x 9 FMAs", blk.x, blk.y);
+        RUN(nm, hipLaunchKernelGGL(copy_step_shape<4>, grd, blk, 0, 0, src, dst, plane4, n / 4, n));
+        snprintf(nm, sizeof nm, "copy_step_shape block %3d x %d, 16 x 9 FMAs", blk.x, blk.y);
+        RUN(nm, hipLaunchKernelGGL(copy_step_shape<16>, grd, blk, 0, 0, src, dst, plane4, n / 4, n));
+    }
+    {
+        const int strips = n / 256, segs = 64, seg_rows = n / segs, items = strips * segs;
+        RUN("march_copy_map 0: x-adjacent strips per workgroup (8 waves/CU)", hipLaunchKernelGGL(march_copy_map<0>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, segs, seg_rows));
+        RUN("march_copy_map 1: one strip, two segments per workgroup", hipLaunchKernelGGL(march_copy_map<1>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, segs, seg_rows));
+        RUN("march_copy_map 2: column-major items", hipLaunchKernelGGL(march_copy_map<2>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, segs, seg_rows));
+        RUN("march_copy_map 3: x-adjacent + XCD transposition", hipLaunchKernelGGL(march_copy_map<3>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, segs, seg_rows));
+    }
+    // the same march with the residency of k_step4 (36 KiB of LDS per two-wave workgroup = 8 waves per CU) and MORE items
+    // than wave slots: short-lived marching waves dispatched in row-major order = a band sweeping the grid
+    for (int seg_rows : {128, 64, 32, 16, 8}) {
+        const int strips = n / 256, segs = n / seg_rows, items = strips * segs;
+        char nm[128];
+        snprintf(nm, sizeof nm, "march_copy, 8 waves/CU resident, %5d items of %3d rows", items, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy<0>, dim3(items / 2), dim3(64, 2), 36 * 1024, 0, src, dst, plane4, n, strips, seg_rows));
     }
     RUN("hipMemcpyDtoD", CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
     return 0;
