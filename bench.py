@@ -119,15 +119,19 @@ def spawn_ranks(n, argv):
     has no need to: the children are ordinary subprocesses)."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    # rank 0's stdout goes through a file, not a pipe: nobody reads while the ranks run, and a chatty runtime
+    # (NCCL_DEBUG=INFO ...) must not be able to fill a pipe and stall the rank
+    out0 = tempfile.TemporaryFile(mode="w+b")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
     # a rank that dies leaves its peers blocked in a collective: poll, and take the others down with it
     failed = None
     while failed is None:
@@ -145,9 +149,12 @@ def spawn_ranks(n, argv):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
-        sys.stderr.write(procs[0].stdout.read().decode(errors="replace"))
+    out0.seek(0)
+    out = out0.read().decode(errors="replace")
+    out0.close()
+    if failed is not None:
+        sys.stderr.write(out)
         raise SystemExit("bench: rank %d exited with status %s" % (failed, procs[failed].returncode))
-    out = procs[0].stdout.read().decode(errors="replace")
     sys.stdout.write(out)
     sys.stdout.flush()
     if not any(l.startswith("{") for l in out.splitlines()):
