@@ -175,6 +175,37 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     // Kept free of control flow so that the compiler pairs the cells into packed fp32 instructions
     // (v_pk_fma/mul/add_f32: 523 packed ops in the periodic kernel against 105 when the boundary branches
     // sat inside this loop -- the wall families ran 7 % slower for that alone).
+    if (BC == LB_BC_VELOCITY_INLET) {
+        // moments of the four cells, then -- rare: the one lane per row that holds x = 0 or x = nx-1 -- the column's overrides
+        // (D2Q9.cl:323-374), then the relaxation of the four cells: the branch sits between the two straight-line parts
+        Cell c[4];
+        float rho[4], ux[4], uy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c[j] = Cell{q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+            if (MASK) bounce_cell(c[j], mk[j] != 0);
+            moments_cell(c[j], rho[j], ux[j], uy[j]);
+        }
+        const bool first = (x4 == 0), last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
+        if (first || last) {
+            const int jl = (a.nx - 1) & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((first && j == 0) || (last && j == jl)) {
+                    const long long o = (long long)(yg - a.y0) * a.pitch + x4 + j;
+                    vel_moments_cell(c[j], first && j == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho[j], ux[j],
+                                     uy[j]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            equilibrate_cell(c[j], a.omega, rho[j], ux[j], uy[j]);
+            r4[j] = rho[j]; u4[j] = ux[j]; v4[j] = uy[j];
+            q[0][j] = c[j].f0; q[1][j] = c[j].f1; q[2][j] = c[j].f2; q[3][j] = c[j].f3; q[4][j] = c[j].f4;
+            q[5][j] = c[j].f5; q[6][j] = c[j].f6; q[7][j] = c[j].f7; q[8][j] = c[j].f8;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};

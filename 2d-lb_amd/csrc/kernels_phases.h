@@ -361,6 +361,19 @@ struct HaloTable {
     int n;
 };
 
+// Copy two runs of whole rows ([pitch] floats each) of `gridDim.z` planes from one plane set into another: run A = n_a rows
+// src row sa.. -> dst row da.., run B = n_b rows sb.. -> db..; 16 bytes per lane (pitch % 64 == 0).  The velocity-inlet
+// family's band scheme (lb_hip.cpp vel_band_pass) moves its wall-row bands with it.
+__global__ void k_rows_copy(const float *src, float *dst, long long plane_src, long long plane_dst, int pitch, int n_a, int sa,
+                            int da, int n_b, int sb, int db)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, j = blockIdx.y, k = blockIdx.z;
+    if (x4 >= pitch || j >= n_a + n_b) return;
+    const int rs = j < n_a ? sa + j : sb + (j - n_a), rd = j < n_a ? da + j : db + (j - n_a);
+    *reinterpret_cast<f4a *>(dst + k * plane_dst + (long long)rd * pitch + x4) =
+        *reinterpret_cast<const f4a *>(src + k * plane_src + (long long)rs * pitch + x4);
+}
+
 // One wave moves 1 KiB of a row segment: 16 bytes per lane when nx is a multiple of 4 (row starts and buffer segments are
 // then 16-byte aligned: pitch % 64 == 0), a dword per lane otherwise.  grid = (ceil(nx / (256 * V)), segments, 2 edges).
 template <int V>

@@ -135,6 +135,7 @@ struct lb_sim {
     float *feq = nullptr;       // raw allocation, lazily created
     float *rho = nullptr, *u = nullptr, *v = nullptr;
     float *vi_corner = nullptr; // VELOCITY_INLET: the eight corner links nothing ever writes (bc_vel_cell), device
+    lb_sim *band[2] = {nullptr, nullptr};   // VELOCITY_INLET: the wall-row bands of a three- / four-step pass (vel_band_pass)
     uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
     bool has_mask = false;
     int cu_count = 256;
@@ -308,14 +309,26 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
 #undef LB_LAUNCH2
 }
 
-// The velocity-inlet family: its wall rows exchange links with each other, which one marching pass can follow for two
-// time steps (step 1 reads memory through the remapped source rows) but not for three -- k_step2 only.
+// The velocity-inlet family.  Its wall rows exchange links with each other, which one marching pass over the whole grid can
+// follow for two time steps (step 1 reads memory through the remapped source rows) but not for three: k_step2 takes whole
+// grids, k_step3 / k_step4 only the rows that no wall-row link reaches within the pass (vel_band_pass does the rest).
 void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs,
-                      int row_end, bool macro, bool nts)
+                      int row_end, bool macro, bool nts, int depth)
 {
-    const dim3 block(64, 4), grid((items + 3) / 4);
-#define LB_LAUNCHV(MASK, MACRO, NTS) \
-    hipLaunchKernelGGL((k_step2<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end)
+    const int waves = (depth == 4) ? STEP4_WAVES : 4;
+    const dim3 block(64, waves), grid((items + waves - 1) / waves);
+#define LB_LAUNCHV(MASK, MACRO, NTS)                                                                                      \
+    do {                                                                                                                  \
+        if (depth == 4)                                                                                                   \
+            hipLaunchKernelGGL((k_step4<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips,   \
+                               seg_rows, nsegs, row_end);                                                                 \
+        else if (depth == 3)                                                                                              \
+            hipLaunchKernelGGL((k_step3<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows,\
+                               nsegs, row_end);                                                                           \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_step2<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows,\
+                               nsegs, row_end);                                                                           \
+    } while (0)
     if (s->has_mask) {
         if (macro) { if (nts) LB_LAUNCHV(true, true, true); else LB_LAUNCHV(true, true, false); }
         else       { if (nts) LB_LAUNCHV(true, false, true); else LB_LAUNCHV(true, false, false); }
@@ -329,7 +342,6 @@ void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int it
 // (h: the height the decision is taken on -- a slab's own, or the smallest of the slabs that must agree)
 bool step3_applicable(const lb_sim *s, int h = -1)
 {
-    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) return false;
     if (h < 0) h = s->H;
     if (s->p.nx < 512 || h < (s->multi_slab() ? 32 : 128)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
@@ -339,7 +351,6 @@ bool step3_applicable(const lb_sim *s, int h = -1)
 // four steps per pass on a whole-grid handle (slabs use it inside the eight-step halo cycle only: cycle_depth)
 bool step4_applicable(const lb_sim *s)
 {
-    if (s->p.bc_mode == LB_BC_VELOCITY_INLET) return false;
     if (s->multi_slab() || s->p.nx < 512 || s->H < 128) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
@@ -401,7 +412,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
     switch (kernel_bc(s)) {
     case LB_BC_PIPE_I: launch_step2_bc<LB_BC_PIPE_I>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
-    case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts); break;
+    case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
@@ -792,6 +803,61 @@ int whole_grid_depths(const lb_sim *s)
     return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s));
 }
 
+// A d-step pass (d = 3, 4) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
+// the marching kernel takes them, treating the wall rows as don't-care like any wall.  The 2d wall-side rows are advanced
+// as a lattice of their own: the 2d rows next to each wall, stacked, ARE a velocity-inlet lattice of 4d rows -- row 0's pull
+// reaches "row ny-2" = local row 4d-2, row ny-1's "row 1" = local row 1 -- except at the seam in the middle, whose garbage
+// travels one row per step and after d steps has reached exactly the rows that are not needed.  So: copy the bands into a
+// 4d-row handle, d single steps there, copy its outer d + d rows (and their rho,u,v on a MACRO pass) into place.
+int vel_band_pass(lb_sim *s, int d, bool macro)
+{
+    int rc;
+    const int H = s->H, hb = 4 * d;
+    lb_sim *&b = s->band[d - 3];
+    if (!b) {
+        lb_params p = s->p;
+        p.ny = p.local_ny = hb;
+        p.y0 = 0;
+        if ((rc = lb_create(&p, &b))) return rc;
+        b->variant = 16;                        // single-step kernel, plain stores (the band lives in the caches)
+    }
+    b->stream = s->stream;
+    b->has_mask = s->has_mask;
+    b->cur = 0;
+    const dim3 blk(256), grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)hb, 9);
+    // bands of the current lattice, of the stored u, v (the inlet / outlet columns read them) and of the mask -> band handle
+    hipLaunchKernelGGL(k_rows_copy, grid, blk, 0, s->stream, (const float *)s->origin(s->cur), b->origin(0), s->plane, b->plane,
+                       (int)s->pitch, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
+    const dim3 grid1(grid.x, grid.y, 1);
+    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, s->stream, (const float *)s->u, b->u, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
+                       H - 2 * d, 2 * d);
+    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, s->stream, (const float *)s->v, b->v, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
+                       H - 2 * d, 2 * d);
+    if (s->has_mask)       // (rows of pitch bytes = pitch / 4 floats)
+        hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)((s->pitch / 16 + 255) / 256), (unsigned)hb, 1), blk, 0, s->stream,
+                           reinterpret_cast<const float *>(s->mask), reinterpret_cast<float *>(b->mask), 0LL, 0LL,
+                           (int)(s->pitch / 4), 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
+    HIP_TRY(hipMemcpyAsync(b->vi_corner, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipGetLastError());
+    // the interior, from the same source lattice
+    if ((rc = launch_step2(s, s->stream, d, H - d, macro, 0, 0, 0, 0, d))) return rc;
+    for (int i = 0; i < d; ++i) {
+        if ((rc = launch_step(b, 0, 1, hb, macro && i == d - 1))) return rc;
+        b->cur ^= 1;
+    }
+    // the band handle's outer rows -> the lattice being written
+    hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 9), blk, 0, s->stream, (const float *)b->origin(b->cur),
+                       s->origin(s->cur ^ 1), b->plane, s->plane, (int)s->pitch, d, 0, 0, d, 3 * d, H - d);
+    if (macro) {
+        float *const from[3] = {b->rho, b->u, b->v}, *const to[3] = {s->rho, s->u, s->v};
+        for (int i = 0; i < 3; ++i)
+            hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 1), blk, 0, s->stream, (const float *)from[i], to[i], 0LL,
+                               0LL, (int)s->pitch, d, 0, 0, d, 3 * d, H - d);
+    }
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
 // n time steps on a whole-grid handle: largest fused kernel first in the remainder (n = 3a + rem with
 // the three-step kernel, 2a + rem with the two-step kernel), hipGraph replay for small grids.
 int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
@@ -813,6 +879,7 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
         const int adv = next_advance(depths, left);
         const bool macro = final_macro && (left == adv);
         if (adv == 4 && tile) rc = launch_tile4(s, macro);
+        else if (adv >= 3 && s->p.bc_mode == LB_BC_VELOCITY_INLET) rc = vel_band_pass(s, adv, macro);
         else if (adv >= 2) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, adv);
         else rc = launch_step(s, 0, 1, s->H, macro);
         if (rc) return rc;
@@ -1051,6 +1118,9 @@ int lb_destroy(lb_sim *s)
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     drop_graph(s);
+    for (lb_sim *&b : s->band) {
+        if (b) { b->stream = b->own_stream; lb_destroy(b); b = nullptr; }
+    }
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner})
         if (p) (void)hipFree(p);

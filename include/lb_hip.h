@@ -52,8 +52,9 @@ typedef enum {
     LB_BC_VELOCITY_INLET = 3  /* D2Q9.cl:263-374: imposed speed inlet_u at x=0 / outlet_u at x=nx-1, north and
                              south rows copy their missing links from the opposite wall row.  Dead code in
                              the reference's `dimensionless` package (only OLD/opencl.py:281-327 launches
-                             it).  Whole-grid handles; lb_run fuses it (one or two time steps per launch),
-                             the phase entry points run it un-fused. */
+                             it).  Whole-grid handles; lb_run fuses it (up to four time steps per launch; from
+                             three on the wall-row bands are advanced as a small lattice of their own), the phase
+                             entry points run it un-fused. */
 } lb_bc_mode;
 
 /* Which of the reference's two (numerically different) paths the handle reproduces.
@@ -143,7 +144,7 @@ int lb_init_pop(lb_sim *s);             /* f = f_streamed = feq (device side of 
  *      as many host waits per step) by fused launches that advance one, two or three time steps each
  *      (k_step, k_step2, k_step3, k_step4; results bitwise independent of which) and no host wait.
  *      rho,u,v of the LAST step are stored (they are only observable through get_fields); feq is
- *      rebuilt from them on demand.  LB_BC_VELOCITY_INLET fuses one or two steps per launch; handles with
+ *      rebuilt from them on demand.  Handles with
  *      LB_SEM_CYTHON run their boundary phase + one fused pass per step.
  *      Multi-slab handles exchange their halo rows inside lb_run when a communicator is attached
  *      (lb_comm_init), otherwise the caller drives lb_step_boundary / lb_halo_export /

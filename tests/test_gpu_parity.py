@@ -580,9 +580,11 @@ def test_velocity_inlet_family_vs_reference_kernels(lbhip, oracle):
     assert_fields_close(c.get_fields(), o.get_fields(), TOLN)
 
 
-@pytest.mark.parametrize("nx,ny,masked", [(45, 23, False), (67, 31, True), (1024, 160, False), (1003, 131, True), (2048, 70, True)])
+@pytest.mark.parametrize("nx,ny,masked", [(45, 23, False), (67, 31, True), (1024, 160, False), (1003, 131, True), (2048, 70, True),
+                                          (1536, 300, True)])
 def test_velocity_inlet_fused_kernels_vs_oracle_and_unfused(lbhip, oracle, nx, ny, masked):
-    """lb_run on the velocity-inlet family = fused kernels (k_step; k_step2 from nx >= 512, >= 64 rows): against the
+    """lb_run on the velocity-inlet family = fused kernels (k_step; k_step2 from nx >= 512, >= 64 rows; from 128 rows also
+    k_step3 / k_step4 on the rows no wall-row link reaches + the wall-row bands advanced as a small lattice of their own): against the
     oracle's restatement of D2Q9.cl:263-374 driven as OLD/opencl.py:281-327 drives it (pinned bit-exact to the executed
     kernels by o2_velocity_inlet_45x23), against the engine's own un-fused phase sequence, and the two fused kernels
     against each other bit for bit.  Random initial populations, so that the four corner cells' never-written links
@@ -602,11 +604,16 @@ def test_velocity_inlet_fused_kernels_vs_oracle_and_unfused(lbhip, oracle, nx, n
     o.set_macro(np.ones((nx, ny)), u0, v0)
     o.set_f(f0)
     outs = {}
-    for name, variant in (("single", 0), ("two", 33), ("auto", -1)):
+    variants = [("single", 0), ("two", 33), ("auto", -1)]
+    if nx >= 512 and ny >= 128:
+        variants += [("three", 97), ("four", 353)]
+    for name, variant in variants:
         s = Simulation(nx, ny, omega, bc="velocity_inlet", inlet_u=uw, outlet_u=ue, obstacle_mask=mask)
         s.set_variant(variant)
         if variant == 33 and nx >= 512 and ny >= 64:
             assert s.steps_per_launch() == 2 and "k_step2" in s.hot_kernel()
+        if variant in (97, 353):
+            assert s.steps_per_launch() == (3 if variant == 97 else 4)
         s.set_fields(np.ones((nx, ny)), u0, v0)
         s.set_f(f0)
         s.run(1)
@@ -619,9 +626,9 @@ def test_velocity_inlet_fused_kernels_vs_oracle_and_unfused(lbhip, oracle, nx, n
                                                               f0[-1, 0, 3], f0[-1, 0, 7], f0[-1, -1, 3], f0[-1, -1, 6]]))
     o.run(11)
     assert_fields_close(outs["single"], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
-    for k in ("f", "rho", "u", "v"):
-        assert np.array_equal(outs["single"][k], outs["two"][k]), k
-        assert np.array_equal(outs["single"][k], outs["auto"][k]), k
+    for name in outs:
+        for k in ("f", "rho", "u", "v"):
+            assert np.array_equal(outs["single"][k], outs[name][k]), (name, k)
     # the un-fused phase sequence (opencl_dim.py:380-387 order), also after fused steps have swapped the lattices
     u = Simulation(nx, ny, omega, bc="velocity_inlet", inlet_u=uw, outlet_u=ue, obstacle_mask=mask)
     u.set_fields(np.ones((nx, ny)), u0, v0)
