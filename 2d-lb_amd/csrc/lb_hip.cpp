@@ -821,40 +821,47 @@ int vel_band_pass(lb_sim *s, int d, bool macro)
         if ((rc = lb_create(&p, &b))) return rc;
         b->variant = 16;                        // single-step kernel, plain stores (the band lives in the caches)
     }
-    b->stream = s->stream;
+    // The band chain (copy in, d small steps, copy out: ~10 tiny dependent launches) runs on the edge stream, beside the
+    // interior launch on the compute stream: both only read the current lattice and write disjoint rows of the other one.
+    const hipStream_t q = s->edge_stream;
+    HIP_TRY(hipEventRecord(s->ev_interior, s->stream));          // everything enqueued so far (the previous pass included)
+    HIP_TRY(hipStreamWaitEvent(q, s->ev_interior, 0));
+    b->stream = q;
     b->has_mask = s->has_mask;
     b->cur = 0;
     const dim3 blk(256), grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)hb, 9);
     // bands of the current lattice, of the stored u, v (the inlet / outlet columns read them) and of the mask -> band handle
-    hipLaunchKernelGGL(k_rows_copy, grid, blk, 0, s->stream, (const float *)s->origin(s->cur), b->origin(0), s->plane, b->plane,
+    hipLaunchKernelGGL(k_rows_copy, grid, blk, 0, q, (const float *)s->origin(s->cur), b->origin(0), s->plane, b->plane,
                        (int)s->pitch, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
     const dim3 grid1(grid.x, grid.y, 1);
-    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, s->stream, (const float *)s->u, b->u, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
+    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->u, b->u, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
                        H - 2 * d, 2 * d);
-    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, s->stream, (const float *)s->v, b->v, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
+    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->v, b->v, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
                        H - 2 * d, 2 * d);
     if (s->has_mask)       // (rows of pitch bytes = pitch / 4 floats)
-        hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)((s->pitch / 16 + 255) / 256), (unsigned)hb, 1), blk, 0, s->stream,
+        hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)((s->pitch / 16 + 255) / 256), (unsigned)hb, 1), blk, 0, q,
                            reinterpret_cast<const float *>(s->mask), reinterpret_cast<float *>(b->mask), 0LL, 0LL,
                            (int)(s->pitch / 4), 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
-    HIP_TRY(hipMemcpyAsync(b->vi_corner, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(b->vi_corner, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToDevice, q));
     HIP_TRY(hipGetLastError());
-    // the interior, from the same source lattice
+    // the interior, from the same source lattice, on the compute stream
     if ((rc = launch_step2(s, s->stream, d, H - d, macro, 0, 0, 0, 0, d))) return rc;
     for (int i = 0; i < d; ++i) {
         if ((rc = launch_step(b, 0, 1, hb, macro && i == d - 1))) return rc;
         b->cur ^= 1;
     }
     // the band handle's outer rows -> the lattice being written
-    hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 9), blk, 0, s->stream, (const float *)b->origin(b->cur),
+    hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 9), blk, 0, q, (const float *)b->origin(b->cur),
                        s->origin(s->cur ^ 1), b->plane, s->plane, (int)s->pitch, d, 0, 0, d, 3 * d, H - d);
     if (macro) {
         float *const from[3] = {b->rho, b->u, b->v}, *const to[3] = {s->rho, s->u, s->v};
         for (int i = 0; i < 3; ++i)
-            hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 1), blk, 0, s->stream, (const float *)from[i], to[i], 0LL,
+            hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 1), blk, 0, q, (const float *)from[i], to[i], 0LL,
                                0LL, (int)s->pitch, d, 0, 0, d, 3 * d, H - d);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_boundary, q));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));   // the next pass (or the caller) sees the bands in place
     return LB_OK;
 }
 
