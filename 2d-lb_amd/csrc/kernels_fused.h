@@ -80,12 +80,25 @@ __device__ __forceinline__ T *lane_ptr(T *row, int x)
     return reinterpret_cast<T *>(reinterpret_cast<B *>(row) + (unsigned)x * (unsigned)sizeof(T));
 }
 
+// Periodic x wrap: the lane holding x = 0 / x = nx-1 fetches the one element per plane that its displaced load takes from
+// the row padding.  In two halves: gather_issue issues these loads FIRST, into temporaries, then the nine plane loads;
+// gather_merge puts the temporaries in place.  (Written as a patch behind the plane loads -- q[1].x = ... -- each waited for
+// the plane load it overwrites: a second, serial memory round trip per row for the two strips at the box's ends, which were
+// the last to finish in every launch of the marching kernels.  And merged right behind the loads, the selects make the wave
+// wait for them on the spot, which undoes k_step4's one-row-ahead gather for those two strips -- again the stragglers,
+// +7 % on the launch: tools/wave_timeline.py.  k_step4 therefore merges at the point of use.)
+struct WrapPatch {
+    float p1, p5, p8, w3, w6, w7;
+};
+
 template <int BC, bool MASK, bool NTL>
-__device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk)
+__device__ __forceinline__ void gather_issue(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk,
+                                             WrapPatch &wp)
 {
     const long long P = a.pitch, S = a.plane;
     const float *s = a.src;
     const float *r0 = s + (long long)yl * P, *rm = s + (long long)ym * P, *rp = s + (long long)yp * P;   // uniform
+    wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #ifdef LB_DIAG
     if (a.diag & 8) {                      // timing only: all nine planes read aligned (wrong results)
         q[0] = load4<NTL>(lane_ptr(r0, x4));          q[1] = load4<NTL>(lane_ptr(r0 + 1 * S, x4));
@@ -97,23 +110,22 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
         return;
     }
 #endif
-    // Periodic x wrap: the lane holding x = 0 / x = nx-1 fetches the one element per plane that its displaced load takes
-    // from the row padding.  These loads are ISSUED FIRST, into temporaries, and merged after the nine plane loads: written
-    // as a patch behind them (q[1].x = ...), each waited for the plane load it overwrites and then cost the wave a second,
-    // serial memory round trip per row -- the strip holding x = nx-1 was the last to finish in every launch of the
-    // marching kernels (tools/wave_timeline.py: 1263 us against 950 us for its neighbours).
-    float p1 = 0.f, p5 = 0.f, p8 = 0.f, w3 = 0.f, w6 = 0.f, w7 = 0.f;
-    const int c = a.nx - 1 - x4;
-    const bool wrap_w = (BC == LB_BC_PERIODIC) && x4 == 0, wrap_e = (BC == LB_BC_PERIODIC) && c >= 0 && c < 4;
-    if (wrap_w) {
-        p1 = s[1 * S + (long long)yl * P + a.nx - 1];
-        p5 = s[5 * S + (long long)ym * P + a.nx - 1];
-        p8 = s[8 * S + (long long)yp * P + a.nx - 1];
-    }
-    if (wrap_e) {
-        w3 = s[3 * S + (long long)yl * P];
-        w6 = s[6 * S + (long long)ym * P];
-        w7 = s[7 * S + (long long)yp * P];
+    if (BC == LB_BC_PERIODIC) {
+        const int c = a.nx - 1 - x4;
+        bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
+#ifdef LB_DIAG
+        if (a.diag & 16384) wrap_w = wrap_e = false;        // timing only: no periodic-wrap patch (wrong results)
+#endif
+        if (wrap_w) {
+            wp.p1 = s[1 * S + (long long)yl * P + a.nx - 1];
+            wp.p5 = s[5 * S + (long long)ym * P + a.nx - 1];
+            wp.p8 = s[8 * S + (long long)yp * P + a.nx - 1];
+        }
+        if (wrap_e) {
+            wp.w3 = s[3 * S + (long long)yl * P];
+            wp.w6 = s[6 * S + (long long)ym * P];
+            wp.w7 = s[7 * S + (long long)yp * P];
+        }
     }
     q[0] = load4<NTL>(lane_ptr(r0, x4));
     q[1] = load4u<NTL>(lane_ptr(r0 + 1 * S - 1, x4));
@@ -126,18 +138,36 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
     q[8] = load4u<NTL>(lane_ptr(rp + 8 * S - 1, x4));
     mk = uc4{0, 0, 0, 0};
     if (MASK) mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)yl * P, x4));
+}
+
+template <int BC>
+__device__ __forceinline__ void gather_merge(const StepArgs &a, int x4, f4a (&q)[9], const WrapPatch &wp)
+{
     if (BC == LB_BC_PERIODIC) {
-        q[1].x = wrap_w ? p1 : q[1].x;
-        q[5].x = wrap_w ? p5 : q[5].x;
-        q[8].x = wrap_w ? p8 : q[8].x;
+        const int c = a.nx - 1 - x4;
+        bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
+#ifdef LB_DIAG
+        if (a.diag & (8 | 16384)) wrap_w = wrap_e = false;
+#endif
+        q[1].x = wrap_w ? wp.p1 : q[1].x;
+        q[5].x = wrap_w ? wp.p5 : q[5].x;
+        q[8].x = wrap_w ? wp.p8 : q[8].x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool hit = wrap_e && j == c;
-            q[3][j] = hit ? w3 : q[3][j];
-            q[6][j] = hit ? w6 : q[6][j];
-            q[7][j] = hit ? w7 : q[7][j];
+            q[3][j] = hit ? wp.w3 : q[3][j];
+            q[6][j] = hit ? wp.w6 : q[6][j];
+            q[7][j] = hit ? wp.w7 : q[7][j];
         }
     }
+}
+
+template <int BC, bool MASK, bool NTL>
+__device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, int ym, int yp, f4a (&q)[9], uc4 &mk)
+{
+    WrapPatch wp;
+    gather_issue<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk, wp);
+    gather_merge<BC>(a, x4, q, wp);
 }
 
 // Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.

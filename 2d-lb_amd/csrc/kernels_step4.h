@@ -104,6 +104,7 @@ constexpr int STEP4_WAVES = 2;      // waves per workgroup: 2 x 2 windows x 9 Ki
 // flags, and (halo lanes) the raw populations of my halo cell.
 struct Row1 {
     f4a q[9];
+    WrapPatch wp;       // periodic boxes: the wrap elements of the lanes at x = 0 / nx-1, merged at the point of use
     uc4 mk;
     Cell hc;
     int hxc;            // wrapped column of the halo cell, -1 = outside a walled box
@@ -121,9 +122,10 @@ __device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool
     o.hxc = -1;
     o.hc = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (o.have) {
-        gather_row<BC, MASK, false>(a, x4, o.rr, ym, yp, o.q, o.mk);
+        gather_issue<BC, MASK, false>(a, x4, o.rr, ym, yp, o.q, o.mk, o.wp);
         if (halo1) halo_cell_load<BC, MASK>(a, hx, o.rr, ym, yp, o.hc, o.hsolid, o.hxc);
     } else {
+        o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) o.q[k] = f4a{0.f, 0.f, 0.f, 0.f};
     }
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     // 100 MHz clock at the top of every row and the wave whose slot parity matches bit 13 of it (82 us per turn, ten
     // rows or so) raises its priority -- complementary at (almost) all times without the waves knowing of each other.
     for (int r = ya - 3; r <= yb + 2; ++r, ++it) {
-        if (a.prio_turns && (it & 3) == 0) {           // (every fourth row: reading the clock drains the wave's LDS queue)
+        if (a.prio_turns > 0 && (it & 3) == 0) {       // (every fourth row: reading the clock drains the wave's LDS queue)
             const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> a.prio_turns) & 1u;
             if (turn == slot) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
         const bool hsolid = cur.hsolid;
         HaloCell9 n1 = {};                              // stage-1 links of my halo cell in row r
         if (cur.have) {
+            gather_merge<BC>(a, x4, q1, cur.wp);          // (periodic wrap elements: merged here, not behind the loads)
 #ifdef LB_DIAG
             if (!(a.diag & 1024))
 #endif

@@ -60,6 +60,10 @@ def main():
         m = wave_slot == ws
         print("wave slot %d: %4d waves, end median %.1f us" % (ws, m.sum(), np.median(end[m])))
     sx, sy = rec[:, 6] % strips, rec[:, 6] // strips
+    order = np.argsort(-end)[:24]
+    print("slowest waves (end us, strip, segment, XCD, CU, SIMD, slot):",
+          " ".join("(%.0f,%d,%d,%d,%d,%d,%d)" % (end[i], sx[i], sy[i], xcc[i], cu[i], simd[i], wave_slot[i]) for i in order))
+    print("end by strip (max us):", " ".join("%.0f" % end[sx == i].max() for i in range(strips)))
     print("end by strip (median us):", " ".join("%.0f" % np.median(end[sx == i]) for i in range(strips)))
     print("end by segment (median us), first 16:", " ".join("%.0f" % np.median(end[sy == i]) for i in range(min(segs, 16))))
 
