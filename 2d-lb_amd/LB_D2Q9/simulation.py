@@ -10,6 +10,7 @@ Host arrays use the reference's conventions: F-ordered float32 ``(nx, ny)`` / ``
 (opencl_dim.py:165, 279, 390-415); for a row slab ``ny`` is the slab height.
 """
 import ctypes as ct
+import os
 
 import numpy as np
 
@@ -52,7 +53,7 @@ def comm_unique_id():
 class Simulation(object):
     def __init__(self, nx, ny, omega, bc="pipe", inlet_rho=1., outlet_rho=1., lid_u=0., rho0=1.,
                  obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False, semantics="opencl",
-                 inlet_u=0., outlet_u=None):
+                 inlet_u=0., outlet_u=None, planar=None):
         """
         :param nx, ny: global grid size (cells, boundary nodes included).
         :param omega: BGK relaxation rate, 0 < omega < 2.
@@ -66,6 +67,9 @@ class Simulation(object):
         :param semantics: 'opencl' (D2Q9.cl, fused fast path), 'cython' (cython_dim.pyx: pipe family, whole grid,
                compatibility path; the two reference paths differ at walls and inlets) or 'd2q9i' (the reference's
                D2Q9i.cl fork of the OpenCL path: pipe family, whole grid, fused).
+        :param planar: device layout of the lattices: False = the nine planes of a row stored together (default),
+               True = each plane contiguous (LB_FLAG_PLANAR); results are identical.  None: environment variable
+               LB_LAYOUT=planar selects True (tuning aid).
         """
         if isinstance(bc, str):
             if bc not in _native.BC_NAMES:
@@ -83,7 +87,10 @@ class Simulation(object):
         p = _native.LbParams()
         p.nx, p.ny, p.y0, p.local_ny = self.nx, self.ny, self.y0, self.local_ny
         p.bc_mode, p.device = bc, self.device
-        p.flags = _native.LB_FLAG_HALO if halo else 0
+        if planar is None:
+            planar = os.environ.get("LB_LAYOUT", "") == "planar"
+        self.planar = bool(planar)
+        p.flags = (_native.LB_FLAG_HALO if halo else 0) | (_native.LB_FLAG_PLANAR if self.planar else 0)
         sem = {"opencl": _native.LB_SEM_OPENCL, "cython": _native.LB_SEM_CYTHON, "d2q9i": _native.LB_SEM_OPENCL_D2Q9I}
         if semantics not in sem:
             raise ValueError("semantics must be one of %s" % sorted(sem))
@@ -406,4 +413,4 @@ class Simulation(object):
     def layout(self):
         a, b, c = ct.c_int64(), ct.c_int64(), ct.c_int64()
         check(self._lib.lb_layout(self._h, ct.byref(a), ct.byref(b), ct.byref(c)))
-        return {"pitch": a.value, "plane_stride": b.value, "bytes": c.value}
+        return {"pitch": a.value, "plane_stride": b.value, "bytes": c.value, "planar": self.planar}

@@ -10,10 +10,11 @@ namespace {
 struct StepArgs {
     const float *src;      // plane 0, row 0, x 0 of the lattice being read
     float *dst;            // same element of the lattice being written
-    const uint8_t *mask;   // [H][pitch] or nullptr
-    float *rho, *u, *v;    // [H][pitch]
-    long long plane;       // plane stride, floats
-    int pitch;             // row pitch, floats
+    const uint8_t *mask;   // [H][fpitch] or nullptr
+    float *rho, *u, *v;    // [H][fpitch]
+    long long plane;       // lattice: plane stride, floats
+    int pitch;             // lattice: row stride, floats (rows interleave the nine planes: 9 * fpitch; planar layout: fpitch)
+    int fpitch;            // row pitch of the fields and the mask = padded row width, floats / bytes
     int nx, ny;            // global grid
     int y0, h;             // slab origin / height
     int row_begin, row_step, row_count;  // local rows visited: row_begin + i*row_step, i < row_count
@@ -53,7 +54,7 @@ __device__ __forceinline__ void finish_cell(const StepArgs &a, int x, int yl, Ce
         // the cell on the inlet / outlet column takes its moments from the rule and the stored fields (D2Q9.cl:323-374)
         moments_cell(c, rho, ux, uy);
         if (x == 0 || x == a.nx - 1) {
-            const long long o = (long long)yl * a.pitch + x;
+            const long long o = (long long)yl * a.fpitch + x;
             const int yg = a.y0 + yl;
             vel_moments_cell(c, x == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho, ux, uy);
         }
@@ -137,7 +138,7 @@ __device__ __forceinline__ void gather_issue(const StepArgs &a, int x4, int yl, 
     q[7] = load4u<NTL>(lane_ptr(rp + 7 * S + 1, x4));
     q[8] = load4u<NTL>(lane_ptr(rp + 8 * S - 1, x4));
     mk = uc4{0, 0, 0, 0};
-    if (MASK) mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)yl * P, x4));
+    if (MASK) mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)yl * a.fpitch, x4));
 }
 
 template <int BC>
@@ -222,7 +223,7 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if ((first && j == 0) || (last && j == jl)) {
-                    const long long o = (long long)(yg - a.y0) * a.pitch + x4 + j;
+                    const long long o = (long long)(yg - a.y0) * a.fpitch + x4 + j;
                     vel_moments_cell(c[j], first && j == 0, yg == 0, yg == a.ny - 1, a.u_w, a.u_e, a.u[o], a.v[o], rho[j], ux[j],
                                      uy[j]);
                 }
@@ -274,7 +275,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a)
     }
     const int x4 = (bx * blockDim.x + threadIdx.x) * 4;
     const int ri = by * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);   // uniform: blockDim.x % 64 == 0
-    if (x4 >= a.pitch || ri >= a.row_count) return;
+    if (x4 >= a.fpitch || ri >= a.row_count) return;
     const int yl = a.row_begin + ri * a.row_step;
     const int yg = a.y0 + yl;
     int ym = yl - 1, yp = yl + 1;          // source rows of the cy=+1 / cy=-1 links
@@ -299,9 +300,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a)
 #pragma unroll
     for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), q[k]);
     if (MACRO) {
-        store4<false>(lane_ptr(a.rho + o0, x4), r4);
-        store4<false>(lane_ptr(a.u + o0, x4), u4);
-        store4<false>(lane_ptr(a.v + o0, x4), v4);
+        const long long m0 = (long long)yl * a.fpitch;
+        store4<false>(lane_ptr(a.rho + m0, x4), r4);
+        store4<false>(lane_ptr(a.u + m0, x4), u4);
+        store4<false>(lane_ptr(a.v + m0, x4), v4);
     }
 }
 
@@ -427,7 +429,7 @@ __device__ __forceinline__ void halo_cell_load(const StepArgs &a, int hx, int rr
     c.f6 = *lane_ptr(rm + 6 * S, xg);
     c.f7 = *lane_ptr(rp + 7 * S, xg);
     c.f8 = *lane_ptr(rp + 8 * S, xl);
-    if (MASK) solid = *lane_ptr(a.mask + (long long)rr * P, xc) != 0;
+    if (MASK) solid = *lane_ptr(a.mask + (long long)rr * a.fpitch, xc) != 0;
 }
 
 template <int BC, bool MASK>
@@ -538,9 +540,10 @@ __global__ __launch_bounds__(256, 2) void k_step2(const StepArgs a, int strips, 
 #pragma unroll
                 for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
                 if (MACRO) {
-                    store4<false>(lane_ptr(a.rho + o, x4), r4);
-                    store4<false>(lane_ptr(a.u + o, x4), u4);
-                    store4<false>(lane_ptr(a.v + o, x4), v4);
+                    const long long m = (long long)y * a.fpitch;
+                    store4<false>(lane_ptr(a.rho + m, x4), r4);
+                    store4<false>(lane_ptr(a.u + m, x4), u4);
+                    store4<false>(lane_ptr(a.v + m, x4), v4);
                 }
             }
         }
@@ -746,9 +749,10 @@ __global__ __launch_bounds__(256, 2) void k_step3(const StepArgs a, int strips, 
 #pragma unroll
                 for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
                 if (MACRO) {
-                    store4<false>(lane_ptr(a.rho + o, x4), r4);
-                    store4<false>(lane_ptr(a.u + o, x4), u4);
-                    store4<false>(lane_ptr(a.v + o, x4), v4);
+                    const long long m = (long long)r3 * a.fpitch;
+                    store4<false>(lane_ptr(a.rho + m, x4), r4);
+                    store4<false>(lane_ptr(a.u + m, x4), u4);
+                    store4<false>(lane_ptr(a.v + m, x4), v4);
                 }
             }
         }

@@ -11,8 +11,10 @@ struct PhaseArgs {
     float *f, *fs, *feq;   // plane 0, row 0, x 0
     float *rho, *u, *v;
     const uint8_t *mask;
-    long long plane;
-    int pitch, nx, ny, bc;
+    long long plane;       // lattice: plane stride
+    int pitch;             // lattice: row stride (StepArgs)
+    int fpitch;            // fields and mask: row pitch
+    int nx, ny, bc;
     float omega, rho_in, rho_out, lid_u, rho0;
 };
 
@@ -49,7 +51,7 @@ __global__ void k_bcs(const PhaseArgs a)
         if (a.bc == LB_BC_PIPE_I) bc_pipe_i_cell(c, w, e, so, no, a.rho_in, a.rho_out);
         if (a.bc == LB_BC_CAVITY) bc_cavity_cell(c, w, e, so, no, a.lid_u, a.rho0);
     }
-    bounce_cell(c, a.mask && a.mask[o]);
+    bounce_cell(c, a.mask && a.mask[(long long)y * a.fpitch + x]);
     f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
     f[5 * S] = c.f5; f[6 * S] = c.f6; f[7 * S] = c.f7; f[8 * S] = c.f8;
 }
@@ -64,9 +66,10 @@ __global__ void k_hydro(const PhaseArgs a)   // D2Q9.cl:67-100
     for (int k = 0; k < 9; ++k) f[k] = a.f[k * a.plane + o];
     const float rho = f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + f[8];
     const float inv = 1.0f / rho;
-    a.rho[o] = rho;
-    a.u[o] = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) * inv;
-    a.v[o] = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
+    const long long m = (long long)y * a.fpitch + x;
+    a.rho[m] = rho;
+    a.u[m] = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) * inv;
+    a.v[m] = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
 }
 
 __global__ void k_hydro_i(const PhaseArgs a)   // D2Q9i.cl:67-97
@@ -78,15 +81,16 @@ __global__ void k_hydro_i(const PhaseArgs a)   // D2Q9i.cl:67-97
     const Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
     float rho, ux, uy;
     moments_i_cell(c, rho, ux, uy);
-    a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+    const long long m = (long long)y * a.fpitch + x;
+    a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy;
 }
 
 __global__ void k_feq_i(const PhaseArgs a)     // D2Q9i.cl:2-64
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x;
-    const float rho = a.rho[o], ux = a.u[o], uy = a.v[o];
+    const long long o = (long long)y * a.pitch + x, m = (long long)y * a.fpitch + x;
+    const float rho = a.rho[m], ux = a.u[m], uy = a.v[m];
     const float usq = ux * ux + uy * uy;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -106,8 +110,8 @@ __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x;
-    const float rho = a.rho[o], ux = a.u[o], uy = a.v[o];
+    const long long o = (long long)y * a.pitch + x, m = (long long)y * a.fpitch + x;
+    const float rho = a.rho[m], ux = a.u[m], uy = a.v[m];
     const float usq = ux * ux + uy * uy;
 #pragma unroll
     for (int k = 0; k < 9; ++k) a.feq[k * a.plane + o] = feq_link(k, rho, ux, uy, usq);
@@ -125,8 +129,8 @@ __global__ void k_zero_vel(const PhaseArgs a) // D2Q9.cl:377-396
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
-    const long long o = (long long)y * a.pitch + x;
-    if (a.mask[o]) { a.u[o] = 0.f; a.v[o] = 0.f; }
+    const long long m = (long long)y * a.fpitch + x;
+    if (a.mask[m]) { a.u[m] = 0.f; a.v[m] = 0.f; }
 }
 
 // D2Q9.cl:263-321 `move_bcs_PeriodicBC_VelocityInlet`, in place like the reference: every thread stores only the
@@ -173,7 +177,7 @@ __global__ void k_bounce(const PhaseArgs a)
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
     const long long o = (long long)y * a.pitch + x, S = a.plane;
-    if (!a.mask[o]) return;
+    if (!a.mask[(long long)y * a.fpitch + x]) return;
     float *f = a.f + o;
     const float f1 = f[S], f2 = f[2 * S], f3 = f[3 * S], f4 = f[4 * S], f5 = f[5 * S], f6 = f[6 * S], f7 = f[7 * S],
                 f8 = f[8 * S];
@@ -193,19 +197,20 @@ __global__ void k_hydro_vel(const PhaseArgs a)
                 f7 = f[7 * S], f8 = f[8 * S];
     float rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
     const float inv = 1.0f / rho;
+    const long long m = (long long)y * a.fpitch + x;
     if (x != 0 && x != a.nx - 1) {
-        a.u[o] = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
-        a.v[o] = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
+        a.u[m] = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
+        a.v[m] = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
     }
     if (x == 0 && y != 0 && y < a.ny - 1) {
         rho = (1.f / (1.f - a.u_w)) * (f0 + f2 + f4 + 2.f * (f3 + f6 + f7));
-        a.u[o] = a.u_w;
+        a.u[m] = a.u_w;
     }
     if (x == a.nx - 1 && y != 0 && y < a.ny - 1) {
         rho = (1.f / (1.f + a.u_e)) * (f0 + f2 + f4 + 2.f * (f1 + f5 + f8));
-        a.u[o] = a.u_e;
+        a.u[m] = a.u_e;
     }
-    a.rho[o] = rho;
+    a.rho[m] = rho;
 }
 
 // ---- the reference's CPU ("Cython") path as GPU kernels -------------------------------------------
@@ -224,20 +229,20 @@ __global__ void k1_bcs(const PhaseArgs a)
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
     const int lx = a.nx - 1, ly = a.ny - 1;
-    const long long o = (long long)y * a.pitch + x, S = a.plane;
+    const long long o = (long long)y * a.pitch + x, S = a.plane, m = (long long)y * a.fpitch + x;
     float *f = a.f + o;
     const bool edge = (x == 0 || x == lx || y == 0 || y == ly);
-    const bool solid = a.mask && a.mask[o];
+    const bool solid = a.mask && a.mask[m];
     if (!edge && !solid) return;
     Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
     if (x == 0 && y >= 1 && y < ly) {                         // inlet, stored u of the previous update_hydro
-        const float u0 = a.u[o], t = (1.f / 6.f) * u0 * a.rho_in;
+        const float u0 = a.u[m], t = (1.f / 6.f) * u0 * a.rho_in;
         const float f2 = c.f2, f4 = c.f4;
         c.f1 = c.f3 + (2.f / 3.f) * a.rho_in * u0;
         c.f5 = (-.5f * f2 + .5f * f4) + c.f7 + t;
         c.f8 = (.5f * f2 - .5f * f4) + c.f6 + t;
     } else if (x == lx && y >= 1 && y < ly) {                 // outlet
-        const float ul = a.u[o], t = (1.f / 6.f) * ul * a.rho_out;
+        const float ul = a.u[m], t = (1.f / 6.f) * ul * a.rho_out;
         const float f2 = c.f2, f4 = c.f4;
         c.f3 = c.f1 - (2.f / 3.f) * a.rho_out * ul;
         c.f6 = (-.5f * f2 + .5f * f4) + c.f8 - t;
@@ -312,9 +317,10 @@ __global__ void k1_hydro(const PhaseArgs a)
     const long long o = (long long)y * a.pitch + x, S = a.plane;
     const float *f = a.f + o;
     float rho, ux, uy;
-    c1_moments(a, x, y, a.mask && a.mask[o], f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S],
+    const long long m = (long long)y * a.fpitch + x;
+    c1_moments(a, x, y, a.mask && a.mask[m], f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S],
                f[8 * S], rho, ux, uy);
-    a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy;
+    a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy;
 }
 
 // One Cython-path time step after its boundary phase, fused: the restricted pull of k1_move, the moments of
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
     const int lx = a.nx - 1, ly = a.ny - 1;
-    const long long o = (long long)y * a.pitch + x, S = a.plane, P = a.pitch;
+    const long long o = (long long)y * a.pitch + x, S = a.plane, P = a.pitch, m = (long long)y * a.fpitch + x;
     const bool up = (y >= 1), dn = (y <= ly - 1), le = (x >= 1), ri = (x <= lx - 1);
     // k: moved (cython_dim.pyx:271-299)                    source when moved
     const float f0 = a.f[o];
@@ -341,9 +347,9 @@ __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
     const float f3 = a.f[3 * S + ((dn && ri) ? o + 1 : o)];              // 3,7: j <= ly-1, i <= lx-1
     const float f7 = a.f[7 * S + ((dn && ri) ? o + P + 1 : o)];
     float rho, ux, uy;
-    c1_moments(a, x, y, a.mask && a.mask[o], f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
-    if (MACRO) { a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy; }
-    else if (x == 0 || x == lx) a.u[o] = ux;
+    c1_moments(a, x, y, a.mask && a.mask[m], f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
+    if (MACRO) { a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy; }
+    else if (x == 0 || x == lx) a.u[m] = ux;
     const float usq = ux * ux + uy * uy;
     const float fk[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
 #pragma unroll
@@ -361,17 +367,17 @@ struct HaloTable {
     int n;
 };
 
-// Copy two runs of whole rows ([pitch] floats each) of `gridDim.z` planes from one plane set into another: run A = n_a rows
-// src row sa.. -> dst row da.., run B = n_b rows sb.. -> db..; 16 bytes per lane (pitch % 64 == 0).  The velocity-inlet
-// family's band scheme (lb_hip.cpp vel_band_pass) moves its wall-row bands with it.
-__global__ void k_rows_copy(const float *src, float *dst, long long plane_src, long long plane_dst, int pitch, int n_a, int sa,
-                            int da, int n_b, int sb, int db)
+// Copy two runs of whole rows (`width` floats each, rows `rs_src` / `rs_dst` floats apart) of `gridDim.z` planes from one plane set into
+// another: run A = n_a rows src row sa.. -> dst row da.., run B = n_b rows sb.. -> db..; 16 bytes per lane (width % 64 == 0).
+// The velocity-inlet family's band scheme (lb_hip.cpp vel_band_pass) moves its wall-row bands with it.
+__global__ void k_rows_copy(const float *src, float *dst, long long plane_src, long long plane_dst, int width, long long rs_src,
+                            long long rs_dst, int n_a, int sa, int da, int n_b, int sb, int db)
 {
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, j = blockIdx.y, k = blockIdx.z;
-    if (x4 >= pitch || j >= n_a + n_b) return;
+    if (x4 >= width || j >= n_a + n_b) return;
     const int rs = j < n_a ? sa + j : sb + (j - n_a), rd = j < n_a ? da + j : db + (j - n_a);
-    *reinterpret_cast<f4a *>(dst + k * plane_dst + (long long)rd * pitch + x4) =
-        *reinterpret_cast<const f4a *>(src + k * plane_src + (long long)rs * pitch + x4);
+    *reinterpret_cast<f4a *>(dst + k * plane_dst + rd * rs_dst + x4) =
+        *reinterpret_cast<const f4a *>(src + k * plane_src + rs * rs_src + x4);
 }
 
 // One wave moves 1 KiB of a row segment: 16 bytes per lane when nx is a multiple of 4 (row starts and buffer segments are

@@ -322,9 +322,10 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
 #pragma unroll
                 for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
                 if (MACRO) {
-                    store4<false>(lane_ptr(a.rho + o, x4), r4);
-                    store4<false>(lane_ptr(a.u + o, x4), u4);
-                    store4<false>(lane_ptr(a.v + o, x4), v4);
+                    const long long m = (long long)r4_ * a.fpitch;
+                    store4<false>(lane_ptr(a.rho + m, x4), r4);
+                    store4<false>(lane_ptr(a.u + m, x4), u4);
+                    store4<false>(lane_ptr(a.v + m, x4), v4);
                 }
             }
         } else {

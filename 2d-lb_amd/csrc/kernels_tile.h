@@ -82,7 +82,7 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
             const long long o = (long long)sy * P + sx;
 #pragma unroll
             for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
-            lmask[c] = (MASK && sx == gx && sy == gy) ? a.mask[o] : 0;
+            lmask[c] = (MASK && sx == gx && sy == gy) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
         }
     }
     __syncthreads();
@@ -127,7 +127,7 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
             float *d = a.dst + o;
             d[0] = q.f0; d[S] = q.f1; d[2 * S] = q.f2; d[3 * S] = q.f3; d[4 * S] = q.f4;
             d[5 * S] = q.f5; d[6 * S] = q.f6; d[7 * S] = q.f7; d[8 * S] = q.f8;
-            if (MACRO) { a.rho[o] = rho; a.u[o] = ux; a.v[o] = uy; }
+            if (MACRO) { const long long m = (long long)gy * a.fpitch + gx; a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy; }
         }
     };
     auto cell_put = [&](int c, const Cell &q) {

@@ -10,12 +10,16 @@
 //   LB_D2Q9/dimensionless/opencl_dim.py   the pyopencl buffer/queue plumbing (:203-255, 291-293,
 //                                 323-327, 395-407) and the per-step launch sequence of run() (:372-387)
 //
-// Device layout: structure of arrays, nine planes per lattice, two lattices
-// (A/B).  Inside a plane a row is `pitch` floats (nx rounded up to 64 floats = 256 B), rows -GHOST..-1 and
-// H..H+GHOST-1 are ghost rows (GHOST = 8: slab halo, deep enough for two four-step launches per exchange /
-// don't-care at walls), so element (k, x, y) of a slab of H rows lives at
-//   lattice + GUARD + k*plane + (y+GHOST)*pitch + x ;
-// the obstacle mask is uint8 [H + 2*LB_MASK_HALO_ROWS][pitch], row y at mask + y*pitch (7 rows of each neighbour).
+// Device layout: structure of arrays, nine planes per lattice, two lattices (A/B).  A plane-row
+// is `pitch` floats (nx rounded up to 64 floats = 256 B); the nine plane-rows of one lattice row are stored together
+// ([row][plane][pitch]: the marching kernels then stream 2 regions per segment instead of 18 -- +12 % at 8192^2,
+// profiles/r02_experiments.txt; LB_FLAG_PLANAR keeps each plane contiguous, [plane][row][pitch]).  Rows -GHOST..-1 and
+// H..H+GHOST-1 are ghost rows (GHOST = 8: slab halo, deep enough for two four-step launches per exchange / don't-care
+// at walls), so element (k, x, y) of a slab of H rows lives at
+//   lattice + GUARD + (y+GHOST)*rowp + k*plane + x,      rowp = 9*pitch, plane = pitch   (planar: rowp = pitch,
+//                                                         plane = (H+2*GHOST)*pitch);
+// rho, u, v are [H][pitch]; the obstacle mask is uint8 [H + 2*LB_MASK_HALO_ROWS][pitch], row y at mask + y*pitch
+// (7 rows of each neighbour).
 // Source layout (one translation unit): d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2,
 // k_step3), kernels_step4.h (k_step4), kernels_tile.h (k_tile4), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
@@ -128,12 +132,13 @@ int rccl_load()
 struct lb_sim {
     lb_params p;
     int H = 0;                  // rows owned
-    long long pitch = 0, plane = 0, lat_floats = 0;
+    long long pitch = 0, rowp = 0, plane = 0, lat_floats = 0;   // padded row width; lattice row / plane strides; floats per lattice
     float *lat[2] = {nullptr, nullptr};   // raw allocations (with guards)
     int cur = 0;                // lattice holding f
     int stepping = 0;           // 1 between lb_step_boundary and lb_step_finish
     float *feq = nullptr;       // raw allocation, lazily created
     float *rho = nullptr, *u = nullptr, *v = nullptr;
+    float *stage = nullptr;     // [H][pitch], lazily: one plane on its way between the host and interleaved rows (lattice_plane_*)
     float *vi_corner = nullptr; // VELOCITY_INLET: the eight corner links nothing ever writes (bc_vel_cell), device
     lb_sim *band[2] = {nullptr, nullptr};   // VELOCITY_INLET: the wall-row bands of a three- / four-step pass (vel_band_pass)
     uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
@@ -158,8 +163,8 @@ struct lb_sim {
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
     int64_t bytes = 0;
 
-    float *origin(int which) const { return lat[which] + GUARD + GHOST * pitch; }   // plane 0, row 0, x 0
-    float *feq_origin() const { return feq + GUARD + GHOST * pitch; }
+    float *origin(int which) const { return lat[which] + GUARD + GHOST * rowp; }   // plane 0, row 0, x 0
+    float *feq_origin() const { return feq + GUARD + GHOST * rowp; }
     bool multi_slab() const { return H != p.ny || (p.flags & LB_FLAG_HALO); }
 };
 
@@ -181,7 +186,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.dst = s->origin(s->cur ^ 1);
     a.mask = s->has_mask ? s->mask : nullptr;
     a.rho = s->rho; a.u = s->u; a.v = s->v;
-    a.plane = s->plane; a.pitch = (int)s->pitch;
+    a.plane = s->plane; a.pitch = (int)s->rowp; a.fpitch = (int)s->pitch;
     a.nx = s->p.nx; a.ny = s->p.ny; a.y0 = s->p.y0; a.h = s->H;
     a.row_begin = row_begin; a.row_step = row_step; a.row_count = row_count;
     a.wrap_y = (s->p.bc_mode == LB_BC_PERIODIC && !s->multi_slab()) ? 1 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? 2 : 0);
@@ -516,7 +521,7 @@ PhaseArgs phase_args(const lb_sim *s)
     a.feq = s->feq ? s->feq_origin() : nullptr;
     a.rho = s->rho; a.u = s->u; a.v = s->v;
     a.mask = s->has_mask ? s->mask : nullptr;
-    a.plane = s->plane; a.pitch = (int)s->pitch; a.nx = s->p.nx; a.ny = s->p.ny; a.bc = kernel_bc(s);
+    a.plane = s->plane; a.pitch = (int)s->rowp; a.fpitch = (int)s->pitch; a.nx = s->p.nx; a.ny = s->p.ny; a.bc = kernel_bc(s);
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     a.u_w = s->p.inlet_u; a.u_e = s->p.outlet_u;
@@ -551,6 +556,32 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
     HIP_TRY(hipMemcpy2DAsync(host, s->p.nx * sizeof(float), dev, s->pitch * sizeof(float),
                              s->p.nx * sizeof(float), s->H, hipMemcpyDeviceToHost, s->stream));
     return LB_OK;
+}
+
+// One plane of a lattice (f or feq; `origin` = its plane 0, row 0): host [H][nx] <-> device.  Planar layout: the plane is one
+// pitched block.  Interleaved rows: through the staging plane -- one DMA plus one device kernel instead of H strided
+// row copies (everything on the handle's stream, so the staging plane is reused plane after plane).
+int lattice_plane_h2d(lb_sim *s, float *origin, int k, const float *host)
+{
+    if (s->rowp == s->pitch) return copy_plane_h2d(s, origin + k * s->plane, host);
+    if (!s->stage) HIP_TRY(hipMalloc(&s->stage, sizeof(float) * s->pitch * s->H));
+    int rc = copy_plane_h2d(s, s->stage, host);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)s->H, 1);
+    hipLaunchKernelGGL(k_rows_copy, grid, dim3(256), 0, s->stream, (const float *)s->stage, origin + k * s->plane, 0LL, 0LL,
+                       (int)s->pitch, s->pitch, s->rowp, s->H, 0, 0, 0, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+int lattice_plane_d2h(lb_sim *s, float *host, const float *origin, int k)
+{
+    if (s->rowp == s->pitch) return copy_plane_d2h(s, host, origin + k * s->plane);
+    if (!s->stage) HIP_TRY(hipMalloc(&s->stage, sizeof(float) * s->pitch * s->H));
+    const dim3 grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)s->H, 1);
+    hipLaunchKernelGGL(k_rows_copy, grid, dim3(256), 0, s->stream, origin + k * s->plane, s->stage, 0LL, 0LL, (int)s->pitch,
+                       s->rowp, s->pitch, s->H, 0, 0, 0, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return copy_plane_d2h(s, host, s->stage);
 }
 
 // Halo of a slab edge, D rows deep: contiguous nx-float row segments ("plane-rows") of the D rows next
@@ -608,7 +639,7 @@ const HaloSeg *const NORTH_IN = HALO3.pos;    // + H
 float *halo_ptr(const lb_sim *s, int which, const HaloSeg &h, bool north)
 {
     const long long row = (north ? s->H : 0) + h.row;
-    return s->origin(which) + h.k * s->plane + row * s->pitch;
+    return s->origin(which) + h.k * s->plane + row * s->rowp;
 }
 
 // Pack both edges of lattice `which` into the send buffers / scatter the receive buffers into its
@@ -620,10 +651,10 @@ int halo_pack(lb_sim *s, int which, hipStream_t q, const HaloTables &T, bool to_
     const dim3 grid((s->p.nx + (vec ? 1023 : 255)) / (vec ? 1024 : 256), T.n, 2);
     float *bn = to_north ? s->halo_buf : nullptr, *bs = to_south ? s->halo_buf + n : nullptr;
     if (vec)
-        hipLaunchKernelGGL(k_halo_pack<4>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->pitch,
+        hipLaunchKernelGGL(k_halo_pack<4>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->rowp,
                            s->H, s->p.nx, bn, bs, T.device(true), T.device(false));
     else
-        hipLaunchKernelGGL(k_halo_pack<1>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->pitch,
+        hipLaunchKernelGGL(k_halo_pack<1>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->rowp,
                            s->H, s->p.nx, bn, bs, T.device(true), T.device(false));
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -633,10 +664,10 @@ int halo_unpack(lb_sim *s, int which, hipStream_t q, const HaloTables &T, const 
     const bool vec = (s->p.nx % 4) == 0;
     const dim3 grid((s->p.nx + (vec ? 1023 : 255)) / (vec ? 1024 : 256), T.n, 2);
     if (vec)
-        hipLaunchKernelGGL(k_halo_unpack<4>, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch, s->H, s->p.nx,
+        hipLaunchKernelGGL(k_halo_unpack<4>, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->rowp, s->H, s->p.nx,
                            from_south, from_north, T.device(true), T.device(false));
     else
-        hipLaunchKernelGGL(k_halo_unpack<1>, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->pitch, s->H, s->p.nx,
+        hipLaunchKernelGGL(k_halo_unpack<1>, grid, dim3(256), 0, q, s->origin(which), s->plane, (int)s->rowp, s->H, s->p.nx,
                            from_south, from_north, T.device(true), T.device(false));
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -832,16 +863,16 @@ int vel_band_pass(lb_sim *s, int d, bool macro)
     const dim3 blk(256), grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)hb, 9);
     // bands of the current lattice, of the stored u, v (the inlet / outlet columns read them) and of the mask -> band handle
     hipLaunchKernelGGL(k_rows_copy, grid, blk, 0, q, (const float *)s->origin(s->cur), b->origin(0), s->plane, b->plane,
-                       (int)s->pitch, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
+                       (int)s->pitch, s->rowp, b->rowp, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
     const dim3 grid1(grid.x, grid.y, 1);
-    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->u, b->u, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
-                       H - 2 * d, 2 * d);
-    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->v, b->v, 0LL, 0LL, (int)s->pitch, 2 * d, 0, 0, 2 * d,
-                       H - 2 * d, 2 * d);
+    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->u, b->u, 0LL, 0LL, (int)s->pitch, s->pitch, s->pitch,
+                       2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
+    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->v, b->v, 0LL, 0LL, (int)s->pitch, s->pitch, s->pitch,
+                       2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
     if (s->has_mask)       // (rows of pitch bytes = pitch / 4 floats)
         hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)((s->pitch / 16 + 255) / 256), (unsigned)hb, 1), blk, 0, q,
                            reinterpret_cast<const float *>(s->mask), reinterpret_cast<float *>(b->mask), 0LL, 0LL,
-                           (int)(s->pitch / 4), 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
+                           (int)(s->pitch / 4), s->pitch / 4, s->pitch / 4, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
     HIP_TRY(hipMemcpyAsync(b->vi_corner, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToDevice, q));
     HIP_TRY(hipGetLastError());
     // the interior, from the same source lattice, on the compute stream
@@ -852,12 +883,12 @@ int vel_band_pass(lb_sim *s, int d, bool macro)
     }
     // the band handle's outer rows -> the lattice being written
     hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 9), blk, 0, q, (const float *)b->origin(b->cur),
-                       s->origin(s->cur ^ 1), b->plane, s->plane, (int)s->pitch, d, 0, 0, d, 3 * d, H - d);
+                       s->origin(s->cur ^ 1), b->plane, s->plane, (int)s->pitch, b->rowp, s->rowp, d, 0, 0, d, 3 * d, H - d);
     if (macro) {
         float *const from[3] = {b->rho, b->u, b->v}, *const to[3] = {s->rho, s->u, s->v};
         for (int i = 0; i < 3; ++i)
             hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 1), blk, 0, q, (const float *)from[i], to[i], 0LL,
-                               0LL, (int)s->pitch, d, 0, 0, d, 3 * d, H - d);
+                               0LL, (int)s->pitch, s->pitch, s->pitch, d, 0, 0, d, 3 * d, H - d);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_boundary, q));
@@ -983,7 +1014,7 @@ int corners_capture(lb_sim *s, int which)
     CornerLink c[8];
     corner_links(s, c);
     for (int i = 0; i < 8; ++i)
-        HIP_TRY(hipMemcpyAsync(s->vi_corner + i, s->origin(which) + c[i].k * s->plane + (long long)c[i].y * s->pitch + c[i].x,
+        HIP_TRY(hipMemcpyAsync(s->vi_corner + i, s->origin(which) + c[i].k * s->plane + (long long)c[i].y * s->rowp + c[i].x,
                                sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     return LB_OK;
 }
@@ -992,7 +1023,7 @@ int corners_patch(lb_sim *s, int which)
     CornerLink c[8];
     corner_links(s, c);
     for (int i = 0; i < 8; ++i)
-        HIP_TRY(hipMemcpyAsync(s->origin(which) + c[i].k * s->plane + (long long)c[i].y * s->pitch + c[i].x, s->vi_corner + i,
+        HIP_TRY(hipMemcpyAsync(s->origin(which) + c[i].k * s->plane + (long long)c[i].y * s->rowp + c[i].x, s->vi_corner + i,
                                sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     return LB_OK;
 }
@@ -1038,7 +1069,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     if (!(p->omega > 0.f && p->omega < 2.f)) return fail(LB_ERR_ARG, "omega must be in (0,2), got %g", p->omega);
     for (int r : p->reserved)
         if (r != 0) return fail(LB_ERR_ARG, "reserved fields must be zero");
-    if (p->flags & ~LB_FLAG_HALO) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(LB_FLAG_HALO | LB_FLAG_PLANAR)) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
     if (p->semantics != LB_SEM_OPENCL && p->semantics != LB_SEM_CYTHON && p->semantics != LB_SEM_OPENCL_D2Q9I)
         return fail(LB_ERR_ARG, "unknown semantics %d", p->semantics);
     if (p->semantics == LB_SEM_OPENCL_D2Q9I &&
@@ -1059,8 +1090,14 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->pitch = ((long long)p->nx + 63) / 64 * 64;
     // (padding the row pitch or skewing the plane stride away from powers of two was measured:
     //  no gain for k_step2, -5..-8 % for k_step -- profiles/r01_sweep_variants.txt)
-    s->plane = (long long)(s->H + 2 * GHOST) * s->pitch;
-    s->lat_floats = 9 * s->plane + 2 * GUARD;
+    if (p->flags & LB_FLAG_PLANAR) {
+        s->rowp = s->pitch;
+        s->plane = (long long)(s->H + 2 * GHOST) * s->pitch;
+    } else {
+        s->rowp = 9 * s->pitch;
+        s->plane = s->pitch;
+    }
+    s->lat_floats = 9 * (long long)(s->H + 2 * GHOST) * s->pitch + 2 * GUARD;
     if (const char *e = getenv("LB_VARIANT")) s->variant = atoi(e);
     if (const char *e = getenv("LB_DIAG")) s->diag = atoi(e);
     {
@@ -1129,7 +1166,7 @@ int lb_destroy(lb_sim *s)
         if (b) { b->stream = b->own_stream; lb_destroy(b); b = nullptr; }
     }
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner})
+    for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner, s->stage})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
     for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_t0, s->ev_t1})
@@ -1208,7 +1245,7 @@ int lb_set_f(lb_sim *s, const float *f)
     DeviceGuard guard(s->p.device);
     const size_t host_plane = (size_t)s->p.nx * s->H;
     for (int k = 0; k < 9; ++k) {
-        int rc = copy_plane_h2d(s, s->origin(s->cur) + k * s->plane, f + k * host_plane);
+        int rc = lattice_plane_h2d(s, s->origin(s->cur), k, f + k * host_plane);
         if (rc) return rc;
     }
     // f_streamed = f (opencl_dim.py:323-327)
@@ -1228,7 +1265,7 @@ int lb_get_f(lb_sim *s, float *f)
     HIP_TRY(hipStreamSynchronize(s->comm_stream));
     const size_t host_plane = (size_t)s->p.nx * s->H;
     for (int k = 0; k < 9; ++k) {
-        int rc = copy_plane_d2h(s, f + k * host_plane, s->origin(s->cur) + k * s->plane);
+        int rc = lattice_plane_d2h(s, f + k * host_plane, s->origin(s->cur), k);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1264,7 +1301,7 @@ int lb_get_feq(lb_sim *s, float *feq)
     if (!s->feq_valid && (rc = lb_update_feq(s))) return rc;
     const size_t host_plane = (size_t)s->p.nx * s->H;
     for (int k = 0; k < 9; ++k)
-        if ((rc = copy_plane_d2h(s, feq + k * host_plane, s->feq_origin() + k * s->plane))) return rc;
+        if ((rc = lattice_plane_d2h(s, feq + k * host_plane, s->feq_origin(), k))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return LB_OK;
 }

@@ -671,3 +671,54 @@ def test_autotune_is_transparent(lbhip, oracle):
     ref2.set_variant(0); ref2.set_f(f0); ref2.run(760)
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(b.get_fields((k,))[k], ref2.get_fields((k,))[k]), k
+
+
+@pytest.mark.parametrize("family", ["pipe_mask", "velocity_inlet", "cython", "d2q9i", "periodic_halo"])
+def test_planar_layout_equals_interleaved_rows(lbhip, family):
+    """The two device layouts of the lattices (rows interleaving the nine planes = default; LB_FLAG_PLANAR = each plane
+    contiguous) are a matter of strides only: same kernels, same bits -- every family, the phase kernels, set / get of f
+    and feq, the halo interface."""
+    from LB_D2Q9.simulation import Simulation
+    rng = np.random.default_rng(77)
+    nx, ny, steps = 600, 140, 11
+    kw = dict(bc="pipe", inlet_rho=1.004)
+    if family == "pipe_mask":
+        mask = rng.random((nx, ny)) < 0.04
+        mask[0, :] = mask[-1, :] = False
+        mask[:, 0] = mask[:, -1] = False
+        kw["obstacle_mask"] = mask
+    elif family == "velocity_inlet":
+        kw = dict(bc="velocity_inlet", inlet_u=0.03)
+    elif family in ("cython", "d2q9i"):
+        kw["semantics"] = family
+    elif family == "periodic_halo":
+        kw = dict(bc="periodic", halo=True)
+    f0 = _random_state(rng, nx, ny)
+    out = []
+    for planar in (False, True):
+        s = Simulation(nx, ny, 1.3, planar=planar, **kw)
+        assert s.layout()["planar"] == planar
+        assert s.layout()["plane_stride"] == (s.layout()["pitch"] * (ny + 16) if planar else s.layout()["pitch"])
+        s.set_f(f0)
+        assert np.array_equal(s.get_fields(("f",))["f"], f0)
+        if family == "periodic_halo":
+            buf = np.zeros((2, s.halo_floats()), np.float32)
+
+            def exchange():                         # the ring of one slab with itself through the halo interface
+                s.halo_export(0, buf[0]); s.halo_export(1, buf[1])
+                s.sync()
+                s.halo_import(0, buf[1]); s.halo_import(1, buf[0])
+                s.sync()
+            exchange()
+            for it in range(steps):
+                s.step_boundary(it == steps - 1); s.step_interior(it == steps - 1)
+                exchange()
+                s.step_finish()
+            s.update_feq()
+        else:
+            s.run(steps)
+            s.move_bcs(); s.update_hydro(); s.update_feq()          # the un-fused phases, too
+        out.append(s.get_fields(("f", "feq", "rho", "u", "v")))
+        s.close()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), (family, k)

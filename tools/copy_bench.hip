@@ -82,11 +82,19 @@ __global__ __launch_bounds__(128) void march_copy(const f4 *__restrict__ src, f4
     const long long row4 = n / 4;
     for (int y = y0; y < y1; ++y) {
         f4 v[9];
-        const long long o = LAYOUT == 0 ? (long long)y * row4 + s * 64 + lane : ((long long)s * n + y) * 64 + lane;
+        // LAYOUT 2: [row][plane][8192] (the nine planes of a row interleaved: 18 fronts per segment become 2);
+        // 3: [row][strip][plane][256] (a wave's nine 1 KiB accesses are one 9 KiB block); 4: [strip][row][plane][256]
+        // (a wave's whole march is one contiguous stream)
+        long long o, ks = plane4;
+        if (LAYOUT == 0) o = (long long)y * row4 + s * 64 + lane;
+        else if (LAYOUT == 1) o = ((long long)s * n + y) * 64 + lane;
+        else if (LAYOUT == 2) { o = (long long)y * 9 * row4 + s * 64 + lane; ks = row4; }
+        else if (LAYOUT == 3) { o = ((long long)y * strips + s) * 9 * 64 + lane; ks = 64; }
+        else { o = ((long long)s * n + y) * 9 * 64 + lane; ks = 64; }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = src[k * plane4 + o];
+        for (int k = 0; k < 9; ++k) v[k] = src[k * ks + o];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * plane4 + o);
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(v[k], dst + k * ks + o);
     }
 }
 
@@ -221,6 +229,12 @@ int main()
         RUN(nm, hipLaunchKernelGGL(march_copy<0>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
         snprintf(nm, sizeof nm, "march_copy strip-major planes, %2d waves/CU, %3d-row segments", wpc, seg_rows);
         RUN(nm, hipLaunchKernelGGL(march_copy<1>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
+        snprintf(nm, sizeof nm, "march_copy [row][plane][x],         %2d waves/CU, %3d-row segments", wpc, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy<2>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
+        snprintf(nm, sizeof nm, "march_copy [row][strip][plane][256], %2d waves/CU, %3d-row segments", wpc, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy<3>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
+        snprintf(nm, sizeof nm, "march_copy [strip][row][plane][256], %2d waves/CU, %3d-row segments", wpc, seg_rows);
+        RUN(nm, hipLaunchKernelGGL(march_copy<4>, dim3(items / 2), dim3(64, 2), 0, 0, src, dst, plane4, n, strips, seg_rows));
     }
     for (int wpc : {8, 12, 16, 24}) {
         const int strips = n / 128, segs = 256 * wpc / strips, seg_rows = (n + segs - 1) / segs, items = strips * segs;
