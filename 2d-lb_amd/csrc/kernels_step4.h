@@ -152,6 +152,11 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     int item_ = xcd_item(blockIdx.x, gridDim.x) * STEP4_WAVES + wy;         // (XCD-transposed order, as k_step3)
 #ifdef LB_DIAG
     if (a.diag & 8192) item_ ^= 1;                      // experiment: wave 0 of the workgroup takes the odd strip
+    if (a.diag & 65536) item_ = blockIdx.x * STEP4_WAVES + wy;              // experiment: no XCD transposition
+    if (a.diag & 131072) {                              // experiment: consecutive workgroups walk down one strip pair's segments
+        const int wg = blockIdx.x, pairs = strips / STEP4_WAVES;
+        if (pairs * STEP4_WAVES == strips) item_ = ((wg % nsegs) * pairs + wg / nsegs) * STEP4_WAVES + wy;
+    }
 #endif
     const int item = item_;
     int sx = item % strips, ya, yb;
