@@ -22,6 +22,7 @@ struct StepArgs {
                            //    rows pull from row 1 / ny-2 in place of the row outside (bc_vel_cell)
     int ghost_s, ghost_n;  // slab has a neighbour below / above: ghost rows hold its edge rows
     int seg_stride;        // k_step2: first row of segment i = row_begin + i*seg_stride
+    int edge_seg_rows;     // k_step4: > 0: the first and the last strip march segments of this many rows (see the kernel)
     int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
     int prio_turns;        // k_step4: the two waves of a SIMD alternate their issue priority (bit of the 100 MHz clock)
     float omega, rho_in, rho_out, lid_u, rho0;

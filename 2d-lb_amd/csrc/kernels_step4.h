@@ -159,14 +159,27 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     }
 #endif
     const int item = item_;
-    int sx = item % strips, ya, yb;
+    // items [0, strips * nsegs): segment item / strips of strip item % strips.  Behind them, where the box has walls at its
+    // left and right end (a.edge_seg_rows > 0): further segments of the first and the last strip only.  Those two strips run
+    // the inlet / outlet / wall rule for one cell per row and stage, which makes their rows ~18 % dearer; with equal segments
+    // their waves were the last to finish by that margin in every launch (tools/wave_timeline.py), so they get shorter ones.
+    int sx, sy, ya, yb;
     const unsigned slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u;       // HW_REG_HW_ID wave_id bit 0: my slot on the SIMD
+    if (item < strips * nsegs) {
+        sx = item % strips;
+        sy = item / strips;
+    } else {
+        if (!a.edge_seg_rows) return;
+        const int j = item - strips * nsegs;
+        sx = (j & 1) ? strips - 1 : 0;
+        sy = nsegs + (j >> 1);
+    }
     {
-        const int sy = item / strips;
-        if (sy >= nsegs) return;
-        ya = a.row_begin + sy * a.seg_stride;
+        int stride = a.seg_stride, rows = seg_rows;
+        if (a.edge_seg_rows && (sx == 0 || sx == strips - 1)) stride = rows = a.edge_seg_rows;
+        ya = a.row_begin + sy * stride;
         if (ya >= row_end) return;
-        yb = min(ya + seg_rows, row_end);
+        yb = min(ya + rows, row_end);
     }
     const int x0 = sx * STRIP_W;
     const int xr = x0 + lane * 4;

@@ -195,6 +195,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.ghost_s = (s->multi_slab() && (periodic || s->p.y0 > 0)) ? 1 : 0;
     a.ghost_n = (s->multi_slab() && (periodic || s->p.y0 + s->H < s->p.ny)) ? 1 : 0;
     a.seg_stride = 0;
+    a.edge_seg_rows = 0;
     a.diag = s->diag;
     a.prio_turns = 0;      // (set by launch_step2 from the variant)
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
@@ -387,7 +388,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
     const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
-    int segs, seg_rows;
+    int segs, seg_rows, extra_items = 0;
     if (nsegs_fixed > 0) {
         segs = nsegs_fixed;
         seg_rows = seg_rows_fixed;
@@ -409,8 +410,27 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         if (seg_rows < 4) seg_rows = 4;
         segs = (rows + seg_rows - 1) / seg_rows;
         a.seg_stride = seg_rows;
+        // k_step4 in a box with walls at its left and right end: the two wall-column strips get shorter segments (their
+        // rows cost edge_cost times an interior strip's: the boundary rule of one cell per row and stage -- measured per
+        // wave, tools/wave_timeline.py: +18 % pipe, +10..16 % cavity; the velocity-inlet columns also read the stored u, v),
+        // within the same number of wave slots: pipe / cavity +5..8 %, velocity inlet +19..30 % (profiles/r02_experiments.txt)
+        static const double edge_env = getenv("LB_EDGE_COST") ? atof(getenv("LB_EDGE_COST")) : 0.0;          // tuning knob
+        const double edge_cost = edge_env > 0.0 ? edge_env : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? 1.6 : 1.2);
+        if (depth == 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
+            const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
+            const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
+            const int rows_i = (rows + segs_i - 1) / segs_i, rows_e = (rows + segs_e - 1) / segs_e;
+            if (segs_i >= 1 && segs_e > segs_i && rows_e >= 8) {
+                seg_rows = rows_i;
+                segs = (rows + rows_i - 1) / rows_i;
+                a.seg_stride = rows_i;
+                a.edge_seg_rows = rows_e;
+                extra_items = 2 * ((rows + rows_e - 1) / rows_e - segs);
+                if (extra_items < 0) extra_items = 0, a.edge_seg_rows = 0;
+            }
+        }
     }
-    const int items = strips * segs;
+    const int items = strips * segs + extra_items;
     const bool nts = (variant & 1) != 0;
     // k_step4: the two waves of a SIMD take turns at the higher issue priority (see the kernel); variant bit 11 = off
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-wave timeline of one k_step4 launch (diagnostic build, LB_DIAG bit 12): when each wave started and ended, on which
-XCD / CU.  Usage (GPU box): python tools/wave_timeline.py [n] [waves_per_cu]"""
+XCD / CU.  Usage (GPU box): [LB_TIMELINE_BC=pipe] python tools/wave_timeline.py [n] [waves_per_cu]"""
 import os
 import sys
 
@@ -18,7 +18,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     from LB_D2Q9.simulation import Simulation
     from bench import shear_layer
-    sim = Simulation(n, n, 1.7, bc="periodic")
+    sim = Simulation(n, n, 1.7, bc=os.environ.get("LB_TIMELINE_BC", "periodic"), inlet_rho=1.0005)
     sim.set_variant(353)
     sim.init_equilibrium(*shear_layer(n, n, 0, n))
     sim.run(8)
@@ -33,6 +33,8 @@ def main():
     seg_rows = max(-(-n // segs), 4)
     segs = -(-n // seg_rows)
     items = strips * segs
+    # (boxes with walls: the first / last strip march shorter segments, their extra items follow: read what is there)
+    items = min(items + 4 * segs, u.size // 8)
     rec = u[:8 * items].reshape(items, 8).astype(np.int64)
     t0 = rec[:, 0] | (rec[:, 1] << 32)
     t1 = rec[:, 2] | (rec[:, 3] << 32)
@@ -59,7 +61,10 @@ def main():
     for ws in sorted(set(wave_slot.tolist())):
         m = wave_slot == ws
         print("wave slot %d: %4d waves, end median %.1f us" % (ws, m.sum(), np.median(end[m])))
-    sx, sy = rec[:, 6] % strips, rec[:, 6] // strips
+    it_id = rec[:, 6]
+    nseg_main = int(os.environ.get("LB_TIMELINE_NSEGS", segs))       # segments of the interior strips (= segs unless walls)
+    sx = np.where(it_id < strips * nseg_main, it_id % strips, np.where((it_id - strips * nseg_main) & 1, strips - 1, 0))
+    sy = np.where(it_id < strips * nseg_main, it_id // strips, nseg_main + ((it_id - strips * nseg_main) >> 1))
     order = np.argsort(-end)[:24]
     print("slowest waves (end us, strip, segment, XCD, CU, SIMD, slot):",
           " ".join("(%.0f,%d,%d,%d,%d,%d,%d)" % (end[i], sx[i], sy[i], xcc[i], cu[i], simd[i], wave_slot[i]) for i in order))
