@@ -143,6 +143,36 @@ def test_full_size_families_four_step_kernel_equals_single_step_kernel_bitwise(l
     assert np.all(np.isfinite(out[0])) and np.array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("bc,nx,ny,masked", [("pipe", 3751, 1251, True), ("cavity", 2048, 2048, False),
+                                             ("velocity_inlet", 4096, 1000, False), ("pipe", 5000, 700, False),
+                                             ("velocity_inlet", 2304, 3000, True), ("pipe", 1024, 6000, False)])
+def test_wall_column_strips_with_shorter_segments_bitwise(lbhip, bc, nx, ny, masked):
+    """In the wall families k_step4 gives the first and the last strip (the wall columns) shorter segments than the others
+    (lb_hip.cpp launch_step2: `edge_seg_rows`); grids of many shapes -- few / many strips, short / tall, odd widths, with a mask,
+    the velocity-inlet family's interior pass -- against the single-step kernel, bit for bit, 4 + 4 + 3 steps."""
+    from LB_D2Q9.simulation import Simulation
+    rng = np.random.default_rng(nx + ny)
+    mask = None
+    if masked:
+        mask = rng.random((nx, ny)) < 0.01
+        mask[0, :] = mask[-1, :] = False
+        mask[:, 0] = mask[:, -1] = False
+    rho = (1.0 + 1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
+    u = (0.02 + 1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
+    v = (1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
+    out = []
+    for variant in (353, 9):
+        sim = Simulation(nx, ny, 1.5, bc=bc, inlet_rho=1.0005, lid_u=0.05, inlet_u=0.02, obstacle_mask=mask)
+        sim.set_variant(variant)
+        sim.init_equilibrium(rho, u, v)
+        sim.run(8)
+        sim.run(3)
+        out.append(sim.get_fields(("f", "rho", "u", "v")))
+        sim.close()
+    for k in out[0]:
+        assert np.all(np.isfinite(out[0][k])) and np.array_equal(out[0][k], out[1][k]), k
+
+
 def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
     """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, four-step kernel, 8-deep halo)
     executed as in-library virtual slabs on one device: bitwise equal to the undivided run."""
