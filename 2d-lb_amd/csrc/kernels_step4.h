@@ -123,6 +123,11 @@ __device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool
     o.hc = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (o.have) {
         gather_issue<BC, MASK, false>(a, x4, o.rr, ym, yp, o.q, o.mk, o.wp);
+#ifdef LB_DIAG
+        // timing only: 262144 = no halo-cell loads at all, 524288 = none on the side facing the workgroup's other wave
+        const bool inner_side = (threadIdx.y == 0) ? (hx > x4) : (hx < x4);
+        if (!(a.diag & 262144) && !((a.diag & 524288) && inner_side))
+#endif
         if (halo1) halo_cell_load<BC, MASK>(a, hx, o.rr, ym, yp, o.hc, o.hsolid, o.hxc);
     } else {
         o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
