@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/copy_bench.hip -o /tmp/copy_bench && /tmp/copy_bench
 // Copies 2.4 GB (one 8192^2 lattice) with 16-byte-per-lane accesses in several shapes and prints GB/s (read + written).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -191,8 +192,22 @@ int main()
     const long long plane4 = (long long)n * n / 4, n4 = 9 * plane4;
     const size_t bytes = (size_t)n4 * 16;
     f4 *src, *dst;
-    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes));
-    CK(hipMemset(src, 1, bytes)); CK(hipMemset(dst, 0, bytes));
+    const size_t slack = 8u << 20;              // room for the destination-offset experiment below
+    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes + slack));
+    CK(hipMemset(src, 1, bytes)); CK(hipMemset(dst, 0, bytes + slack));
+    if (getenv("COPY_BENCH_OFFSETS")) {
+        // does the distance between the lattice read and the lattice written matter (HBM channel / bank conflicts between
+        // the read front and the write front)?  march_copy in the interleaved-row layout, destination shifted
+        const int strips = n / 256, segs = 256 * 8 / strips, seg_rows = (n + segs - 1) / segs, items = strips * segs;
+        printf("src %p dst %p (dst - src = %lld B)\n", (void *)src, (void *)dst, (long long)((char *)dst - (char *)src));
+        for (size_t off : {(size_t)0, (size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)147456,
+                           (size_t)262144, (size_t)1048576, (size_t)2097152 + 147456}) {
+            f4 *d = dst + off / 16;
+            double ms = time_ms([&] { hipLaunchKernelGGL(march_copy<2>, dim3(items / 2), dim3(64, 2), 0, 0, src, d, plane4, n, strips, seg_rows); }, 10);
+            printf("march_copy [row][plane][x], destination + %8zu B: %7.1f us  %7.1f GB/s\n", off, ms * 1e3, 2.0 * bytes / 1e9 / (ms * 1e-3));
+        }
+        return 0;
+    }
     const double gb = 2.0 * bytes / 1e9;
 #define RUN(name, ...) do { double ms = time_ms([&] { __VA_ARGS__; }, 10); printf("%-58s %7.1f us  %7.1f GB/s\n", name, ms * 1e3, gb / (ms * 1e-3)); } while (0)
     for (int blocks : {256 * 2, 256 * 4, 256 * 8, 256 * 16, 256 * 32}) {
