@@ -658,6 +658,9 @@ def test_autotune_is_transparent(lbhip, oracle):
     a.set_f(f0)
     used = a.autotune()
     assert used > 0 and a.steps_per_launch() in (1, 2, 3, 4)
+    name = a.hot_kernel()                         # names the kernel; a marching kernel also its tuned waves per CU
+    assert name.startswith("k_") and "<PIPE, MASK>" in name
+    assert ("tuned:" in name) == (a.steps_per_launch() > 1 and "k_tile4" not in name)
     ref.run(used)
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(a.get_fields((k,))[k], ref.get_fields((k,))[k]), k
