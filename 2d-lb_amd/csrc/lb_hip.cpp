@@ -237,15 +237,17 @@ void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, b
 // profiles/r01_sweep_variants.txt):
 //   >= 1024^2 / 1280^2 cells on this GPU : temporal blocking -- three / four time steps per pass (marching
 //                                          kernels; nx >= 512 and enough rows, else they do not apply)
-//   lattice pair >= 1 GB (4096^2 up)     : + non-temporal stores (+3..6 %), and 2 rows x 512 cells per
-//                                          workgroup wherever the single-step kernel runs
+//   lattice pair >= 1 GB (4096^2 up)     : + non-temporal stores (+3..6 %), and 4 rows x 256 cells per
+//                                          workgroup wherever the single-step kernel runs (with contiguous
+//                                          planes 2 x 512 was the better shape; with interleaved rows 4 x 256
+//                                          streams 3..8 % faster at 4096^2 / 8192^2: profiles/r02_experiments.txt)
 //   smaller (Infinity-Cache resident)    : single step, plain stores, XCD-aware tile order
 int effective_variant(const lb_sim *s)
 {
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
-    int v = pair_bytes >= 1.0e9 ? 9 : 16;
+    int v = pair_bytes >= 1.0e9 ? ((s->p.flags & LB_FLAG_PLANAR) ? 9 : 1) : 16;
     // from 1024^2 cells: three steps per pass (110 k MLUPS at 1024^2 against 87 k single-step); from 1280^2:
     // four (125 k at 1280^2, 158 k at 1536^2, 170 k at 2048^2, 220 k from 3072^2), whole grids and slabs alike,
     // in every boundary family, with and without obstacles (profiles/r01_sweep_variants.txt,
