@@ -582,17 +582,23 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
 
 // One plane of a lattice (f or feq; `origin` = its plane 0, row 0): host [H][nx] <-> device.  Planar layout: the plane is one
 // pitched block.  Interleaved rows: through the staging plane -- one DMA plus one device kernel instead of H strided
-// row copies (everything on the handle's stream, so the staging plane is reused plane after plane).
+// row copies.  The staging plane is reused plane after plane, and a copy between PAGEABLE host memory and the device is
+// not ordered behind the kernels already enqueued on the stream (the runtime stages it through its own buffers and may
+// start at once): with the GPU shared by several processes the next plane's upload overwrote the staging plane before the
+// scatter kernel had read it -- rows of one plane in another, every eighth row or so (tools/slab_stress.py).  Hence the
+// explicit synchronisation between the kernel and the copy, both ways.
 int lattice_plane_h2d(lb_sim *s, float *origin, int k, const float *host)
 {
     if (s->rowp == s->pitch) return copy_plane_h2d(s, origin + k * s->plane, host);
     if (!s->stage) HIP_TRY(hipMalloc(&s->stage, sizeof(float) * s->pitch * s->H));
     int rc = copy_plane_h2d(s, s->stage, host);
     if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));           // the upload has landed
     const dim3 grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)s->H, 1);
     hipLaunchKernelGGL(k_rows_copy, grid, dim3(256), 0, s->stream, (const float *)s->stage, origin + k * s->plane, 0LL, 0LL,
                        (int)s->pitch, s->pitch, s->rowp, s->H, 0, 0, 0, 0, 0);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));           // the staging plane is free again
     return LB_OK;
 }
 int lattice_plane_d2h(lb_sim *s, float *host, const float *origin, int k)
@@ -603,7 +609,11 @@ int lattice_plane_d2h(lb_sim *s, float *host, const float *origin, int k)
     hipLaunchKernelGGL(k_rows_copy, grid, dim3(256), 0, s->stream, origin + k * s->plane, s->stage, 0LL, 0LL, (int)s->pitch,
                        s->rowp, s->pitch, s->H, 0, 0, 0, 0, 0);
     HIP_TRY(hipGetLastError());
-    return copy_plane_d2h(s, host, s->stage);
+    HIP_TRY(hipStreamSynchronize(s->stream));           // the staging plane is complete
+    int rc = copy_plane_d2h(s, host, s->stage);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));           // ... and read, before the next plane is gathered into it
+    return LB_OK;
 }
 
 // Halo of a slab edge, D rows deep: contiguous nx-float row segments ("plane-rows") of the D rows next
@@ -1631,7 +1641,11 @@ int lb_run(lb_sim *s, int n_steps)
         // ghosts: e.g. 20 steps = two eight-step cycles + one four-step launch); what is left after that (< D steps) runs
         // launch by launch below.  One deep exchange serves both.
         const HaloTables &T = cycle_halo(D);
-        if (s->ghost_depth < (left >= 2 * D ? 2 * D : D)) {
+        // (a first half that is not the run's last launch recomputes D ghost rows of the new lattice on the way and reads 2D
+        // deep for that; only the very last launch gets by with D.  With `left >= 2D ? 2D : D` here, run(29) + run(4) on the
+        // six-step cycle started the second run's first half from 3-deep ghosts: rows 0 and H-1 wrong one step later --
+        // found by tools/ring_stress.py)
+        if (s->ghost_depth < (left == D ? D : 2 * D)) {
             if ((rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
             s->ghost_depth = 2 * D;
         }
@@ -1687,6 +1701,19 @@ int lb_run(lb_sim *s, int n_steps)
 // all on one device, advanced in lock step with device-to-device halo copies.  Same kernels, same
 // schedule and same halo tables as the RCCL path; exists so that the slab code can be verified
 // bitwise against the undivided run on a single GPU.
+// LB_DEBUG_SYNC (bits): full device synchronisation at chosen points of lb_run_group -- a tool to find a missing
+// dependency between its streams (tools/slab_stress.py): 1 after every launch phase, 2 after every exchange, 4 after every
+// join, 8 at entry and exit.
+static int debug_sync_bits()
+{
+    static const int bits = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) : 0;
+    return bits;
+}
+#define DBG_SYNC(bit)                                                   \
+    do {                                                                \
+        if (debug_sync_bits() & (bit)) HIP_TRY(hipDeviceSynchronize()); \
+    } while (0)
+
 int lb_run_group(lb_sim **sims, int count, int n_steps)
 {
     if (!sims || count < 1 || n_steps < 0) return fail(LB_ERR_ARG, "bad argument");
@@ -1699,28 +1726,40 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
     }
     if (n_steps == 0) return LB_OK;
     DeviceGuard guard(sims[0]->p.device);
+    DBG_SYNC(8);
     const bool wrap = (sims[0]->p.bc_mode == LB_BC_PERIODIC);
     int rc;
-    // halo of lattice `rel` (0 = current, 1 = the one being written) of every member, receiver-driven:
-    // after the sender's edge rows are complete, copy them into my ghost rows on my comm stream
+    // halo (3 rows deep) of lattice `rel` (0 = current, 1 = the one being written) of every member: each packs its edge
+    // rows into its send buffers on its communication stream once they are complete, the receivers scatter them from
+    // there into their ghost rows (the kernels of the RCCL path, with the transport replaced by a plain read of the
+    // neighbour's buffer)
+    for (int i = 0; i < count; ++i)
+        if (!sims[i]->halo_buf) {
+            HIP_TRY(hipMalloc(&sims[i]->halo_buf, sizeof(float) * 4 * HALO_SEGS_DEEP * sims[i]->p.nx));
+            sims[i]->bytes += sizeof(float) * 4 * HALO_SEGS_DEEP * sims[i]->p.nx;
+        }
+    auto south_nb = [&](int i) { return i > 0 ? i - 1 : (wrap ? count - 1 : -1); };
+    auto north_nb = [&](int i) { return i < count - 1 ? i + 1 : (wrap ? 0 : -1); };
     auto exchange = [&](int rel, bool wait_edges) -> int {
+        const size_t n3 = (size_t)HALO3.n * sims[0]->p.nx;
         for (int i = 0; i < count; ++i) {
             lb_sim *me = sims[i];
-            const int south = i > 0 ? i - 1 : (wrap ? count - 1 : -1);
-            const int north = i < count - 1 ? i + 1 : (wrap ? 0 : -1);
-            for (int side = 0; side < 2; ++side) {
-                const int nb = side ? north : south;
-                if (nb < 0) continue;
-                lb_sim *from = sims[nb];
-                HIP_TRY(hipStreamWaitEvent(me->comm_stream, wait_edges ? from->ev_boundary : from->ev_interior, 0));
-                if (wait_edges) HIP_TRY(hipStreamWaitEvent(me->comm_stream, me->ev_boundary, 0));
-                const HaloSeg *out = side ? SOUTH_OUT : NORTH_OUT;   // my north ghosts <- its south edge
-                const HaloSeg *in = side ? NORTH_IN : SOUTH_IN;
-                for (int k = 0; k < HALO_SEGS; ++k)
-                    HIP_TRY(hipMemcpyAsync(halo_ptr(me, me->cur ^ rel, in[k], side != 0),
-                                           halo_ptr(from, from->cur ^ rel, out[k], side == 0),
-                                           sizeof(float) * me->p.nx, hipMemcpyDeviceToDevice, me->comm_stream));
-            }
+            // my edge rows are complete; my send buffers are free (both neighbours have read the previous halo out of them)
+            HIP_TRY(hipStreamWaitEvent(me->comm_stream, wait_edges ? me->ev_boundary : me->ev_interior, 0));
+            for (int nb : {south_nb(i), north_nb(i)})
+                if (nb >= 0) HIP_TRY(hipStreamWaitEvent(me->comm_stream, sims[nb]->ev_halo, 0));
+            if ((rc = halo_pack(me, me->cur ^ rel, me->comm_stream, HALO3, north_nb(i) >= 0, south_nb(i) >= 0))) return rc;
+            HIP_TRY(hipEventRecord(me->ev_packed, me->comm_stream));
+        }
+        for (int i = 0; i < count; ++i) {
+            lb_sim *me = sims[i];
+            const int so = south_nb(i), no = north_nb(i);
+            for (int nb : {so, no})
+                if (nb >= 0) HIP_TRY(hipStreamWaitEvent(me->comm_stream, sims[nb]->ev_packed, 0));
+            // my south ghost rows <- what the southern neighbour sent north, and vice versa
+            if ((rc = halo_unpack(me, me->cur ^ rel, me->comm_stream, HALO3, so >= 0 ? sims[so]->halo_buf : nullptr,
+                                  no >= 0 ? sims[no]->halo_buf + n3 : nullptr)))
+                return rc;
             HIP_TRY(hipEventRecord(me->ev_halo, me->comm_stream));
         }
         return LB_OK;
@@ -1774,16 +1813,20 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
             return LB_OK;
         };
         if ((rc = exchange_deep())) return rc;
+        DBG_SYNC(2);
         for (; left >= 2 * D; left -= 2 * D) {
             for (int i = 0; i < count; ++i) {
                 if ((rc = slab_cycle_first(sims[i], D))) return rc;
                 sims[i]->cur ^= 1;
             }
+            DBG_SYNC(1);
             for (int i = 0; i < count; ++i) {
                 if ((rc = slab_cycle_second(sims[i], left == 2 * D, D))) return rc;
                 sims[i]->cur ^= 1;
             }
+            DBG_SYNC(1);
             if ((rc = exchange_deep())) return rc;
+            DBG_SYNC(2);
             for (int i = 0; i < count; ++i) HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_boundary, 0));
         }
         int depth_after = 2 * D;
@@ -1810,6 +1853,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         }
     }
     if ((rc = exchange(0, false))) return rc;
+    DBG_SYNC(2);
     for (int i = 0; i < count; ++i) {
         HIP_TRY(hipStreamWaitEvent(sims[i]->stream, sims[i]->ev_halo, 0));
         HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_halo, 0));
@@ -1818,7 +1862,9 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         const int adv = next_advance(depth_mask(two, three), left);
         for (int i = 0; i < count; ++i)
             if ((rc = slab_step_launch(sims[i], adv, left == adv))) return rc;
+        DBG_SYNC(1);
         if ((rc = exchange(1, true))) return rc;
+        DBG_SYNC(2);
         for (int i = 0; i < count; ++i) {
             if ((rc = slab_step_join(sims[i]))) return rc;
             // a neighbour's next launch overwrites the lattice my comm stream may still be reading
@@ -1833,11 +1879,13 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         }
         for (int i = 0; i < count; ++i) sims[i]->cur ^= 1;
         left -= adv;
+        DBG_SYNC(4);
     }
     for (int i = 0; i < count; ++i) {
         sims[i]->ghost_depth = 3;
         sims[i]->feq_valid = false;
     }
+    DBG_SYNC(8);
     return LB_OK;
 }
 

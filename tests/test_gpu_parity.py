@@ -321,7 +321,7 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
     one = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask)
     one.set_variant(0)
     one.set_f(f0)
-    one.run(61)
+    one.run(61 + 29 + 4 + 5 + 16 + 7)
     for variant in (97 | 256, 97, 97 | 128):      # eight-step cycle, six-step cycle, no cycle
         two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
         two.set_variant(variant)
@@ -333,6 +333,11 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
         two.run(12)                               # 2 cycles on valid 6-deep ghosts
         two.run(4)
         two.run(20)                               # the bench block: two eight-step cycles + one lone four-step half (or 3 x 6 + 2)
+        two.run(29)                               # ... + a lone first half that is not the last launch + launch by launch
+        two.run(4)                                # six-step cycle: a first half that is not the last launch, from 3-deep ghosts
+        two.run(5)                                #   (it reads 2D deep: must exchange first -- was wrong until tools/ring_stress.py)
+        two.run(16)                               # full cycles only: leaves 2D-deep ghosts
+        two.run(7)                                # eight-step cycle: first half, not last, from 8-deep ghosts
         a, b = one.get_fields(("f", "rho", "u", "v")), two.get_fields(("f", "rho", "u", "v"))
         for k in a:
             assert np.array_equal(a[k], b[k]), (variant, k)

@@ -91,3 +91,36 @@ def test_random_slab_partition(lbhip, seed):
     a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
     for k in a:
         assert np.array_equal(a[k], b[k]), (bc, nx, ny, nslabs, variant, total, k)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LB_RANDOM_RING_SEEDS", "16"))))
+def test_random_self_ring(lbhip, seed):
+    """The production slab path (lb_run with the RCCL exchange) as a one-rank periodic ring that sends its halo to itself:
+    random shapes, variants (eight- / six-step cycle, no cycle, two- and single-step launches), masks and sequences of run
+    lengths (every transition between cycles, lone first halves and launch-by-launch steps, with whatever ghost depth the
+    previous run left) against the plain whole-grid handle, bit for bit.  (tools/ring_stress.py is the same in a loop.)"""
+    from LB_D2Q9.simulation import Simulation, comm_unique_id
+    rng = np.random.default_rng(9000 + (71 if seed == 0 else seed))      # 9071: the case that found the ghost-depth bug
+    nx = int(rng.choice((512, 516, 768, 1000, 1024, 1284, 2048)))
+    ny = int(rng.integers(8, 700))
+    variant = int(rng.choice((-1, 97 | 256, 97, 97 | 128, 33, 1)))
+    mask = None
+    if rng.integers(0, 2):
+        mask = rng.random((nx, ny)) < 0.03
+    f0 = _random_state(rng, nx, ny)
+    one = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask)
+    one.set_variant(0)
+    one.set_f(f0)
+    ring = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask, halo=True)
+    ring.comm_init(comm_unique_id(), 0, 1)
+    ring.set_variant(variant)
+    ring.set_f(f0)
+    runs = [int(n) for n in rng.integers(1, 40, size=3)]
+    for n in runs:
+        ring.run(n)
+    one.run(sum(runs))
+    a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (nx, ny, variant, runs, k)
+    one.close()
+    ring.close()
