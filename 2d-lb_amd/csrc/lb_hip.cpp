@@ -566,6 +566,18 @@ int need_single_slab(const lb_sim *s, const char *what)
     return LB_OK;
 }
 
+// A whole lattice copied on the device by a kernel on the handle's stream (k_copy4: it runs at the streaming ceiling, and it
+// is ordered like every other kernel of that stream; hipMemcpyAsync device-to-device goes through the runtime's copy path,
+// whose completion the stream did not always wait for when several processes shared the GPU: tools/slab_stress.py).
+int copy_lattice(lb_sim *s, float *dst, const float *src)
+{
+    const long long n4 = s->lat_floats / 4;              // (lat_floats is a multiple of 64)
+    hipLaunchKernelGGL(k_copy4<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s->stream,
+                       reinterpret_cast<const f4a *>(src), reinterpret_cast<f4a *>(dst), n4);
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
 // host [rows][nx] <-> device [rows][pitch]
 int copy_plane_h2d(lb_sim *s, float *dev, const float *host)
 {
@@ -1290,10 +1302,9 @@ int lb_set_f(lb_sim *s, const float *f)
         if (rc) return rc;
     }
     // f_streamed = f (opencl_dim.py:323-327)
-    HIP_TRY(hipMemcpyAsync(s->lat[s->cur ^ 1], s->lat[s->cur], sizeof(float) * s->lat_floats,
-                           hipMemcpyDeviceToDevice, s->stream));
-    int rc = corners_capture(s, s->cur);
+    int rc = copy_lattice(s, s->lat[s->cur ^ 1], s->lat[s->cur]);
     if (rc) return rc;
+    if ((rc = corners_capture(s, s->cur))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->ghost_depth = 0;
     return LB_OK;
@@ -1433,8 +1444,10 @@ int lb_move(lb_sim *s)
     HIP_TRY(hipGetLastError());
     // copy_buffer: f = f_streamed (kept as a copy, not a pointer swap, so that the stale
     // never-written entries of f_streamed behave exactly like the reference's)
-    HIP_TRY(hipMemcpyAsync(s->lat[s->cur], s->lat[s->cur ^ 1], sizeof(float) * s->lat_floats,
-                           hipMemcpyDeviceToDevice, s->stream));
+    {
+        int rc = copy_lattice(s, s->lat[s->cur], s->lat[s->cur ^ 1]);
+        if (rc) return rc;
+    }
     // VELOCITY_INLET: the eight corner links no phase ever writes are kept apart (fused launches swap the lattices,
     // so "whatever f_streamed held" would not survive them): put them where the boundary phase reads them
     if (s->p.bc_mode == LB_BC_VELOCITY_INLET) return corners_patch(s, s->cur);
@@ -1527,8 +1540,7 @@ int lb_init_pop(lb_sim *s)
     int rc;
     if (!s->feq_valid && (rc = lb_update_feq(s))) return rc;
     for (int i = 0; i < 2; ++i)
-        HIP_TRY(hipMemcpyAsync(s->lat[i], s->feq, sizeof(float) * s->lat_floats, hipMemcpyDeviceToDevice,
-                               s->stream));
+        if ((rc = copy_lattice(s, s->lat[i], s->feq))) return rc;
     s->ghost_depth = 0;
     return corners_capture(s, s->cur);
 }
@@ -1701,12 +1713,16 @@ int lb_run(lb_sim *s, int n_steps)
 // all on one device, advanced in lock step with device-to-device halo copies.  Same kernels, same
 // schedule and same halo tables as the RCCL path; exists so that the slab code can be verified
 // bitwise against the undivided run on a single GPU.
-// LB_DEBUG_SYNC (bits): full device synchronisation at chosen points of lb_run_group -- a tool to find a missing
-// dependency between its streams (tools/slab_stress.py): 1 after every launch phase, 2 after every exchange, 4 after every
-// join, 8 at entry and exit.
+// Full device synchronisation at chosen points of lb_run_group (bits: 1 after every launch phase, 2 after every exchange,
+// 4 after every step, 8 at entry and exit).  Default 2: with the GPU shared by several processes, rare partitions (a few
+// in a thousand) differed from the undivided run when the members' streams were ordered by events alone -- never in a
+// process that had the GPU to itself, never with one hardware queue per process (GPU_MAX_HW_QUEUES=1), never in lb_run's
+// own schedule (tools/slab_stress.py, tools/ring_stress.py, profiles/r02_experiments.txt); the cross-member waits of this
+// harness, or the runtime's handling of them under oversubscription, are not understood yet.  A verification harness must
+// not raise false alarms, so it joins the device after every exchange; LB_DEBUG_SYNC=0 gives the event-only schedule.
 static int debug_sync_bits()
 {
-    static const int bits = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) : 0;
+    static const int bits = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) : 2;
     return bits;
 }
 #define DBG_SYNC(bit)                                                   \
