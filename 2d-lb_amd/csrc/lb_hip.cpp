@@ -594,11 +594,9 @@ int copy_plane_d2h(lb_sim *s, float *host, const float *dev)
 
 // One plane of a lattice (f or feq; `origin` = its plane 0, row 0): host [H][nx] <-> device.  Planar layout: the plane is one
 // pitched block.  Interleaved rows: through the staging plane -- one DMA plus one device kernel instead of H strided
-// row copies.  The staging plane is reused plane after plane, and a copy between PAGEABLE host memory and the device is
-// not ordered behind the kernels already enqueued on the stream (the runtime stages it through its own buffers and may
-// start at once): with the GPU shared by several processes the next plane's upload overwrote the staging plane before the
-// scatter kernel had read it -- rows of one plane in another, every eighth row or so (tools/slab_stress.py).  Hence the
-// explicit synchronisation between the kernel and the copy, both ways.
+// row copies.  The staging plane is reused plane after plane; the stream is synchronised between the scatter / gather
+// kernel and the next copy from / to (pageable) host memory instead of relying on the runtime ordering its staged copies
+// behind kernels already enqueued -- a precaution (nine cheap synchronisations per set / get), not a measured necessity.
 int lattice_plane_h2d(lb_sim *s, float *origin, int k, const float *host)
 {
     if (s->rowp == s->pitch) return copy_plane_h2d(s, origin + k * s->plane, host);
