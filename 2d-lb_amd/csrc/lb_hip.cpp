@@ -1172,7 +1172,8 @@ int lb_create(const lb_params *p, lb_sim **out)
     {
         int lo = 0, hi = 0;   // edge bands and halo first: highest priority the device offers
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, hi));
+        static const bool flat = getenv("LB_EDGE_PRIO") && atoi(getenv("LB_EDGE_PRIO")) == 0;   // diagnostic: no priority
+        CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, flat ? lo : hi));
     }
     const unsigned ev_flags = hipEventDisableTiming;
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, ev_flags));
