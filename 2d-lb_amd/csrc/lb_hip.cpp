@@ -1715,9 +1715,10 @@ int lb_run(lb_sim *s, int n_steps)
 // Full device synchronisation at chosen points of lb_run_group (bits: 1 after every launch phase, 2 after every exchange,
 // 4 after every step, 8 at entry and exit).  Default 2: with the GPU shared by several processes, rare partitions (a few
 // in a thousand) differed from the undivided run when the members' streams were ordered by events alone -- never in a
-// process that had the GPU to itself, never with one hardware queue per process (GPU_MAX_HW_QUEUES=1), never in lb_run's
-// own schedule (tools/slab_stress.py, tools/ring_stress.py, profiles/r02_experiments.txt); the cross-member waits of this
-// harness, or the runtime's handling of them under oversubscription, are not understood yet.  A verification harness must
+// process that had the GPU to itself, never with one hardware queue per process (GPU_MAX_HW_QUEUES=1), never with the edge
+// stream at normal priority (LB_EDGE_PRIO=0), never in lb_run's own schedule (tools/slab_stress.py, tools/ring_stress.py,
+// profiles/r02_experiments.txt): it looks like barriers between a high-priority and a normal hardware queue going wrong
+// while queues are time-sliced, but a missing wait here has not been ruled out.  A verification harness must
 // not raise false alarms, so it joins the device after every exchange; LB_DEBUG_SYNC=0 gives the event-only schedule.
 static int debug_sync_bits()
 {
