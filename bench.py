@@ -270,6 +270,21 @@ def main():
         total += wall
     wall, ev_ms = statistics.median(walls), statistics.median(evs)
 
+    # ---- duration of ONE launch of the dominant kernel, for the roofline (outside the timed region) -----------
+    # A run() ends with the launch that also stores rho, u, v (12 B per cell more, ~11 % longer at 8192^2), so the K-step
+    # block above averages two kinds of launches.  The plain launch's duration is the difference between runs of 2q and
+    # of q launches, divided by q (HIP events on the engine's stream, median of 5 each) -- the figure rocprofv3 reports
+    # as the kernel's average (profiles/r02_rocprof_summary.md).
+    plain_ms = macro_extra_ms = None
+    if dist is None:
+        spl_probe = eng.steps_per_launch()
+        q = max(1, args.steps // spl_probe)
+        t1 = statistics.median(sim.timed_run(spl_probe * q) for _ in range(5))
+        t2 = statistics.median(sim.timed_run(2 * spl_probe * q) for _ in range(5))
+        a = (t2 - t1) / q
+        if 0.5 * t1 / q < a <= 1.02 * t1 / q:          # (else: keep the block average below)
+            plain_ms, macro_extra_ms = a, max(t1 - q * a, 0.0)
+
     # sanity: the run must have produced finite numbers (guards against timing a broken kernel)
     chk = eng.get_fields(("rho",))["rho"]
     if not np.all(np.isfinite(chk)) or abs(float(chk.mean()) - 1.0) > 1e-3:
@@ -287,6 +302,11 @@ def main():
         # K timed steps = (K // spl) launches of the spl-step kernel (+ at most one shorter launch for the
         # remainder, priced at the same per-step rate)
         launch_s = ev_ms / 1e3 / args.steps * spl
+        launch_source = "K-step block average (includes the launch that also stores rho, u, v)"
+        if plain_ms is not None and not python_driven:
+            launch_s = plain_ms / 1e3
+            launch_source = ("difference of runs of 2q and q launches / q (plain launches of the dominant kernel; the last "
+                             "launch of a run also stores rho, u, v: +%.4f ms)" % macro_extra_ms)
         bytes_per_launch = B_ALG * n * h
         achieved = bytes_per_launch / launch_s / 1e9
         effective = bytes_per_launch * spl / launch_s / 1e9
@@ -297,7 +317,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
-                "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
+                "launch_ms": round(launch_s * 1e3, 4), "launch_ms_source": launch_source, "steps_per_launch": spl,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "effective_GBps": round(effective, 1), "effective_x_roofline": round(effective / HBM_PEAK_GBS, 4),
                 "note": "achieved = 72 B x cells of one launch (compulsory: each plane read once, written once) / "
