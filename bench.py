@@ -18,8 +18,10 @@ fresh box no longer decides the line.
 Extra objects in the line:
   roofline     - the dominant kernel against the HBM roofline.  `achieved` = the bytes one launch MUST move --
                  72 B x the cells of its slab (nine fp32 planes read once, nine written once), whatever
-                 number of time steps the launch fuses -- / its average duration (HIP events on the engine's
-                 stream over the timed blocks); `frac` = achieved / 8 TB/s, <= 1 by construction.
+                 number of time steps the launch fuses -- / the duration of one launch of that kernel (HIP events
+                 on the engine's stream: runs of 2q and of q launches, difference / q, right after the timed region;
+                 the last launch of a run() also stores rho, u, v and is ~11 % longer, so the K-step block average
+                 would mix two kinds of launches; N > 1: the block average); `frac` = achieved / 8 TB/s, <= 1.
                  `effective_GBps` = 72 B x lattice UPDATES / time (what an un-blocked kernel would have to move
                  for the same MLUPS; exceeds the peak when several steps share one pass) is reported beside it,
                  never as `frac`.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of
