@@ -157,10 +157,13 @@ def spawn_ranks(n, argv):
     if failed is not None:
         sys.stderr.write(out)
         raise SystemExit("bench: rank %d exited with status %s" % (failed, procs[failed].returncode))
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    if not any(l.startswith("{") for l in out.splitlines()):
+    # exactly ONE line on stdout: the result; whatever else rank 0 wrote there (a runtime's banner) goes to stderr
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    sys.stderr.write("".join(l + "\n" for l in out.splitlines() if not l.startswith("{")))
+    if not lines:
         raise SystemExit("bench: rank 0 printed no result line")
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -188,6 +191,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])
         return
+
+    # stdout carries ONE line, the result.  RCCL prints a version banner to the C-level stdout of every process that
+    # creates a communicator (it surfaces at exit, behind the result): file descriptor 1 is pointed at stderr for
+    # everything else, the line itself goes to a duplicate of the original stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -348,7 +358,7 @@ def main():
             roof["frac_of_copy_on_this_device"] = round(achieved / max(copy_gbs.values()), 4)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=result_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
