@@ -25,10 +25,17 @@ def main():
         if rng.integers(0, 2):
             mask = rng.random((nx, ny)) < 0.03
         f0 = _random_state(rng, nx, ny)
-        one = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask)
+        # every third case a walled family: a whole grid flagged as a slab with a 1-rank communicator has no neighbour (the
+        # exchange degenerates to an empty group) but runs lb_run's slab schedule all the same
+        bc = ("periodic", "periodic", ("pipe", "cavity")[(seed // 3) % 2])[seed % 3]
+        kw = dict(inlet_rho=1.004, lid_u=0.05)
+        if mask is not None and bc != "periodic":
+            mask[0, :] = mask[-1, :] = False
+            mask[:, 0] = mask[:, -1] = False
+        one = Simulation(nx, ny, 1.5, bc=bc, obstacle_mask=mask, **kw)
         one.set_variant(0)
         one.set_f(f0)
-        ring = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask, halo=True)
+        ring = Simulation(nx, ny, 1.5, bc=bc, obstacle_mask=mask, halo=True, **kw)
         ring.comm_init(comm_unique_id(), 0, 1)
         ring.set_variant(variant)
         ring.set_f(f0)
@@ -44,8 +51,8 @@ def main():
                 if d.ndim == 3:
                     d = d.any(axis=2)
                 rows = np.nonzero(d.any(axis=0))[0]
-                print("seed %d %dx%d variant %d runs %s mask %d: %s differs in %d cells, rows %d..%d" % (
-                    seed, nx, ny, variant, runs, mask is not None, k, int(d.sum()), rows.min(), rows.max()), flush=True)
+                print("seed %d %s %dx%d variant %d runs %s mask %d: %s differs in %d cells, rows %d..%d" % (
+                    seed, bc, nx, ny, variant, runs, mask is not None, k, int(d.sum()), rows.min(), rows.max()), flush=True)
         one.close()
         ring.close()
     print("%d seeds, %d mismatching fields" % (seeds, bad))
