@@ -123,7 +123,7 @@ class LocalSlabRing(_SlabSet):
 
     def run_in_library(self, n):
         """The same slabs advanced by lb_run_group: the multi-GPU schedule (edge bands first, two-step
-        kernel where applicable, halo copies on a side stream) with device-to-device copies."""
+        kernel where applicable, halo packed / unpacked on a side stream) with the neighbour's buffer read directly."""
         from .simulation import run_group
         run_group(self.slabs, n)
         self._ghosts_valid = False      # lb_run_group refreshes the ghosts itself

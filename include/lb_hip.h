@@ -181,8 +181,9 @@ int lb_halo_import(lb_sim *s, int side, const void *buf);
  * first), each [LB_MASK_HALO_ROWS][nx] int32, NULL = no solid cells.  The multi-step kernels recompute
  * the neighbours' edge rows and need their masks. */
 int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_rows);
-/* Advance `count` slab handles that tile one grid on ONE device in lock step, moving halos with
- * device-to-device copies: the multi-GPU schedule and kernels without a second GPU (verification). */
+/* Advance `count` slab handles that tile one grid on ONE device in lock step: the multi-GPU schedule and kernels
+ * without a second GPU (verification).  Halos move through the pack / unpack kernels of the RCCL path, the receiver
+ * reading the sender's buffer; the device is joined after every exchange (environment LB_DEBUG_SYNC=0: events only). */
 int lb_run_group(lb_sim **sims, int count, int n_steps);
 
 /* Population sets (the periodic multi-population lattices of the reference's research forks: porous_media/
