@@ -132,6 +132,7 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one node: bootstrap over the loopback interface
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
     # a rank that dies leaves its peers blocked in a collective: poll, and take the others down with it
@@ -215,6 +216,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one node: bootstrap over the loopback interface
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from LB_D2Q9.simulation import Simulation

@@ -11,9 +11,23 @@ for p in (os.path.join(ROOT, "2d-lb_amd"), ROOT):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Single-node runs: RCCL's bootstrap sockets on the loopback interface (the container's other interfaces / hostname are
+# not always usable: "use 127.0.0.1 for any rendezvous").
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a wedged device, a bootstrap that never returns) must fail, not stall the run: every
+    one of them finishes in seconds, the largest in under a minute."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
 
 
 def golden(name):
