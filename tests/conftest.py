@@ -27,7 +27,7 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(900))
+            item.add_marker(pytest.mark.timeout(900, method="thread"))      # (a hang inside a C call: the signal method never fires)
 
 
 def golden(name):
