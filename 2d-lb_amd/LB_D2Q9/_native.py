@@ -11,12 +11,13 @@ LIB_PATH = os.environ.get("LB_LIB") or os.path.join(_HERE, "liblbhip.so")   # LB
 LB_BC_PIPE, LB_BC_PERIODIC, LB_BC_CAVITY, LB_BC_VELOCITY_INLET = 0, 1, 2, 3
 LB_FLAG_HALO = 1
 LB_FLAG_PLANAR = 2
+LB_FLAG_EAGER_MACRO = 4
 LB_MASK_HALO_ROWS = 7
 LB_SEM_OPENCL, LB_SEM_CYTHON, LB_SEM_OPENCL_D2Q9I = 0, 1, 2
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
             "velocity_inlet": LB_BC_VELOCITY_INLET}
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/lb_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -27,7 +28,7 @@ EXPORTS = (
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group", "lb_run_batch",
     "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
-    "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state",
+    "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state", "lb_check", "lb_set_debug_sync",
 )
 
 
@@ -88,6 +89,8 @@ def lib():
     L.lb_get_corner_state.argtypes = [h, vp]
     L.lb_set_corner_state.argtypes = [h, vp]
     L.lb_hot_kernel.argtypes = [h, ct.c_char_p, I]
+    L.lb_check.argtypes = [h, I, ct.POINTER(ct.c_int64), fp, ct.POINTER(ct.c_double)]
+    L.lb_set_debug_sync.argtypes = [I]
     if L.lb_abi_version() != ABI_VERSION:
         raise LbError("liblbhip.so ABI %d != binding ABI %d: rebuild" % (L.lb_abi_version(), ABI_VERSION))
     _lib = L

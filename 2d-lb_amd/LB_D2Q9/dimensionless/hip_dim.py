@@ -196,6 +196,10 @@ class Pipe_Flow(object):
     def step(self):
         self._sim.run(1)
 
+    def check(self, **kw):
+        """Device-side health check (Simulation.check): non-finite cells, max Mach number, total mass."""
+        return self._sim.check(**kw)
+
     # ---- state I/O (new: the reference has no checkpointing) ----------------------------------------
     def save_checkpoint(self, path):
         self._sim.save_checkpoint(path)

@@ -10,7 +10,8 @@ and its cylinder class zeroes u, v inside the obstacle after every ``update_hydr
 Here: the same classes on the engine's ``semantics='d2q9i'`` kernels (fused ``run``, one kernel per phase method).
 The fork is reproduced as it is, including its instability (executed faithfully, |u| grows about tenfold in ten steps
 from a 2e-4 density drop and overflows within a hundred: tests/golden/o2_d2q9i_53x27, tests/test_gpu_d2q9i.py) -- no
-notebook of the reference uses it.
+notebook of the reference uses it.  ``run`` ends with the device-side health check and raises ``FloatingPointError`` once
+the lattice holds non-finite cells.
 """
 import numpy as np
 
@@ -47,6 +48,12 @@ class Pipe_Flow(hip_dim.Pipe_Flow):
         rin, rout = self._boundary_densities()
         return Simulation(self.nx, self.ny, self.omega, bc='pipe', inlet_rho=rin, outlet_rho=rout, device=self.device,
                           semantics='d2q9i')
+
+    def run(self, num_iterations):
+        """As the base class; then one device pass over the populations (Simulation.check): the fork is unstable, and a
+        run that has produced non-finite cells raises FloatingPointError here instead of returning NaN fields later."""
+        super(Pipe_Flow, self).run(num_iterations)
+        self._sim.check(raise_nonfinite=True)
 
 
 class Pipe_Flow_Cylinder(Pipe_Flow, hip_dim.Pipe_Flow_Cylinder):

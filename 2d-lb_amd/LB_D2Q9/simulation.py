@@ -53,7 +53,7 @@ def comm_unique_id():
 class Simulation(object):
     def __init__(self, nx, ny, omega, bc="pipe", inlet_rho=1., outlet_rho=1., lid_u=0., rho0=1.,
                  obstacle_mask=None, device=0, y0=0, local_ny=None, halo=False, semantics="opencl",
-                 inlet_u=0., outlet_u=None, planar=None):
+                 inlet_u=0., outlet_u=None, planar=None, eager_macro=False):
         """
         :param nx, ny: global grid size (cells, boundary nodes included).
         :param omega: BGK relaxation rate, 0 < omega < 2.
@@ -70,6 +70,9 @@ class Simulation(object):
         :param planar: device layout of the lattices: False = the nine planes of a row stored together (default),
                True = each plane contiguous (LB_FLAG_PLANAR); results are identical.  None: environment variable
                LB_LAYOUT=planar selects True (tuning aid).
+        :param eager_macro: the last launch of every run() stores rho, u, v itself (LB_FLAG_EAGER_MACRO).  Default: the
+               plain families leave them to be rebuilt from the populations -- whose moments they are, BGK relaxation
+               conserving both -- the first time get_fields / update_feq / ... needs them (include/lb_hip.h).
         """
         if isinstance(bc, str):
             if bc not in _native.BC_NAMES:
@@ -90,7 +93,9 @@ class Simulation(object):
         if planar is None:
             planar = os.environ.get("LB_LAYOUT", "") == "planar"
         self.planar = bool(planar)
-        p.flags = (_native.LB_FLAG_HALO if halo else 0) | (_native.LB_FLAG_PLANAR if self.planar else 0)
+        self.eager_macro = bool(eager_macro)
+        p.flags = ((_native.LB_FLAG_HALO if halo else 0) | (_native.LB_FLAG_PLANAR if self.planar else 0) |
+                   (_native.LB_FLAG_EAGER_MACRO if self.eager_macro else 0))
         sem = {"opencl": _native.LB_SEM_OPENCL, "cython": _native.LB_SEM_CYTHON, "d2q9i": _native.LB_SEM_OPENCL_D2Q9I}
         if semantics not in sem:
             raise ValueError("semantics must be one of %s" % sorted(sem))
@@ -107,6 +112,7 @@ class Simulation(object):
         self._shape2 = (self.nx, self.local_ny)
         self._shape3 = (self.nx, self.local_ny, NUM_JUMPERS)
         self._mask_host = None
+        self._mask_halo_host = None      # (south_rows, north_rows) as last given to set_obstacle_mask_halo
         if obstacle_mask is not None:
             self.set_obstacle_mask(obstacle_mask)
 
@@ -194,12 +200,15 @@ class Simulation(object):
     # -- the hot path --------------------------------------------------------
     def run(self, num_iterations, wait=True):
         """num_iterations fused time steps.  The reference returns with the work complete (it waits after
-        every kernel); pass wait=False to only enqueue (never blocks the host).  A blocking run long enough to
-        pay for it first times the candidate kernel configurations on its own first steps (lb_autotune_quick:
-        they are bitwise equivalent, the trajectory is unchanged) and keeps the fastest for this grid."""
+        every kernel); pass wait=False to only enqueue (never blocks the host).  A blocking run of at least four
+        times the tuning pass (4 x 241 + 7 = 971 steps; 4 x 721 + 7 on grids <= 768^2) first times the candidate kernel
+        configurations on its own first steps (lb_autotune_quick: they are bitwise equivalent, the trajectory is
+        unchanged) and keeps the fastest for this grid; shorter runs use the size heuristic (or call autotune())."""
         n = int(num_iterations)
         if wait and n > 0:
-            used = self._lib.lb_autotune_quick(self._h, n - 7)
+            # (the pass costs 241 steps, 721 on grids <= 768^2, some of them in configurations several times slower than
+            #  the best: it only pays for itself in a run several times that long)
+            used = self._lib.lb_autotune_quick(self._h, (n - 7) // 4)
             if used < 0:
                 check(used)
             n -= used
@@ -209,6 +218,26 @@ class Simulation(object):
 
     def step(self):
         self.run(1)
+
+    # -- health -----------------------------------------------------------------
+    MACH_TOLERANCE = 0.1        # the forks' default `mach_tolerance` (porous_media/single_component.py:254)
+
+    def check(self, across_ranks=False, warn=False, raise_nonfinite=False):
+        """One device pass over the populations (lb_check): {'n_nonfinite': cells whose density or velocity is not
+        finite, 'max_mach': max |u| / c_s, 'sum_rho': total mass of the finite cells}.  The reference's forks have the
+        two halves of this as `check_max_ulb` (a warning when max |u| > c_s * mach_tolerance,
+        porous_media/single_component.py:221-225) and `check_fields()` (:753-766); `warn=True` issues that warning,
+        `raise_nonfinite=True` raises FloatingPointError when the run has diverged.  across_ranks: combined over the
+        ranks of the communicator (collective)."""
+        n, m, r = ct.c_int64(), ct.c_float(), ct.c_double()
+        check(self._lib.lb_check(self._h, int(bool(across_ranks)), ct.byref(n), ct.byref(m), ct.byref(r)))
+        out = {"n_nonfinite": n.value, "max_mach": m.value, "sum_rho": r.value}
+        if raise_nonfinite and n.value:
+            raise FloatingPointError("lattice has %d non-finite cell(s): the run has diverged" % n.value)
+        if warn and m.value > self.MACH_TOLERANCE:
+            import warnings
+            warnings.warn("max_ulb is greater than cs/10! Ma= %g" % m.value, RuntimeWarning, stacklevel=2)
+        return out
 
     def timer_start(self):
         """Record the start HIP event on the engine's stream."""
@@ -267,6 +296,10 @@ class Simulation(object):
             d[k] = getattr(self, k)
         if self.bc_mode == _native.LB_BC_VELOCITY_INLET:
             d["corner_state"] = self.get_corner_state()
+        if self._mask_halo_host is not None:         # a slab: the neighbours' obstacle rows it was given
+            empty = np.zeros((0, 0), np.int32)
+            d["mask_halo_south"] = empty if self._mask_halo_host[0] is None else self._mask_halo_host[0]
+            d["mask_halo_north"] = empty if self._mask_halo_host[1] is None else self._mask_halo_host[1]
         return d
 
     def save_checkpoint(self, path):
@@ -297,6 +330,9 @@ class Simulation(object):
     def restore_arrays(self, d):
         self._check_compatible(d)
         self.set_obstacle_mask(d["mask"] if d["mask"].size else None)
+        if "mask_halo_south" in d:
+            so, no = d["mask_halo_south"], d["mask_halo_north"]
+            self.set_obstacle_mask_halo(so if so.size else None, no if no.size else None)
         self.set_fields(d["rho"], d["u"], d["v"])
         self.set_f(d["f"])
         if self.bc_mode == _native.LB_BC_VELOCITY_INLET:
@@ -357,6 +393,7 @@ class Simulation(object):
             rows.append(None if r is None else np.ascontiguousarray((np.asarray(r) != 0).astype(np.int32)))
         ptr = lambda a: None if a is None else a.ctypes.data
         check(self._lib.lb_set_mask_halo(self._h, ptr(rows[0]), ptr(rows[1])))
+        self._mask_halo_host = tuple(rows)
 
     def halo_export(self, side, buf):
         """Copy the halo leaving through edge `side` (0 south, 1 north) into buf[18*nx]

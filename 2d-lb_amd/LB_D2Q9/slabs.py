@@ -50,6 +50,11 @@ def _is_periodic(bc):
     return bc in ("periodic", _native.LB_BC_PERIODIC) and not isinstance(bc, bool)
 
 
+def _bc_code(bc):
+    """Boundary family as its lb_bc_mode number, whether it was given by name or by number."""
+    return _native.BC_NAMES[bc] if isinstance(bc, str) else int(bc)
+
+
 def _default_engine(**kw):
     from .simulation import Simulation
     return Simulation(**kw)
@@ -318,6 +323,28 @@ class DistributedSlab(_SlabSet):
     def get_local_fields(self, which=("f", "feq", "u", "v", "rho")):
         return self.engine.get_fields(which)
 
+    def check(self, warn=False, raise_nonfinite=False):
+        """Collective.  Health of the whole lattice (Simulation.check over every rank's rows): non-finite cells and
+        mass summed, Mach number maximised over the ranks -- inside the engine with ncclAllReduce when RCCL carries
+        the halos, otherwise with torch.distributed on the three scalars."""
+        if self.transport == "rccl":
+            return self.engine.check(across_ranks=True, warn=warn, raise_nonfinite=raise_nonfinite)
+        import torch
+        c = self.engine.check()
+        on_gpu = self._dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", self.engine.device) if on_gpu else torch.device("cpu")
+        t = torch.tensor([c["sum_rho"], float(c["n_nonfinite"])], dtype=torch.float64, device=dev)
+        m = torch.tensor([c["max_mach"]], dtype=torch.float32, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        self._dist.all_reduce(m, op=self._dist.ReduceOp.MAX, group=self.group)
+        out = {"n_nonfinite": int(t[1]), "max_mach": float(m[0]), "sum_rho": float(t[0])}
+        if raise_nonfinite and out["n_nonfinite"]:
+            raise FloatingPointError("lattice has %d non-finite cell(s): the run has diverged" % out["n_nonfinite"])
+        if warn and out["max_mach"] > 0.1:
+            import warnings
+            warnings.warn("max_ulb is greater than cs/10! Ma= %g" % out["max_mach"], RuntimeWarning, stacklevel=2)
+        return out
+
     # -- state I/O across ranks (the reference has none; SURVEY 8f-3) --------------------------------------
     CHECKPOINT_VERSION = 1
 
@@ -336,8 +363,10 @@ class DistributedSlab(_SlabSet):
                  mask=(np.zeros((0, 0), np.uint8) if mask is None else (np.asarray(mask) != 0).astype(np.uint8)),
                  y0=self.y0, h=self.h)
         if self.rank == 0:
+            import numbers
+            scalar = lambda v: isinstance(v, (numbers.Real, np.generic)) and not isinstance(v, (bool, np.bool_))
             man = {"version": self.CHECKPOINT_VERSION, "nx": self.nx, "ny": self.ny, "bc": self.bc if isinstance(self.bc, str) else int(self.bc),
-                   "omega": float(self.omega), "params": {k: float(v) for k, v in self._engine_kw.items() if isinstance(v, (int, float))},
+                   "omega": float(self.omega), "params": {k: float(v) for k, v in self._engine_kw.items() if scalar(v)},
                    "nranks": self.nranks, "partition_rows": [list(p) for p in self.parts], "has_mask": bool(self._has_mask)}
             with open(os.path.join(path, "manifest.json"), "w") as fh:
                 json.dump(man, fh, indent=1)
@@ -360,7 +389,7 @@ class DistributedSlab(_SlabSet):
         man = self.read_manifest(path)
         if (man["nx"], man["ny"]) != (self.nx, self.ny):
             raise ValueError("checkpoint is for a %dx%d grid, this run is %dx%d" % (man["nx"], man["ny"], self.nx, self.ny))
-        if _is_periodic(man["bc"]) != self.periodic or str(man["bc"]) != str(self.bc if isinstance(self.bc, str) else int(self.bc)):
+        if _bc_code(man["bc"]) != _bc_code(self.bc):
             raise ValueError("checkpoint was written with boundary family %r, this run has %r" % (man["bc"], self.bc))
         if np.float32(man["omega"]) != np.float32(self.omega):
             raise ValueError("checkpoint has omega = %r, this run %r" % (man["omega"], self.omega))

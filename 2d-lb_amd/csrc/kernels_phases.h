@@ -357,6 +357,106 @@ __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
         a.fs[k * S + o] = fk[k] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
 }
 
+// ---- macroscopic fields on demand + device-side health check ---------------------------------------------------
+// BGK relaxation conserves rho and rho*u, so the moments of the post-collision populations a run() leaves behind
+// ARE the rho, u, v of its last step (the reference stores the pre-collision ones, opencl_dim.py:384-385: equal up to
+// rounding).  lb_run therefore does not store them in the plain families; this kernel rebuilds them the first time
+// somebody asks (lb_get_macro, lb_update_feq, ...).  The same pass reduces what the reference's forks print or warn
+// about while they run -- max |u| against the speed of sound (porous_media/single_component.py:221-225), the sums of
+// check_fields() (:753-766) -- plus a count of non-finite cells: per workgroup a partial (wave reduction through
+// cross-lane moves, then four waves through LDS), and k_check_final folds the partials in a fixed order, so the
+// result does not depend on the order in which workgroups retire.
+struct CheckPartial {
+    double sum_rho;                 // over the finite cells
+    unsigned long long nonfinite;   // cells whose rho, u or v is not finite
+    float max_usq;                  // max u^2 + v^2 (lattice units)
+    int pad;
+};
+
+__device__ __forceinline__ void check_reduce_wave(double &s, unsigned long long &n, float &m)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_xor(s, d);
+        n += __shfl_xor(n, d);
+        m = fmaxf(m, __shfl_xor(m, d));
+    }
+}
+
+// grid = (ceil(fpitch / 1024), H), 256 threads, 4 cells per lane; origin = plane 0, row 0 of the current lattice
+template <bool STORE>
+__global__ __launch_bounds__(256) void k_macro_check(const float *origin, long long plane, int pitch, int fpitch, int nx,
+                                                     float *rho, float *u, float *v, CheckPartial *part)
+{
+    __shared__ CheckPartial sh[4];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    double s = 0.0;
+    unsigned long long n = 0;
+    float m = 0.f;
+    if (x4 < fpitch) {
+        const float *r = origin + (long long)y * pitch + x4;
+        f4a q[9], r4, u4, v4;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q[k] = *reinterpret_cast<const f4a *>(r + k * plane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+            float rr, ux, uy;
+            moments_cell(c, rr, ux, uy);
+            r4[j] = rr; u4[j] = ux; v4[j] = uy;
+            if (x4 + j < nx) {
+                const float usq = ux * ux + uy * uy;
+                const bool ok = fabsf(rr) <= 3.0e38f && fabsf(usq) <= 3.0e38f;      // (false for NaN)
+                if (ok) { s += (double)rr; m = fmaxf(m, usq); }
+                else ++n;
+            }
+        }
+        if (STORE) {
+            const long long o = (long long)y * fpitch + x4;
+            *reinterpret_cast<f4a *>(rho + o) = r4;
+            *reinterpret_cast<f4a *>(u + o) = u4;
+            *reinterpret_cast<f4a *>(v + o) = v4;
+        }
+    }
+    check_reduce_wave(s, n, m);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = CheckPartial{s, n, m, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        CheckPartial t = sh[0];
+        for (int i = 1; i < 4; ++i) { t.sum_rho += sh[i].sum_rho; t.nonfinite += sh[i].nonfinite; t.max_usq = fmaxf(t.max_usq, sh[i].max_usq); }
+        part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// one workgroup of 1024 threads: thread t folds partials t, t + 1024, ... in that order, then a fixed tree
+__global__ __launch_bounds__(1024) void k_check_final(const CheckPartial *part, long long count, CheckPartial *out)
+{
+    __shared__ CheckPartial sh[16];
+    double s = 0.0;
+    unsigned long long n = 0;
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < count; i += 1024) {
+        s += part[i].sum_rho; n += part[i].nonfinite; m = fmaxf(m, part[i].max_usq);
+    }
+    check_reduce_wave(s, n, m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = CheckPartial{s, n, m, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        CheckPartial t = sh[0];
+        for (int i = 1; i < 16; ++i) { t.sum_rho += sh[i].sum_rho; t.nonfinite += sh[i].nonfinite; t.max_usq = fmaxf(t.max_usq, sh[i].max_usq); }
+        *out = t;
+    }
+}
+
+// the folded record laid out for two all-reduces: {sum_rho, count} as doubles, max u^2 as a float
+__global__ void k_check_spread(const CheckPartial *res, double *d, float *m)
+{
+    d[0] = res->sum_rho;
+    d[1] = (double)res->nonfinite;
+    m[0] = res->max_usq;
+}
+
 // Halo pack / unpack: the halo of one edge is 18 (3 rows deep), 45 (6 deep) or 63 (8 deep) row segments scattered
 // over the planes (HaloTables on the host side).  One tiny kernel gathers both edges into two contiguous
 // buffers (so that an exchange is one send + one receive per neighbour), one scatters the received

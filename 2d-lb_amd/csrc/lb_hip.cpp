@@ -145,6 +145,9 @@ struct lb_sim {
     bool has_mask = false;
     int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
+    bool macro_valid = true;    // rho,u,v hold the last step's fields (false: to be rebuilt from the populations, ensure_macro)
+    CheckPartial *check_part = nullptr;   // one partial per workgroup of k_macro_check (+ the folded result behind them)
+    long long check_cap = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr, edge_stream = nullptr;
     hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_packed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     ncclComm_t comm = nullptr;
@@ -178,6 +181,15 @@ struct DeviceGuard {
 
 // boundary family as the kernels' template argument (the D2Q9i fork is the PIPE family with its own cell routines)
 int kernel_bc(const lb_sim *s) { return s->p.semantics == LB_SEM_OPENCL_D2Q9I ? LB_BC_PIPE_I : s->p.bc_mode; }
+
+// rho, u, v of the plain families are rebuilt from the populations on demand instead of being stored by the last launch
+// of every run (include/lb_hip.h, LB_FLAG_EAGER_MACRO); LB_EAGER_MACRO=1 in the environment = the flag on every handle
+bool lazy_macro(const lb_sim *s)
+{
+    static const bool eager_env = getenv("LB_EAGER_MACRO") && atoi(getenv("LB_EAGER_MACRO")) != 0;
+    return !eager_env && !(s->p.flags & LB_FLAG_EAGER_MACRO) && s->p.semantics == LB_SEM_OPENCL &&
+           (s->p.bc_mode == LB_BC_PIPE || s->p.bc_mode == LB_BC_PERIODIC || s->p.bc_mode == LB_BC_CAVITY);
+}
 
 StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
 {
@@ -261,6 +273,7 @@ int effective_variant(const lb_sim *s)
 int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macro)
 {
     if (row_count <= 0) return LB_OK;
+    macro = macro && !lazy_macro(s);       // (no fused kernel stores rho, u, v on a handle that rebuilds them on demand)
     const StepArgs a = step_args(s, row_begin, row_step, row_count);
     const int variant = effective_variant(s);
     const int rpb_sel = (variant >> 2) & 3;          // bits 2-3: rows per block 0 -> 4, 1 -> 1, 2 -> 2
@@ -387,6 +400,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
                  int seg_rows_fixed = 0, int seg_stride = 0, int reserve = 0, int depth = 2)
 {
     if (row_end <= row_begin) return LB_OK;
+    macro = macro && !lazy_macro(s);
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
     const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
@@ -476,6 +490,7 @@ void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
 // Four time steps of a whole-grid handle through LDS tiles.
 int launch_tile4(lb_sim *s, bool macro)
 {
+    macro = macro && !lazy_macro(s);
     const StepArgs a = step_args(s, 0, 1, s->H);
     switch (s->p.bc_mode) {
     case LB_BC_PIPE: launch_tile_bc<LB_BC_PIPE>(s, a, macro); break;
@@ -563,6 +578,44 @@ int need_single_slab(const lb_sim *s, const char *what)
 {
     if (s->multi_slab())
         return fail(LB_ERR_STATE, "%s is only available on a handle that owns the whole grid", what);
+    return LB_OK;
+}
+
+// One pass over the current populations (k_macro_check): store = rebuild rho, u, v from them; the per-workgroup partials of
+// the health check are folded into check_part[blocks] on the way (lb_check reads that one record).
+int macro_check_pass(lb_sim *s, bool store)
+{
+    const dim3 grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)s->H);
+    const long long blocks = (long long)grid.x * grid.y;
+    if (s->check_cap < blocks + 1) {
+        if (s->check_part) HIP_TRY(hipFree(s->check_part));
+        s->check_part = nullptr;
+        s->check_cap = 0;
+        HIP_TRY(hipMalloc(&s->check_part, sizeof(CheckPartial) * (size_t)(blocks + 1)));
+        s->check_cap = blocks + 1;
+        s->bytes += (int64_t)sizeof(CheckPartial) * (blocks + 1);
+    }
+    if (store)
+        hipLaunchKernelGGL(k_macro_check<true>, grid, dim3(256), 0, s->stream, (const float *)s->origin(s->cur), s->plane,
+                           (int)s->rowp, (int)s->pitch, s->p.nx, s->rho, s->u, s->v, s->check_part);
+    else
+        hipLaunchKernelGGL(k_macro_check<false>, grid, dim3(256), 0, s->stream, (const float *)s->origin(s->cur), s->plane,
+                           (int)s->rowp, (int)s->pitch, s->p.nx, s->rho, s->u, s->v, s->check_part);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_check_final, dim3(1), dim3(1024), 0, s->stream, (const CheckPartial *)s->check_part, blocks,
+                       s->check_part + blocks);
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+// rho, u, v as of the last time step, before anybody reads them or overwrites the populations they are derived from
+int ensure_macro(lb_sim *s)
+{
+    if (s->macro_valid) return LB_OK;
+    // (a run on a slab ends with both of its other streams joined into s->stream: lb_run's tail)
+    int rc = macro_check_pass(s, true);
+    if (rc) return rc;
+    s->macro_valid = true;
     return LB_OK;
 }
 
@@ -745,6 +798,7 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
 {
     int rc;
     const int H = s->H;
+    macro = macro && !lazy_macro(s);
     if (adv >= 2) {
         const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
         const bool three = (adv == 3);
@@ -831,10 +885,11 @@ int slab_cycle_first(lb_sim *s, int D, bool last = false)
 {
     const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
     const StepArgs probe = step_args(s, 0, 1, 1);
+    const bool macro = last && !lazy_macro(s);
     int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D, H - D, (probe.ghost_n && !last) ? H + D : H,
-                          last, D);
+                          macro, D);
     if (rc) return rc;
-    if ((rc = launch_step2(s, s->stream, D, H - D, last, 0, 0, 0, 2 * strips, D))) return rc;
+    if ((rc = launch_step2(s, s->stream, D, H - D, macro, 0, 0, 0, 2 * strips, D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
@@ -843,6 +898,7 @@ int slab_cycle_first(lb_sim *s, int D, bool last = false)
 int slab_cycle_second(lb_sim *s, bool macro, int D)
 {
     const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
+    macro = macro && !lazy_macro(s);
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     int rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D);
     if (rc) return rc;
@@ -955,9 +1011,10 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
             left -= GRAPH_STEPS;                                // GRAPH_STEPS is even: cur is unchanged
         }
     }
+    const bool store_macro = final_macro && !lazy_macro(s);   // (lazy: rebuilt from the populations when asked for)
     while (left > 0) {
         const int adv = next_advance(depths, left);
-        const bool macro = final_macro && (left == adv);
+        const bool macro = store_macro && (left == adv);
         if (adv == 4 && tile) rc = launch_tile4(s, macro);
         else if (adv >= 3 && s->p.bc_mode == LB_BC_VELOCITY_INLET) rc = vel_band_pass(s, adv, macro);
         else if (adv >= 2) rc = launch_step2(s, s->stream, 0, s->H, macro, 0, 0, 0, 0, adv);
@@ -966,7 +1023,10 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
         s->cur ^= 1;
         left -= adv;
     }
-    if (n_steps) s->feq_valid = false;
+    if (n_steps) {
+        s->feq_valid = false;
+        s->macro_valid = store_macro;
+    }
     return LB_OK;
 }
 
@@ -1046,6 +1106,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     if (rc) return rc;
     s->cur ^= 1;
     s->feq_valid = false;
+    s->macro_valid = !lazy_macro(s);
     return used + 1;
 }
 
@@ -1120,7 +1181,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     if (!(p->omega > 0.f && p->omega < 2.f)) return fail(LB_ERR_ARG, "omega must be in (0,2), got %g", p->omega);
     for (int r : p->reserved)
         if (r != 0) return fail(LB_ERR_ARG, "reserved fields must be zero");
-    if (p->flags & ~(LB_FLAG_HALO | LB_FLAG_PLANAR)) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
+    if (p->flags & ~(LB_FLAG_HALO | LB_FLAG_PLANAR | LB_FLAG_EAGER_MACRO)) return fail(LB_ERR_ARG, "unknown flags 0x%x", p->flags);
     if (p->semantics != LB_SEM_OPENCL && p->semantics != LB_SEM_CYTHON && p->semantics != LB_SEM_OPENCL_D2Q9I)
         return fail(LB_ERR_ARG, "unknown semantics %d", p->semantics);
     if (p->semantics == LB_SEM_OPENCL_D2Q9I &&
@@ -1221,6 +1282,7 @@ int lb_destroy(lb_sim *s)
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner, s->stage})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
+    if (s->check_part) (void)hipFree(s->check_part);
     for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_t0, s->ev_t1})
         if (e) (void)hipEventDestroy(e);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1271,6 +1333,7 @@ int lb_set_macro(lb_sim *s, const float *rho, const float *u, const float *v)
     if (!s || !rho || !u || !v) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     int rc;
+    s->macro_valid = true;
     if ((rc = copy_plane_h2d(s, s->rho, rho))) return rc;
     if ((rc = copy_plane_h2d(s, s->u, u))) return rc;
     if ((rc = copy_plane_h2d(s, s->v, v))) return rc;
@@ -1283,6 +1346,7 @@ int lb_get_macro(lb_sim *s, float *rho, float *u, float *v)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     int rc;
+    if ((rc = ensure_macro(s))) return rc;
     if (rho && (rc = copy_plane_d2h(s, rho, s->rho))) return rc;
     if (u && (rc = copy_plane_d2h(s, u, s->u))) return rc;
     if (v && (rc = copy_plane_d2h(s, v, s->v))) return rc;
@@ -1295,13 +1359,15 @@ int lb_set_f(lb_sim *s, const float *f)
     if (!s || !f) return fail(LB_ERR_ARG, "null argument");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_set_f between lb_step_boundary and lb_step_finish");
     DeviceGuard guard(s->p.device);
+    int rc = ensure_macro(s);       // rho, u, v stay those of the last step, as in the reference (they are derived from the OLD f)
+    if (rc) return rc;
     const size_t host_plane = (size_t)s->p.nx * s->H;
     for (int k = 0; k < 9; ++k) {
-        int rc = lattice_plane_h2d(s, s->origin(s->cur), k, f + k * host_plane);
+        rc = lattice_plane_h2d(s, s->origin(s->cur), k, f + k * host_plane);
         if (rc) return rc;
     }
     // f_streamed = f (opencl_dim.py:323-327)
-    int rc = copy_lattice(s, s->lat[s->cur ^ 1], s->lat[s->cur]);
+    rc = copy_lattice(s, s->lat[s->cur ^ 1], s->lat[s->cur]);
     if (rc) return rc;
     if ((rc = corners_capture(s, s->cur))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1432,6 +1498,7 @@ int lb_move(lb_sim *s)
     int rc = need_single_slab(s, "lb_move");
     if (rc) return rc;
     DeviceGuard guard(s->p.device);
+    if ((rc = ensure_macro(s))) return rc;
     if (s->p.semantics == LB_SEM_CYTHON) {
         // every entry of the target is written, so the lattices simply swap
         hipLaunchKernelGGL(k1_move, cells_grid(s, 9), dim3(256), 0, s->stream, phase_args(s));
@@ -1459,6 +1526,7 @@ int lb_move_bcs(lb_sim *s)
     int rc = need_single_slab(s, "lb_move_bcs");
     if (rc) return rc;
     DeviceGuard guard(s->p.device);
+    if ((rc = ensure_macro(s))) return rc;
     if (s->p.semantics == LB_SEM_CYTHON)
         hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     else if (s->p.bc_mode == LB_BC_VELOCITY_INLET) {
@@ -1489,6 +1557,7 @@ int lb_update_hydro(lb_sim *s)
     } else
         hipLaunchKernelGGL(k_hydro, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
+    s->macro_valid = true;
     return LB_OK;   // feq keeps its previous content, as the reference's feq buffer does
 }
 
@@ -1498,6 +1567,7 @@ int lb_update_feq(lb_sim *s)
     DeviceGuard guard(s->p.device);
     int rc = ensure_feq(s);
     if (rc) return rc;
+    if ((rc = ensure_macro(s))) return rc;
     PhaseArgs a = phase_args(s);
     a.ny = s->H;   // rho,u,v are local: valid for slabs too
     if (s->p.semantics == LB_SEM_OPENCL_D2Q9I)
@@ -1516,6 +1586,7 @@ int lb_collide_particles(lb_sim *s)
     if (rc) return rc;
     if (!s->feq) return fail(LB_ERR_STATE, "lb_collide_particles before any lb_update_feq");
     DeviceGuard guard(s->p.device);
+    if ((rc = ensure_macro(s))) return rc;
     hipLaunchKernelGGL(k_collide, cells_grid(s, 9), dim3(256), 0, s->stream, phase_args(s));
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -1526,6 +1597,10 @@ int lb_zero_velocity_in_obstacle(lb_sim *s)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (!s->has_mask) return LB_OK;
     DeviceGuard guard(s->p.device);
+    {
+        int rc = ensure_macro(s);
+        if (rc) return rc;
+    }
     PhaseArgs a = phase_args(s);
     hipLaunchKernelGGL(k_zero_vel, dim3((s->p.nx + 255) / 256, s->H, 1), dim3(256), 0, s->stream, a);
     HIP_TRY(hipGetLastError());
@@ -1574,6 +1649,7 @@ int lb_step_finish(lb_sim *s)
     s->cur ^= 1;
     s->stepping = 0;
     s->feq_valid = false;
+    s->macro_valid = !lazy_macro(s);      // (rebuilt on demand there; the other families stored them if write_macro said so)
     s->ghost_depth = 0;   // the caller imports the new ghosts (lb_run manages its own)
     return LB_OK;
 }
@@ -1627,7 +1703,7 @@ int lb_run(lb_sim *s, int n_steps)
             HIP_TRY(hipGetLastError());
             s->cur ^= 1;
         }
-        if (n_steps) s->feq_valid = false;
+        if (n_steps) { s->feq_valid = false; s->macro_valid = true; }
         return LB_OK;
     }
     if (!s->multi_slab()) return run_whole_grid(s, n_steps);     // (never blocks the host: tuning is lb_autotune*'s job)
@@ -1705,6 +1781,7 @@ int lb_run(lb_sim *s, int n_steps)
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
     if (stepped) s->ghost_depth = 3;
     s->feq_valid = false;
+    s->macro_valid = !lazy_macro(s);
     return LB_OK;
 }
 
@@ -1720,10 +1797,17 @@ int lb_run(lb_sim *s, int n_steps)
 // profiles/r02_experiments.txt): it looks like barriers between a high-priority and a normal hardware queue going wrong
 // while queues are time-sliced, but a missing wait here has not been ruled out.  A verification harness must
 // not raise false alarms, so it joins the device after every exchange; LB_DEBUG_SYNC=0 gives the event-only schedule.
+static int g_debug_sync = -1;         // < 0: not read from the environment yet
 static int debug_sync_bits()
 {
-    static const int bits = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) : 2;
-    return bits;
+    if (g_debug_sync < 0) g_debug_sync = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) & 15 : 2;
+    return g_debug_sync;
+}
+int lb_set_debug_sync(int bits)
+{
+    const int prev = debug_sync_bits();
+    g_debug_sync = bits & 15;
+    return prev;
 }
 #define DBG_SYNC(bit)                                                   \
     do {                                                                \
@@ -1861,6 +1945,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
             HIP_TRY(hipStreamSynchronize(sims[i]->stream));
             sims[i]->ghost_depth = depth_after;
             sims[i]->feq_valid = false;
+            sims[i]->macro_valid = !lazy_macro(sims[i]);
         }
         if (left == 0) return LB_OK;
         for (int i = 0; i < count; ++i) {
@@ -1900,6 +1985,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
     for (int i = 0; i < count; ++i) {
         sims[i]->ghost_depth = 3;
         sims[i]->feq_valid = false;
+        sims[i]->macro_valid = !lazy_macro(sims[i]);
     }
     DBG_SYNC(8);
     return LB_OK;
@@ -1933,10 +2019,12 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps)
     }
     const dim3 block(256, 1);
     const dim3 grid((unsigned)((s0->pitch / 4 + 255) / 256), (unsigned)s0->H, (unsigned)count);
+    bool lazy = true;              // (one launch serves all members: rho, u, v are stored unless every member rebuilds them on demand)
+    for (int i = 0; i < count; ++i) lazy = lazy && lazy_macro(sims[i]);
     for (int it = 0; it < n_steps; ++it) {
         BatchArgs b;
         for (int i = 0; i < count; ++i) b.a[i] = step_args(sims[i], 0, 1, sims[i]->H);
-        const bool macro = (it == n_steps - 1);
+        const bool macro = (it == n_steps - 1) && !lazy;
         if (s0->has_mask) {
             if (macro) hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, true, true>), grid, block, 0, s0->stream, b);
             else hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, true, false>), grid, block, 0, s0->stream, b);
@@ -1952,6 +2040,7 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps)
     for (int i = 0; i < count; ++i) {
         if (i) HIP_TRY(hipStreamWaitEvent(sims[i]->stream, s0->ev_interior, 0));
         sims[i]->feq_valid = false;
+        sims[i]->macro_valid = !lazy;
     }
     return LB_OK;
 }
@@ -1996,6 +2085,43 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
         HIP_TRY(hipStreamSynchronize(s->edge_stream));
     }
     s->ghost_depth = 0;
+    return LB_OK;
+}
+
+// ---- health check ------------------------------------------------------------------------
+int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach, double *sum_rho)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (s->stepping) return fail(LB_ERR_STATE, "lb_check inside a split step");
+    if (across_ranks && !s->comm) return fail(LB_ERR_STATE, "lb_check across ranks needs lb_comm_init");
+    DeviceGuard guard(s->p.device);
+    // the pass that rebuilds rho, u, v reduces the same three numbers: one pass serves both when the fields are due
+    int rc = macro_check_pass(s, !s->macro_valid);
+    if (rc) return rc;
+    s->macro_valid = true;
+    CheckPartial *res = s->check_part + (s->check_cap - 1);
+    CheckPartial h;
+    if (across_ranks) {
+        // sum_rho and the count travel as two doubles (exact up to 2^53 cells), the maximum on its own
+        double *d = reinterpret_cast<double *>(s->halo_buf);             // (>= 4 x 63 x nx floats, free between runs)
+        float *m = reinterpret_cast<float *>(d + 4);
+        hipLaunchKernelGGL(k_check_spread, dim3(1), dim3(1), 0, s->stream, (const CheckPartial *)res, d, m);
+        HIP_TRY(hipGetLastError());
+        NCCL_TRY(g_rccl.AllReduce(d, d + 2, 2, ncclFloat64, ncclSum, s->comm, s->stream));
+        NCCL_TRY(g_rccl.AllReduce(m, m + 1, 1, ncclFloat32, ncclMax, s->comm, s->stream));
+        double hd[2];
+        float hm;
+        HIP_TRY(hipMemcpyAsync(hd, d + 2, sizeof(hd), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(&hm, m + 1, sizeof(hm), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        h.sum_rho = hd[0]; h.nonfinite = (unsigned long long)hd[1]; h.max_usq = hm;
+    } else {
+        HIP_TRY(hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    if (n_nonfinite) *n_nonfinite = (int64_t)h.nonfinite;
+    if (max_mach) *max_mach = sqrtf(3.f * h.max_usq);                   // |u| / c_s, c_s = 1 / sqrt(3)
+    if (sum_rho) *sum_rho = h.sum_rho;
     return LB_OK;
 }
 

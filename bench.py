@@ -299,10 +299,12 @@ def main():
         if 0.5 * t1 / q < a <= 1.02 * t1 / q:          # (else: keep the block average below)
             plain_ms, macro_extra_ms = a, max(t1 - q * a, 0.0)
 
-    # sanity: the run must have produced finite numbers (guards against timing a broken kernel)
-    chk = eng.get_fields(("rho",))["rho"]
-    if not np.all(np.isfinite(chk)) or abs(float(chk.mean()) - 1.0) > 1e-3:
-        raise SystemExit("bench: non-physical density after the run (mean %r)" % float(chk.mean()))
+    # sanity: the run must have produced finite, physical numbers (guards against timing a broken kernel) -- one
+    # device pass and 24 bytes to the host (lb_check) instead of downloading a 268 MB plane
+    health = sim.check() if dist is not None else eng.check()
+    mean_rho = health["sum_rho"] / (float(n) * n)
+    if health["n_nonfinite"] or abs(mean_rho - 1.0) > 1e-3 or not health["max_mach"] < 0.3:
+        raise SystemExit("bench: non-physical state after the run (%r)" % (health,))
 
     if rank == 0:
         cells = float(n) * n

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 4
+#define LB_ABI_VERSION 5
 
 typedef enum {
     LB_OK = 0,
@@ -98,6 +98,14 @@ typedef struct {
  * ([row][plane][pitch]); with this flag each plane is contiguous ([plane][row][pitch], the round-1 layout).  Results are
  * bit-identical; the marching kernels stream ~12 % faster from interleaved rows at 8192^2. */
 #define LB_FLAG_PLANAR 2
+/* rho, u, v after lb_run.  BGK relaxation conserves rho and rho*u, so the moments of the post-collision populations a run
+ * leaves behind are the rho, u, v of its last step (the reference stores the pre-collision moments, opencl_dim.py:384-385:
+ * equal up to rounding).  By default lb_run therefore stores nothing but the populations in the PIPE / PERIODIC / CAVITY
+ * families of the OpenCL path, and the fields are rebuilt from them by one device pass the first time they are asked for
+ * (lb_get_macro, lb_update_feq, ..., or before anything else overwrites the populations).  With this flag the last launch
+ * of every lb_run stores them itself, as round 2 did (12 B per cell more in that launch).  The other families /
+ * semantics always store: their fields are not plain moments (imposed inlet speeds, wall overrides, momentum). */
+#define LB_FLAG_EAGER_MACRO 4
 
 /* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the eight-step halo cycle
  * recomputes four of the neighbour's rows and reads the mask three rows beyond them. */
@@ -205,6 +213,22 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps);
 int lb_comm_available(void);               /* 0 when librccl can be loaded in this process (no communicator is made) */
 int lb_comm_unique_id(void *unique_id_128);
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
+
+/* ---- health check (the reference's forks warn when max |u| exceeds a tenth of the speed of sound,
+ *      porous_media/single_component.py:221-225, and print field sums while debugging, check_fields() :753-766; the
+ *      `dimensionless` classes have nothing, and a diverged run is only noticed after downloading a field) ------------
+ * One device pass over the current populations of this handle's rows: the number of cells whose density or velocity is
+ * not finite, the largest Mach number max |u| / c_s (c_s = 1/sqrt(3); velocity = first moment / density in every
+ * semantics) and the total mass, sum of rho, over the finite cells.  Reduced on the device (wave64 cross-lane
+ * reduction, one partial per workgroup, folded in a fixed order: the result is reproducible), 24 bytes travel to the
+ * host.  Waits for the handle's work.  across_ranks != 0 on a handle with a communicator (lb_comm_init): the three
+ * values are combined over all ranks with ncclAllReduce (sum, max, sum) -- a collective, every rank calls it.
+ * Any output pointer may be NULL. */
+int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach, double *sum_rho);
+/* lb_run_group joins the device at chosen points (bits: 1 after every launch phase, 2 after every exchange, 4 after every
+ * step, 8 at entry and exit); 0 = events only, the schedule lb_run itself relies on.  Process-wide; initial value from the
+ * environment variable LB_DEBUG_SYNC, default 0.  Returns the previous value. */
+int lb_set_debug_sync(int bits);
 
 /* ---- measurement --------------------------------------------------------- */
 /* hipEvent pair on the handle's stream: start, [enqueue work], stop -> ms. */

@@ -108,6 +108,18 @@ class OracleSlabEngine(object):
                 if row == 0 and k in K_DOWN:
                     a[k, self.rows - 1] = src[i]
 
+    def check(self, across_ranks=False, warn=False, raise_nonfinite=False):
+        """Simulation.check on the host: moments of the current populations of this slab's rows."""
+        f = self.cur[:, self.gs:self.gs + self.h].astype(np.float64)
+        rho = f.sum(axis=0)
+        with np.errstate(all="ignore"):
+            ux = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) / rho
+            uy = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) / rho
+        ok = np.isfinite(rho) & np.isfinite(ux) & np.isfinite(uy)
+        usq = np.where(ok, ux * ux + uy * uy, 0.0)
+        return {"n_nonfinite": int((~ok).sum()), "max_mach": float(np.sqrt(3.0 * usq.max())),
+                "sum_rho": float(rho[ok].sum())}
+
     def get_fields(self, which=("f", "u", "v", "rho")):
         sl = slice(self.gs, self.gs + self.h)
         out = {}

@@ -39,8 +39,10 @@ def _worker(rank, world, port, bc, steps, out_dir):
         slab.set_f(f0)
         slab.run(steps)
         g = slab.get_fields(("f", "rho", "u", "v"))
+        chk = slab.check()                  # collective: the three health scalars combined over the ranks
         if rank == 0:
-            np.savez(os.path.join(out_dir, "out_%s_%d.npz" % (bc, world)), **g)
+            np.savez(os.path.join(out_dir, "out_%s_%d.npz" % (bc, world)), check=np.array(
+                [chk["n_nonfinite"], chk["max_mach"], chk["sum_rho"]], np.float64), **g)
     finally:
         dist.destroy_process_group()
 
@@ -65,6 +67,14 @@ def test_distributed_slabs_equal_single_domain(oracle, tmp_path, bc, world):
     want = ref.get_fields()
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(got[k], want[k]), (bc, world, k)
+    # DistributedSlab.check: the per-rank scalars summed / maximised over the ranks == the whole lattice's
+    f = want["f"].astype(np.float64)
+    rho = f.sum(axis=2)
+    ux = (f[..., 1] - f[..., 3] + f[..., 5] - f[..., 6] - f[..., 7] + f[..., 8]) / rho
+    uy = (f[..., 5] + f[..., 2] + f[..., 6] - f[..., 7] - f[..., 4] - f[..., 8]) / rho
+    n_bad, mach, mass = got["check"]
+    assert n_bad == 0 and abs(mass - rho.sum()) <= 1e-9 * rho.sum()
+    assert abs(mach - np.sqrt(3.0 * (ux * ux + uy * uy).max())) <= 1e-6
 
 
 # ---- multi-rank checkpoint: written by 2 ranks, continued by 3 ---------------------------------------------------
