@@ -5,6 +5,11 @@ periodic shear layer (BASELINE.json: metric / configs[3]), 1..8 MI355X, row slab
     python bench.py --gpus N --steps K --warmup W          # N > 1: spawns one rank process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config {2,3,4,5}                     # the other single-GPU configurations of BASELINE.json
+                                                           # (1-based: 2 = 1024^2 lid-driven cavity Re 1000, 3 = 4096^2
+                                                           # Kelvin-Helmholtz, 4 = the default, 5 = 4096^2 pipe + TIFF obstacles),
+                                                           # one timed run per case like the reference's own comparison
+                                                           # (docs/python_cython_opencl_comparison.ipynb:271-273)
 
 A "step" = one pass of the hot path (stream + BC + moments + feq + BGK collide) over the whole grid.  The
 grid is fixed as N grows (strong scaling, as the north-star states its 8-GPU target).  Rank 0 prints ONE JSON
@@ -17,17 +22,19 @@ fresh box no longer decides the line.
 
 Extra objects in the line:
   roofline     - the dominant kernel against the HBM roofline.  `achieved` = the bytes one launch MUST move --
-                 72 B x the cells of its slab (nine fp32 planes read once, nine written once), whatever
-                 number of time steps the launch fuses -- / the duration of one launch of that kernel (HIP events
-                 on the engine's stream: runs of 2q and of q launches, difference / q, right after the timed region;
-                 the last launch of a run() also stores rho, u, v and is ~11 % longer, so the K-step block average
-                 would mix two kinds of launches; N > 1: the block average); `frac` = achieved / 8 TB/s, <= 1.
+                 72 B x the cells of its slab (nine fp32 planes read once, nine written once; 73 B with an obstacle
+                 mask), whatever number of time steps the launch fuses -- / the average duration of a launch inside the
+                 timed K-step blocks (HIP events on the engine's stream around every block: what `value` is made of);
+                 `frac` = achieved / 8 TB/s, <= 1.  `frac_plain_launch` prices a launch in the middle of a long run
+                 instead (runs of 2q and of q launches, difference / q, right after the timed region): the two differ
+                 by whatever the first / last launch of a run() costs extra.
                  `effective_GBps` = 72 B x lattice UPDATES / time (what an un-blocked kernel would have to move
                  for the same MLUPS; exceeds the peak when several steps share one pass) is reported beside it,
                  never as `frac`.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of
                  this same command (profiles/pmc_traffic.json; see `traffic_source`), not measured in this run.
-  cpu_baseline - oracle port of the reference's Cython CPU path (oracle/d2q9_oracle.c o1_run),
-                 1 core, on a bounded sample; reported, not a target.  Rank 0, N=1 only.
+  cpu_baseline - oracle port of the reference's Cython CPU path (oracle/d2q9_oracle.c o1_run, in the mode that is
+                 pinned bit-exact to the imported reference: numpy2=True), 1 core, bounded samples at 256^2, 1024^2 and
+                 4096^2 (`value` = the 4096^2 sample); reported, not a target.  Rank 0, N=1 only.
 """
 import argparse
 import json
@@ -62,56 +69,98 @@ def shear_layer(nx, ny, y0, h, U=0.04, seed=0):
     return rho, u, v
 
 
-def cpu_baseline(budget_s=12.0, n=4096, all_cores_budget_s=4.0):
-    """Time the oracle's restatement of the reference Cython path (cython_dim.pyx:346-359, five
-    un-fused passes, single thread) on an n x n pipe flow for about budget_s seconds."""
+def cpu_baseline(budgets=((256, 3.0), (1024, 4.0), (4096, 10.0)), all_cores_budget_s=4.0):
+    """Time the oracle's restatement of the reference Cython path (cython_dim.pyx:346-359, five un-fused passes, single
+    thread) in its pinned mode (numpy2=True: bit-exact against the imported reference, tests/test_oracle_golden.py) on
+    n x n pipe flows for about the given seconds each: 256^2 (BASELINE config 1), 1024^2, 4096^2."""
     from oracle import oracle as O
-    kw = dict(diameter=1., rho=1., viscosity=0.05, pressure_grad=-1., pipe_length=1., N=n - 1,
-              time_prefactor=(n - 1) / 10.)
-    sim = O.O1Sim.pipe_flow(numpy2=False, **kw)
-    sim.run(1)                                   # touch every page once
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        sim.run(1)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 1000:
-            break
-    mlups = sim.nx * sim.ny * steps / el / 1e6
-    out = {"value": round(mlups, 3), "unit": "MLUPS", "cores": 1, "kind": "port",
-           "sample": "oracle o1_run (C port of cython_dim.pyx Pipe_Flow.run), %dx%d grid, %d steps, %.1f s, "
-                     "1 thread of %d available" % (sim.nx, sim.ny, steps, el, len(os.sched_getaffinity(0)))}
+    ncores = len(os.sched_getaffinity(0))
+
+    def sample(n, budget_s, openmp=False):
+        kw = dict(diameter=1., rho=1., viscosity=0.05, pressure_grad=-1., pipe_length=1., N=n - 1,
+                  time_prefactor=(n - 1) / 10.)
+        sim = O.O1Sim.pipe_flow(numpy2=True, **kw)
+        sim.run(1, openmp=openmp)                    # touch every page once
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            sim.run(1, openmp=openmp)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or steps >= 20000:
+                break
+        return sim.nx * sim.ny * steps / el / 1e6, sim.nx, sim.ny, steps, el
+
+    sizes = []
+    for n, budget in budgets:
+        mlups, nx, ny, steps, el = sample(n, budget)
+        sizes.append({"grid": [nx, ny], "value": round(mlups, 3), "steps": steps, "seconds": round(el, 2)})
+    big = sizes[-1]
+    out = {"value": big["value"], "unit": "MLUPS", "cores": 1, "kind": "port",
+           "sample": "oracle o1_run (C port of cython_dim.pyx Pipe_Flow.run, numpy2=True = the mode pinned bit-exact to the "
+                     "imported reference), %dx%d grid, %d steps, %.1f s, 1 thread of %d available"
+                     % (big["grid"][0], big["grid"][1], big["steps"], big["seconds"], ncores),
+           "sizes": sizes}
     if all_cores_budget_s > 0:
         # "honest best CPU" line (BASELINE.md section 4): the same port with OpenMP over the independent
         # cell loops (the in-place streaming only splits four ways), all host cores
-        ncores = len(os.sched_getaffinity(0))
-        sim.run(1, openmp=True)
-        steps, t0 = 0, time.perf_counter()
-        while True:
-            sim.run(1, openmp=True)
-            steps += 1
-            el = time.perf_counter() - t0
-            if el >= all_cores_budget_s or steps >= 1000:
-                break
-        out["all_cores"] = {"value": round(sim.nx * sim.ny * steps / el / 1e6, 3), "unit": "MLUPS", "cores": ncores,
-                            "sample": "same port, -fopenmp, %d steps, %.1f s" % (steps, el)}
+        mlups, nx, ny, steps, el = sample(budgets[-1][0], all_cores_budget_s, openmp=True)
+        out["all_cores"] = {"value": round(mlups, 3), "unit": "MLUPS", "cores": ncores,
+                            "sample": "same port, -fopenmp, %dx%d, %d steps, %.1f s" % (nx, ny, steps, el)}
     return out
 
 
-def load_pmc_traffic(n_side, steps_per_launch=1):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
-    workload (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); (None, None) when absent."""
+def load_pmc_traffic(key, steps_per_launch=1):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this workload
+    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py; key = grid side, or "c<config>/<side>" for the
+    configurations other than the default).  Returns (bytes, source); bytes None with the reason in `source` when no
+    profile of that workload has been committed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    name = "%s/%d" % (key, steps_per_launch)
     try:
         with open(path) as fh:
             d = json.load(fh)
-        ent = d.get("%d/%d" % (n_side, steps_per_launch))
-        if not ent:
-            return None, None
-        return ent.get("hbm_bytes_per_launch"), "committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
-            "command, read side calibrated on k_copy4), not measured in this run" % ent.get("source", "profiles/pmc_traffic.json")
-    except (OSError, ValueError):
-        return None, None
+    except (OSError, ValueError) as exc:
+        return None, "no traffic figure: %s unreadable (%s)" % (path, exc)
+    ent = d.get(name)
+    if not ent:
+        return None, "no traffic figure: profiles/pmc_traffic.json holds no --pmc profile for %r (has: %s)" % (
+            name, ", ".join(sorted(d)))
+    return ent.get("hbm_bytes_per_launch"), "committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+        "command, read side calibrated on k_copy4), not measured in this run" % ent.get("source", "profiles/pmc_traffic.json")
+
+
+def workload(config, n, omega, local_rank, eager_macro=False):
+    """The single-GPU configurations of BASELINE.json (1-based as listed there): returns (simulation, description,
+    bytes per cell and launch).  Initial states are built on the device from uploaded rho, u, v (f = feq)."""
+    from LB_D2Q9.simulation import Simulation
+    if config == 2:
+        # 1024^2 lid-driven cavity, Re = U L / nu = 1000 with lid speed U = 0.1 (tests/test_gpu_fullsize.py: same case)
+        U = 0.1
+        nu = U * (n - 1) / 1000.0
+        om = 1.0 / (3.0 * nu + 0.5) if omega is None else omega
+        sim = Simulation(n, n, om, bc="cavity", lid_u=U, rho0=1.0, device=local_rank, eager_macro=eager_macro)
+        z = np.zeros((n, n), np.float32, order="F")
+        sim.init_equilibrium(np.ones((n, n), np.float32, order="F"), z, z)
+        return sim, "%dx%d lid-driven cavity, Re=1000 (U=%.2g, omega=%.4f), D2Q9 BGK fp32" % (n, n, U, om), B_ALG
+    if config == 3:
+        om = 1.8 if omega is None else omega
+        sim = Simulation(n, n, om, bc="periodic", device=local_rank, eager_macro=eager_macro)
+        sim.init_equilibrium(*shear_layer(n, n, 0, n, U=0.05))
+        return sim, "%dx%d Kelvin-Helmholtz double vortex sheet (periodic, U=0.05, omega=%g), D2Q9 BGK fp32" % (n, n, om), B_ALG
+    if config == 5:
+        from LB_D2Q9.masks import obstacle_mask_from_tiff
+        om = 1.0 if omega is None else omega
+        mask = np.array(obstacle_mask_from_tiff(os.path.join(ROOT, "tests", "golden", "CS205_obstacle_4.tif"), (n, n)), dtype=bool)
+        mask[0, :] = mask[-1, :] = False
+        mask[:, 0] = mask[:, -1] = False
+        sim = Simulation(n, n, om, bc="pipe", inlet_rho=1.001, outlet_rho=1.0, obstacle_mask=mask, device=local_rank,
+                         eager_macro=eager_macro)
+        z = np.zeros((n, n), np.float32, order="F")
+        sim.init_equilibrium(np.ones((n, n), np.float32, order="F"), z, z)
+        sim.zero_velocity_in_obstacle()
+        return sim, ("%dx%d porous-media obstacle flow: pressure-driven pipe, bounce-back mask from docs/CS205_obstacle_4.tif "
+                     "(%.2f %% solid), omega=%g, D2Q9 BGK fp32" % (n, n, 100.0 * mask.mean(), om)), B_ALG + 1.0
+    raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU plumbing case: tests/test_config1.py)")
 
 
 def spawn_ranks(n, argv):
@@ -172,11 +221,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--size", type=int, default=8192, help="grid side (BASELINE metric: 8192)")
-    ap.add_argument("--omega", type=float, default=1.7)
+    ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configuration, 1-based: 4 (default) = 8192^2 periodic shear layer, the one the metric "
+                         "is quoted on; 2 = 1024^2 lid-driven cavity Re=1000; 3 = 4096^2 Kelvin-Helmholtz; 5 = 4096^2 pipe "
+                         "flow through the porous-medium image.  2, 3, 5 are single-GPU cases")
+    ap.add_argument("--size", type=int, default=None, help="grid side (default: the configuration's own: 1024 / 4096 / 8192 / 4096)")
+    ap.add_argument("--omega", type=float, default=None, help="BGK relaxation rate (default: the configuration's own; 1.7 for config 4)")
     ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
+    ap.add_argument("--eager-macro", action="store_true",
+                    help="the last launch of every run() stores rho, u, v (LB_FLAG_EAGER_MACRO; round-2 behaviour) instead of "
+                         "leaving them to be rebuilt from the populations on demand")
     ap.add_argument("--force-slab-path", action="store_true",
                     help="run through DistributedSlab / the RCCL halo path even with one rank (a 1-rank periodic "
                          "ring exchanging with itself): exercises the multi-GPU code on a single GPU")
@@ -188,6 +244,12 @@ def main():
     args = ap.parse_args()
     if args.steps < 1:
         raise SystemExit("--steps must be >= 1")
+    if args.size is None:
+        args.size = {2: 1024, 3: 4096, 4: 8192, 5: 4096}[args.config]
+    if args.config != 4 and (args.gpus > 1 or args.force_slab_path):
+        raise SystemExit("--config %d is a single-GPU case" % args.config)
+    if args.config == 4 and args.omega is None:
+        args.omega = 1.7
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])
@@ -223,15 +285,20 @@ def main():
     from LB_D2Q9.slabs import DistributedSlab
 
     n = args.size
-    if world == 1 and not args.force_slab_path:
-        sim = Simulation(n, n, args.omega, bc="periodic", device=local_rank)
+    bytes_per_cell, what = B_ALG, None
+    if args.config != 4:
+        sim, what, bytes_per_cell = workload(args.config, n, args.omega, local_rank, eager_macro=args.eager_macro)
+        eng, y0, h = sim, 0, n
+    elif world == 1 and not args.force_slab_path:
+        sim = Simulation(n, n, args.omega, bc="periodic", device=local_rank, eager_macro=args.eager_macro)
         eng, y0, h = sim, 0, n
     else:
         # RCCL halo exchange inside the engine; if any rank cannot set it up, every rank falls back to the
         # torch.distributed-driven exchange (same halo format, single-step kernel, not overlapped)
         slab, failed = None, 0
         try:
-            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=args.transport, device=local_rank)
+            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=args.transport, device=local_rank,
+                                   eager_macro=args.eager_macro)
         except Exception as exc:                                   # noqa: BLE001 - reported below
             failed = 1
             print("rank %d: %s halo transport unavailable (%s)" % (rank, args.transport, exc), file=sys.stderr, flush=True)
@@ -243,13 +310,15 @@ def main():
             args.transport = "torch"
             if slab is not None:
                 slab.engine.close()
-            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport="torch", device=local_rank)
+            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport="torch", device=local_rank,
+                                   eager_macro=args.eager_macro)
         sim, eng, y0, h = slab, slab.engine, slab.y0, slab.h
     if args.variant is not None:
         eng.set_variant(args.variant)
-    rho, u, v = shear_layer(n, n, y0, h)
-    eng.init_equilibrium(rho, u, v)            # feq and f = feq are built on the device
-    del rho, u, v
+    if args.config == 4:
+        rho, u, v = shear_layer(n, n, y0, h)
+        eng.init_equilibrium(rho, u, v)        # feq and f = feq are built on the device
+        del rho, u, v
 
     def barrier():
         eng.sync()
@@ -318,17 +387,19 @@ def main():
         # K timed steps = (K // spl) launches of the spl-step kernel (+ at most one shorter launch for the
         # remainder, priced at the same per-step rate)
         launch_s = ev_ms / 1e3 / args.steps * spl
-        launch_source = "K-step block average (includes the launch that also stores rho, u, v)"
-        if plain_ms is not None and not python_driven:
-            launch_s = plain_ms / 1e3
-            launch_source = ("difference of runs of 2q and q launches / q (plain launches of the dominant kernel; the last "
-                             "launch of a run also stores rho, u, v: +%.4f ms)" % macro_extra_ms)
-        bytes_per_launch = B_ALG * n * h
+        launch_source = ("K-step block average: HIP events on the engine's stream around each timed block of %d steps / its "
+                         "%g launches (median block)" % (args.steps, args.steps / float(spl)))
+        bytes_per_launch = bytes_per_cell * n * h
         achieved = bytes_per_launch / launch_s / 1e9
-        effective = bytes_per_launch * spl / launch_s / 1e9
-        traffic, traffic_source = load_pmc_traffic(n, spl) if dist is None else (None, None)
+        effective = B_ALG * n * h * spl / launch_s / 1e9
+        traffic, traffic_source = load_pmc_traffic(n if args.config == 4 else "c%d/%d" % (args.config, n), spl) \
+            if dist is None else (None, "no traffic figure: counters are collected on one GPU")
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_plain_launch": None if plain_ms is None or python_driven else round(bytes_per_launch / (plain_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                "plain_launch_ms": None if plain_ms is None or python_driven else round(plain_ms, 4),
+                "plain_launch_source": "difference of runs of 2q and q launches / q, outside the timed region (a launch in the "
+                                       "middle of a long run; first/last-launch extras of a run: %+.4f ms)" % (macro_extra_ms or 0.0),
                 "frac_of_measured_copy": round(achieved / COPY_CEILING_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
@@ -336,9 +407,11 @@ def main():
                 "launch_ms": round(launch_s * 1e3, 4), "launch_ms_source": launch_source, "steps_per_launch": spl,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "effective_GBps": round(effective, 1), "effective_x_roofline": round(effective / HBM_PEAK_GBS, 4),
-                "note": "achieved = 72 B x cells of one launch (compulsory: each plane read once, written once) / "
+                "macro_fields": "rebuilt on demand from the populations (lb_get_macro / lb_check), not stored by run()"
+                                if not getattr(eng, "eager_macro", False) else "stored by the last launch of every run()",
+                "note": "achieved = %g B x cells of one launch (compulsory: each plane read once, written once%s) / "
                         "launch time; effective_GBps = 72 B x lattice updates / time is NOT an HBM rate when "
-                        "steps_per_launch > 1"}
+                        "steps_per_launch > 1" % (bytes_per_cell, "" if bytes_per_cell == B_ALG else ", + 1 B obstacle mask")}
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",
@@ -351,16 +424,17 @@ def main():
                        "min_ms_per_step": round(min(walls) * 1e3 / args.steps, 4),
                        "max_ms_per_step": round(max(walls) * 1e3 / args.steps, 4),
                        "timed_s": round(total, 3)},
-            "config": {"workload": "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
-                                   "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
-                                                                    "" if dist is None else ", halo via " + args.transport),
-                       "grid": [n, n], "bytes_per_lattice_update": B_ALG},
+            "config": {"workload": what or "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
+                                           "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
+                                                                            "" if dist is None else ", halo via " + args.transport),
+                       "baseline_config": args.config, "grid": [n, n], "bytes_per_lattice_update": B_ALG},
+            "health": health,
             "roofline": roof,
         }
         if copy_gbs is not None:
             line["copy_GBps"] = copy_gbs
             roof["frac_of_copy_on_this_device"] = round(achieved / max(copy_gbs.values()), 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 4:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=result_out, flush=True)
     if dist is not None:

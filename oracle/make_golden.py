@@ -467,9 +467,75 @@ def gen_o1_config1(m):
          u_col0=u[0].copy(), u_collast=u[-1].copy())
 
 
+# --------------------------------------------------------------------------
+#  move_periodic of the research forks (porous_media/single_component.cl:338-375), executed
+# --------------------------------------------------------------------------
+MOVE_PERIODIC_DRIVER = r'''
+#include <stddef.h>
+#include <math.h>
+static int g_gid[3], g_lid[3], g_lsz[3] = {32, 32, 1};
+#define cl_khr_fp64 1            /* the capability macro an fp64-capable OpenCL compiler predefines (the file #errors without) */
+#define __kernel
+#define __global
+#define __local
+#define __constant const
+#define __read_only
+#define __write_only
+#define CLK_LOCAL_MEM_FENCE 0
+static inline int get_global_id(int d)  { return g_gid[d]; }
+static inline int get_local_id(int d)   { return g_lid[d]; }
+static inline int get_local_size(int d) { return g_lsz[d]; }
+static inline void barrier(int flags)   { (void)flags; }
+#include "%(cl)s"
+
+static int pad32(int n) { return (n + 31) / 32 * 32; }
+static const int CXc[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
+static const int CYc[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+/* single_component.py:177-184: one launch per population over the padded 2-d NDRange (32 x 32 work-groups) */
+void k_move_periodic(double *f, double *fs, int nx, int ny, int cur_field, int num_populations, int num_jumpers)
+{
+    for (int y = 0; y < pad32(ny); ++y)
+        for (int x = 0; x < pad32(nx); ++x) {
+            g_gid[0] = x; g_gid[1] = y; g_gid[2] = 0;
+            g_lid[0] = x %% 32; g_lid[1] = y %% 32; g_lid[2] = 0;
+            move_periodic(f, fs, CXc, CYc, nx, ny, cur_field, num_populations, num_jumpers);
+        }
+}
+'''
+
+
+def gen_move_periodic(tmp):
+    """Execute the forks' `move_periodic` (porous_media/single_component.cl:338-375; host call single_component.py:177-184)
+    on small [jumper][population][y][x] arrays of distinct integer-valued doubles -- pure index arithmetic -- and store
+    input and output.  The product's populations module streams fp32 lattices; integers below 2^24 survive the cast."""
+    src = os.path.join(tmp, "move_periodic_driver.c")
+    with open(src, "w") as fh:
+        fh.write(MOVE_PERIODIC_DRIVER % {"cl": os.path.join(REF, "porous_media", "single_component.cl")})
+    so = os.path.join(tmp, "libmoveperiodic.so")
+    subprocess.check_call(["gcc", "-O1", "-std=gnu99", "-ffp-contract=off", "-fPIC", "-shared", "-w", src, "-o", so, "-lm"])
+    L = ct.CDLL(so)
+    dp = ct.POINTER(ct.c_double)
+    L.k_move_periodic.argtypes = [dp, dp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int]
+    out = {}
+    for tag, (nx, ny, P) in (("a", (32, 24, 2)), ("b", (37, 19, 2)), ("c", (5, 7, 1))):
+        rng = np.random.default_rng(nx * 100 + ny)
+        n = nx * ny * P * 9
+        # the forks' shape (nx, ny, num_populations, num_jumpers), Fortran order = the kernel's jump*P*nx*ny + field*nx*ny + y*nx + x
+        f = np.asfortranarray(rng.permutation(n).astype(np.float64).reshape((nx, ny, P, 9), order="F"))
+        fs = np.asfortranarray(np.full((nx, ny, P, 9), -1.0))
+        for field in range(P):
+            L.k_move_periodic(f.ctypes.data_as(dp), fs.ctypes.data_as(dp), nx, ny, field, P, 9)
+        assert fs.min() >= 0 and np.array_equal(np.sort(fs.ravel()), np.arange(n))     # a permutation: every entry written once
+        out["f_" + tag], out["streamed_" + tag] = f.astype(np.int32), fs.astype(np.int32)     # (integers: stored as such)
+    save("o2_move_periodic", **out)
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="lb_golden_", dir="/tmp")
     print("scratch dir", tmp)
+    if "--only-move-periodic" in sys.argv:
+        gen_move_periodic(tmp)
+        return
     if "--only-config1" in sys.argv:
         gen_o1_config1(build_o1(tmp))
         return
@@ -483,6 +549,7 @@ def main():
     gen_o2_d2q9i(build_o2(tmp, "D2Q9i.cl"))
     if "--only-d2q9i" in sys.argv:
         return
+    gen_move_periodic(tmp)
     m = build_o1(tmp)
     gen_o1(m)
     gen_o1_config1(m)

@@ -24,10 +24,20 @@ def test_shear_layer_shape_and_slab_consistency():
 
 def test_cpu_baseline_leg_reports_the_contract_keys():
     import bench
-    r = bench.cpu_baseline(budget_s=0.5, n=128, all_cores_budget_s=0.3)
-    assert set(r) == {"value", "unit", "cores", "kind", "sample", "all_cores"}
+    r = bench.cpu_baseline(budgets=((64, 0.2), (128, 0.4)), all_cores_budget_s=0.3)
+    assert set(r) == {"value", "unit", "cores", "kind", "sample", "sizes", "all_cores"}
     assert r["all_cores"]["cores"] >= 1 and r["all_cores"]["value"] > 0
     assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "MLUPS" and r["value"] > 0.1
+    assert "numpy2=True" in r["sample"]                                # the mode pinned bit-exact to the imported reference
+    assert [s["grid"] for s in r["sizes"]] == [[64, 64], [128, 128]] and r["value"] == r["sizes"][-1]["value"]
+
+
+def test_pmc_traffic_lookup_says_why_when_there_is_no_profile():
+    import bench
+    b, src = bench.load_pmc_traffic(8192, 4)
+    assert b and "committed profile" in src
+    b, src = bench.load_pmc_traffic("c9/123", 4)
+    assert b is None and "no --pmc profile" in src and "8192/4" in src
 
 
 def test_bench_refuses_to_run_without_a_gpu(lbhip):

@@ -294,3 +294,26 @@ def test_periodic_family_taylor_green_decay_rate(oracle):
         e.append(float((g["u"].astype(np.float64) ** 2 + g["v"].astype(np.float64) ** 2).mean()))
     rate = -np.polyfit(np.array(t, float), np.log(np.array(e)), 1)[0]
     assert rate == pytest.approx(4 * nu * k * k, rel=0.02)
+
+
+def test_periodic_streaming_is_the_forks_move_periodic(oracle):
+    """The oracle's periodic streaming ([BD] in d2q9_oracle.c: no counterpart in LB_D2Q9/dimensionless) against the one
+    periodic kernel the reference has, executed: porous_media/single_component.cl:338-375 `move_periodic`
+    (fixture o2_move_periodic, oracle/make_golden.py gen_move_periodic; integer-valued entries, exact).  Also pins the
+    `np.roll` restatement the GPU test uses at sizes the fixture does not hold."""
+    d = golden("o2_move_periodic")
+    cx = [0, 1, 0, -1, 0, 1, -1, -1, 1]
+    cy = [0, 0, 1, 0, -1, 1, 1, -1, -1]
+    for tag in "abc":
+        f, want = d["f_" + tag], d["streamed_" + tag]               # (nx, ny, P, 9)
+        nx, ny, P, J = f.shape
+        assert J == 9 and sorted(want.ravel()) == sorted(f.ravel())
+        rolled = np.empty_like(f)
+        for j in range(9):
+            rolled[:, :, :, j] = np.roll(np.roll(f[:, :, :, j], cx[j], axis=0), cy[j], axis=1)
+        assert np.array_equal(rolled, want)
+        for i in range(P):
+            o = oracle.O2Sim(nx, ny, 1.0, oracle.BC_PERIODIC)
+            o.set_f(f[:, :, i, :].astype(np.float32))
+            o.move()
+            assert np.array_equal(o.get_fields()["f"], want[:, :, i, :].astype(np.float32)), (tag, i)
