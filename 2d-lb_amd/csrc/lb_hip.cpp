@@ -298,12 +298,13 @@ template <int BC>
 void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows,
                      int nsegs, int row_end, bool macro, bool nts, int depth)
 {
-    const int waves = (depth == 4) ? STEP4_WAVES : 4;      // wave-items per workgroup
+    const int waves = (depth == 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4: the two directions of ONE item (a
+                                                           // segment pair); the others: four independent items
     // k_step4 gathers one row ahead where that fits in 256 registers without scratch: the instantiations without an obstacle
     // mask (+3 % periodic 8192^2, +-0 pipe; with a mask it spills 20-44 B per lane and loses 10 %: profiles/r02_experiments.txt).
     // Variant bit 10 switches it off (A/B runs).
     const bool pf = !s->has_mask && !(effective_variant(s) & 1024);
-    const dim3 block(64, waves), grid((items + waves - 1) / waves);
+    const dim3 block(64, waves), grid(depth == 4 ? items : (items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
         if (depth == 4 && pf) {                                                                                  \
@@ -337,7 +338,7 @@ void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int it
                       int row_end, bool macro, bool nts, int depth)
 {
     const int waves = (depth == 4) ? STEP4_WAVES : 4;
-    const dim3 block(64, waves), grid((items + waves - 1) / waves);
+    const dim3 block(64, waves), grid(depth == 4 ? items : (items + waves - 1) / waves);
 #define LB_LAUNCHV(MASK, MACRO, NTS)                                                                                      \
     do {                                                                                                                  \
         if (depth == 4)                                                                                                   \
@@ -415,15 +416,18 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         int waves_per_cu = s->tuned_wpc > 0 ? s->tuned_wpc : 8;
         static const int wpc_env = getenv("LB_STEP2_WAVES_PER_CU") ? atoi(getenv("LB_STEP2_WAVES_PER_CU")) : 0;   // tuning knob
         if (wpc_env > 0) waves_per_cu = wpc_env;
-        const int capacity = s->cu_count * waves_per_cu - reserve;
+        // (k_step4: an item is a PAIR of segments, marched by the two waves of a workgroup from its middle line: two
+        //  wave slots each; `capacity`, `segs`, `seg_rows` then count pairs)
+        const int per_item = (depth == 4) ? STEP4_WAVES : 1;
+        const int capacity = (s->cu_count * waves_per_cu - reserve) / per_item;
         const int rows = row_end - row_begin;
         segs = capacity / strips;
         if (segs < 1) segs = 1;
         seg_rows = (rows + segs - 1) / segs;
         // (floor: grids of 1024^2 .. 2048^2 are latency-bound, not bandwidth-bound -- filling every wave slot
-        //  with a short segment beats fewer, longer ones although each segment recomputes 2(d-1) rows: with the
-        //  earlier floor of 16 rows 2048^2 ran at 142 k MLUPS, with 4..8 at 170 k: profiles/r01_sweep_variants.txt)
-        if (seg_rows < 4) seg_rows = 4;
+        //  with a short segment beats fewer, longer ones although each segment recomputes (d-1) [k_step4] or 2(d-1) rows:
+        //  with the earlier floor of 16 rows 2048^2 ran at 142 k MLUPS, with 4..8 at 170 k: profiles/r01_sweep_variants.txt)
+        if (seg_rows < 4 * per_item) seg_rows = 4 * per_item;
         segs = (rows + seg_rows - 1) / seg_rows;
         a.seg_stride = seg_rows;
         // k_step4 in a box with walls at its left and right end: the two wall-column strips get shorter segments (their
@@ -436,7 +440,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
             const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
             const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
             const int rows_i = (rows + segs_i - 1) / segs_i, rows_e = (rows + segs_e - 1) / segs_e;
-            if (segs_i >= 1 && segs_e > segs_i && rows_e >= 8) {
+            if (segs_i >= 1 && segs_e > segs_i && rows_e >= 8 * per_item) {
                 seg_rows = rows_i;
                 segs = (rows + rows_i - 1) / rows_i;
                 a.seg_stride = rows_i;
@@ -889,7 +893,8 @@ int slab_cycle_first(lb_sim *s, int D, bool last = false)
     int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D, H - D, (probe.ghost_n && !last) ? H + D : H,
                           macro, D);
     if (rc) return rc;
-    if ((rc = launch_step2(s, s->stream, D, H - D, macro, 0, 0, 0, 2 * strips, D))) return rc;
+    // (wave slots left to the band launch running beside it: two bands x strips items, two waves each under k_step4)
+    if ((rc = launch_step2(s, s->stream, D, H - D, macro, 0, 0, 0, 2 * strips * (D == 4 ? STEP4_WAVES : 1), D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
@@ -903,7 +908,7 @@ int slab_cycle_second(lb_sim *s, bool macro, int D)
     int rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-    return launch_step2(s, s->stream, 2 * D, H - 2 * D, macro, 0, 0, 0, 2 * strips, D);
+    return launch_step2(s, s->stream, 2 * D, H - 2 * D, macro, 0, 0, 0, 2 * strips * (D == 4 ? STEP4_WAVES : 1), D);
 }
 
 // Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
@@ -1025,7 +1030,7 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
     }
     if (n_steps) {
         s->feq_valid = false;
-        s->macro_valid = store_macro;
+        s->macro_valid = store_macro || (s->diag & 4096);      // (LB_DIAG bit 12: the rho array carries the diagnostic build's per-wave timeline)
     }
     return LB_OK;
 }

@@ -16,30 +16,33 @@ if len(sys.argv) > 2:
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    ny = int(os.environ.get("LB_TIMELINE_NY", n))
     from LB_D2Q9.simulation import Simulation
     from bench import shear_layer
-    sim = Simulation(n, n, 1.7, bc=os.environ.get("LB_TIMELINE_BC", "periodic"), inlet_rho=1.0005)
+    # (the records travel in the rho array: no launch stores rho, u, v on this handle, and LB_DIAG bit 12 keeps lb_get_macro
+    #  from rebuilding them)
+    sim = Simulation(n, ny, 1.7, bc=os.environ.get("LB_TIMELINE_BC", "periodic"), inlet_rho=1.0005)
     sim.set_variant(353)
-    sim.init_equilibrium(*shear_layer(n, n, 0, n))
+    sim.init_equilibrium(*shear_layer(n, ny, 0, ny))
     sim.run(8)
-    sim.run(4)                                    # the launch whose timeline is read (no MACRO in the diag build's path: variant 353, 4 = one launch with MACRO though)
+    sim.run(4)                                    # the launch whose timeline is read
     raw = sim.get_fields(("rho",))["rho"]
     u = np.ascontiguousarray(raw.T).view(np.uint32).reshape(-1)          # device order: [y][x]
     # device rows are pitch floats long; host rows nx: with nx % 64 == 0 they coincide
     strips = (n + 255) // 256
     wpc = int(os.environ.get("LB_STEP2_WAVES_PER_CU", "8"))
-    cap = 256 * wpc
+    cap = 256 * wpc // 2                          # an item = a pair of segments = one workgroup of two waves (up / down)
     segs = max(cap // strips, 1)
-    seg_rows = max(-(-n // segs), 4)
-    segs = -(-n // seg_rows)
-    items = strips * segs
+    seg_rows = max(-(-ny // segs), 8)
+    segs = -(-ny // seg_rows)
+    items = 2 * strips * segs
     # (boxes with walls: the first / last strip march shorter segments, their extra items follow: read what is there)
-    items = min(items + 4 * segs, u.size // 8)
+    items = min(items + 8 * segs, u.size // 8)
     rec = u[:8 * items].reshape(items, 8).astype(np.int64)
     t0 = rec[:, 0] | (rec[:, 1] << 32)
     t1 = rec[:, 2] | (rec[:, 3] << 32)
     ok = (rec[:, 6] == np.arange(items)) & (t1 > t0)
-    print("items", items, "valid records", int(ok.sum()), "segments", segs, "rows per segment", seg_rows)
+    print("grid %d x %d: wave records %d, valid %d, pairs per strip %d, rows per pair %d" % (n, ny, items, int(ok.sum()), segs, seg_rows))
     t0, t1, rec = t0[ok], t1[ok], rec[ok]
     base = t0.min()
     start, end = (t0 - base) / 100.0, (t1 - base) / 100.0            # microseconds
@@ -57,11 +60,16 @@ def main():
     for sd in range(4):
         m = simd == sd
         if m.any():
-            print("SIMD %d: %4d waves, end median %.1f us; strip parity of its waves: %.2f odd" % (sd, m.sum(), np.median(end[m]), (rec[m, 6] % 2).mean()))
+            print("SIMD %d: %4d waves, end median %.1f us; share of upward waves: %.2f" % (sd, m.sum(), np.median(end[m]), (rec[m, 6] % 2).mean()))
     for ws in sorted(set(wave_slot.tolist())):
         m = wave_slot == ws
         print("wave slot %d: %4d waves, end median %.1f us" % (ws, m.sum(), np.median(end[m])))
-    it_id = rec[:, 6]
+    it_id = rec[:, 6] >> 1                                            # the pair; bit 0 = direction (0 down, 1 up)
+    for d, name in ((0, "down"), (1, "up")):
+        m = (rec[:, 6] & 1) == d
+        if m.any():
+            print("%-4s waves: start median %.1f us, end median %.1f us, duration median %.1f us" % (
+                name, np.median(start[m]), np.median(end[m]), np.median((end - start)[m])))
     nseg_main = int(os.environ.get("LB_TIMELINE_NSEGS", segs))       # segments of the interior strips (= segs unless walls)
     sx = np.where(it_id < strips * nseg_main, it_id % strips, np.where((it_id - strips * nseg_main) & 1, strips - 1, 0))
     sy = np.where(it_id < strips * nseg_main, it_id // strips, nseg_main + ((it_id - strips * nseg_main) >> 1))
