@@ -223,26 +223,19 @@ __global__ void k_hydro_vel(const PhaseArgs a)
 // magnitude faster than the reference's CPU loop.
 // x = i (0..lx), y = j (0..ly) in the .pyx's notation.
 
-// cython_dim.pyx:204-269 `move_bcs` (+ :468-513 obstacle swap), in place
-__global__ void k1_bcs(const PhaseArgs a)
+// cython_dim.pyx:204-269 `move_bcs` (+ :468-513 obstacle swap) of one cell; u_here = the stored u of this cell (inlet /
+// outlet columns: the value the previous update_hydro left there)
+__device__ __forceinline__ void c1_bcs_cell(const PhaseArgs &a, int x, int y, float u_here, bool solid, Cell &c)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
     const int lx = a.nx - 1, ly = a.ny - 1;
-    const long long o = (long long)y * a.pitch + x, S = a.plane, m = (long long)y * a.fpitch + x;
-    float *f = a.f + o;
-    const bool edge = (x == 0 || x == lx || y == 0 || y == ly);
-    const bool solid = a.mask && a.mask[m];
-    if (!edge && !solid) return;
-    Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
     if (x == 0 && y >= 1 && y < ly) {                         // inlet, stored u of the previous update_hydro
-        const float u0 = a.u[m], t = (1.f / 6.f) * u0 * a.rho_in;
+        const float u0 = u_here, t = (1.f / 6.f) * u0 * a.rho_in;
         const float f2 = c.f2, f4 = c.f4;
         c.f1 = c.f3 + (2.f / 3.f) * a.rho_in * u0;
         c.f5 = (-.5f * f2 + .5f * f4) + c.f7 + t;
         c.f8 = (.5f * f2 - .5f * f4) + c.f6 + t;
     } else if (x == lx && y >= 1 && y < ly) {                 // outlet
-        const float ul = a.u[m], t = (1.f / 6.f) * ul * a.rho_out;
+        const float ul = u_here, t = (1.f / 6.f) * ul * a.rho_out;
         const float f2 = c.f2, f4 = c.f4;
         c.f3 = c.f1 - (2.f / 3.f) * a.rho_out * ul;
         c.f6 = (-.5f * f2 + .5f * f4) + c.f8 - t;
@@ -265,6 +258,21 @@ __global__ void k1_bcs(const PhaseArgs a)
         c.f3 = c.f1; c.f4 = c.f2; c.f6 = t; c.f7 = c.f5; c.f8 = t;
     }
     bounce_cell(c, solid);
+}
+
+// ... as a phase of its own, in place
+__global__ void k1_bcs(const PhaseArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.nx) return;
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    const long long o = (long long)y * a.pitch + x, S = a.plane, m = (long long)y * a.fpitch + x;
+    float *f = a.f + o;
+    const bool edge = (x == 0 || x == lx || y == 0 || y == ly);
+    const bool solid = a.mask && a.mask[m];
+    if (!edge && !solid) return;
+    Cell c = {f[0], f[S], f[2 * S], f[3 * S], f[4 * S], f[5 * S], f[6 * S], f[7 * S], f[8 * S]};
+    c1_bcs_cell(a, x, y, (x == 0 || x == lx) ? a.u[m] : 0.f, solid, c);
     f[S] = c.f1; f[2 * S] = c.f2; f[3 * S] = c.f3; f[4 * S] = c.f4;
     f[5 * S] = c.f5; f[6 * S] = c.f6; f[7 * S] = c.f7; f[8 * S] = c.f8;
 }
@@ -355,6 +363,177 @@ __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
 #pragma unroll
     for (int k = 0; k < 9; ++k)
         a.fs[k * S + o] = fk[k] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
+}
+
+// The Cython path, one launch per time step, four cells per lane.  Its step is rule -> stream -> moments -> relax
+// (cython_dim.pyx:346-359); the rule of step n+1 only touches the cell's own populations (and, on the inlet / outlet
+// columns, the u that step n's moments produced for this very cell), so it rides at the END of step n's pass: restricted
+// pull from a lattice whose boundary cells have already been through the rule, moments with their overrides, equilibrium,
+// relaxation, then -- RULE -- next step's rule on the cells it concerns, then nine aligned 16-byte stores.  A run is
+// k1_bcs once (the first step's rule), n passes, the last one without RULE so that the populations it leaves are the
+// post-collision ones the reference holds after run().  Same expressions as k1_bcs + k1_move + k1_hydro + k_feq +
+// k_collide (c1_bcs_cell, c1_moments, feq_link): the same bits (test_cython_path_fused_run_equals_phase_calls).
+// Loads: the three links with cx = 0 aligned, the six others through 16-byte loads displaced by one element, as in
+// k_step; "a link outside its loop range keeps its value" becomes: rows 0 / ny-1 read their own row for the links that do
+// not move there (wave-uniform), and the single cells at x = 0 / x = nx-1 get their own value patched in.
+template <bool MASK, bool RULE, bool MACRO>
+__global__ __launch_bounds__(256) void k1_fstep(const PhaseArgs a)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);
+    if (x4 >= a.fpitch || y >= a.ny) return;
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    const long long S = a.plane, P = a.pitch;
+    const bool up = (y >= 1), dn = (y <= ly - 1);              // wave-uniform: links 1,2,5,6 move iff up, 3,4,7,8 iff dn
+    const float *r0 = a.f + (long long)y * P;                   // own row; rows the moving links come from:
+    const float *rm = up ? r0 - P : r0, *rp = dn ? r0 + P : r0;
+    const int su = up ? 1 : 0, sd = dn ? 1 : 0;                 // x displacement of the diagonal / horizontal links when they move
+    // the cells at x = 0 (links 1,5,4,8 stay) and x = lx (links 2,6,3,7 stay): their own values, fetched first
+    const bool first = (x4 == 0), last = (x4 <= lx && lx < x4 + 4);
+    const int jl = lx & 3;
+    float p1 = 0.f, p5 = 0.f, p4 = 0.f, p8 = 0.f, p2 = 0.f, p6 = 0.f, p3 = 0.f, p7 = 0.f;
+    if (first) { p1 = r0[1 * S]; p5 = r0[5 * S]; p4 = r0[4 * S]; p8 = r0[8 * S]; }
+    if (last) { p2 = r0[2 * S + lx]; p6 = r0[6 * S + lx]; p3 = r0[3 * S + lx]; p7 = r0[7 * S + lx]; }
+    f4a q[9];
+    q[0] = load4<false>(lane_ptr(r0, x4));
+    q[1] = load4u<false>(lane_ptr(r0 + 1 * S - su, x4));        // 1: from (x-1, y)     iff y >= 1 and x >= 1
+    q[5] = load4u<false>(lane_ptr(rm + 5 * S - su, x4));        // 5: from (x-1, y-1)
+    q[2] = load4<false>(lane_ptr(rm + 2 * S, x4));              // 2: from (x, y-1)     iff y >= 1 and x <= lx-1
+    q[6] = load4u<false>(lane_ptr(rm + 6 * S + su, x4));        // 6: from (x+1, y-1)
+    q[4] = load4<false>(lane_ptr(rp + 4 * S, x4));              // 4: from (x, y+1)     iff y <= ly-1 and x >= 1
+    q[8] = load4u<false>(lane_ptr(rp + 8 * S - sd, x4));        // 8: from (x-1, y+1)
+    q[3] = load4u<false>(lane_ptr(r0 + 3 * S + sd, x4));        // 3: from (x+1, y)     iff y <= ly-1 and x <= lx-1
+    q[7] = load4u<false>(lane_ptr(rp + 7 * S + sd, x4));        // 7: from (x+1, y+1)
+    uc4 mk = {0, 0, 0, 0};
+    if (MASK) mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)y * a.fpitch, x4));
+    if (first) { q[1].x = p1; q[5].x = p5; q[4].x = p4; q[8].x = p8; }
+    if (last) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j == jl) { q[2][j] = p2; q[6][j] = p6; q[3][j] = p3; q[7][j] = p7; }
+    }
+    f4a r4, u4, v4;
+    const bool wall_row = (y == 0 || y == ly);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = x4 + j;
+        const bool solid = MASK && mk[j] != 0;
+        float rho, ux, uy;
+        c1_moments(a, x, y, solid, q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j], rho, ux, uy);
+        r4[j] = rho; u4[j] = ux; v4[j] = uy;
+        const float usq = ux * ux + uy * uy;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q[k][j] = q[k][j] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
+        if (RULE && x <= lx && (wall_row || x == 0 || x == lx || solid)) {
+            Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+            c1_bcs_cell(a, x, y, ux, solid, c);                 // (ux: what this pass would store as u on the inlet / outlet columns)
+            q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
+            q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+        }
+    }
+    float *d = a.fs + (long long)y * P;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) store4<false>(lane_ptr(d + k * S, x4), q[k]);
+    if (MACRO) {
+        const long long m = (long long)y * a.fpitch;
+        store4<false>(lane_ptr(a.rho + m, x4), r4);
+        store4<false>(lane_ptr(a.u + m, x4), u4);
+        store4<false>(lane_ptr(a.v + m, x4), v4);
+    }
+}
+
+// The same four time steps at a time through LDS tiles (k_tile4's scheme, kernels_tile.h): a workgroup loads a 32 x 16
+// tile + 4 halo cells on every side of all nine planes into LDS once, advances it four Cython-path steps there -- after
+// step s the outermost s rings are stale and no longer computed -- and stores the tile.  A single-step pass of this path
+// moves 72 B per cell and sits at the streaming ceiling (79 k MLUPS on the reference's 3751 x 1251 case); four steps per
+// pass is the only way past it, and because this path's rule is cell-local and its pull is restricted at the box's
+// edges (no cell ever pulls from outside), the tile form needs no wall pass.  RULE_LAST: the fourth step is also followed
+// by the next step's boundary rule (false for the last launch of a run).  Same cell functions: same bits.
+template <bool MASK, bool MACRO, bool RULE_LAST>
+__global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS)) void k1_tile4(const PhaseArgs a, int tiles_x)
+{
+    typedef TileShape<32, 16, 2> T;
+    constexpr int L = T::LW, LH = T::LH, CELLS = T::CELLS, THREADS = T::THREADS, CPT = T::CPT;
+    __shared__ float lds[9][CELLS];
+    __shared__ unsigned char lmask[CELLS];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int gx0 = tx * 32 - TILE_T, gy0 = ty * 16 - TILE_T;        // global coordinates of region cell (0,0)
+    const int lx = a.nx - 1, ly = a.ny - 1;
+    const long long P = a.pitch, S = a.plane;
+    int gxs[CPT], gys[CPT], ring[CPT];
+    bool mine[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * THREADS;
+        const int cx = c % L, cy = c / L;
+        const int gx = gx0 + cx, gy = gy0 + cy;
+        // (cells outside the box are computed from copies of the nearest cells inside; nothing consumes them: a cell on
+        //  the box's edge keeps its own value for every link that would come from outside)
+        const int sx = min(max(gx, 0), lx), sy = min(max(gy, 0), ly);
+        gxs[i] = gx; gys[i] = gy;
+        ring[i] = c < CELLS ? min(min(cx, L - 1 - cx), min(cy, LH - 1 - cy)) : -1;
+        mine[i] = gx >= 0 && gx <= lx && gy >= 0 && gy <= ly;
+        if (c < CELLS) {
+            const long long o = (long long)sy * P + sx;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) lds[k][c] = a.f[k * S + o];
+            lmask[c] = (MASK && mine[i]) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s <= TILE_T; ++s) {
+        const bool last = (s == TILE_T);
+        float out[CPT][9], rr[CPT], uu[CPT], vv[CPT];
+        bool act[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * THREADS, x = gxs[i], y = gys[i];
+            act[i] = ring[i] >= s;
+            if (!act[i]) continue;
+            const bool up = (y >= 1), dn = (y <= ly - 1), le = (x >= 1), ri = (x <= lx - 1);      // cython_dim.pyx:271-299
+            const float f0 = lds[0][c];
+            const float f1 = lds[1][(up && le) ? c - 1 : c];
+            const float f5 = lds[5][(up && le) ? c - L - 1 : c];
+            const float f2 = lds[2][(up && ri) ? c - L : c];
+            const float f6 = lds[6][(up && ri) ? c - L + 1 : c];
+            const float f4 = lds[4][(dn && le) ? c + L : c];
+            const float f8 = lds[8][(dn && le) ? c + L - 1 : c];
+            const float f3 = lds[3][(dn && ri) ? c + 1 : c];
+            const float f7 = lds[7][(dn && ri) ? c + L + 1 : c];
+            const bool solid = MASK && lmask[c] != 0;
+            float rho, ux, uy;
+            c1_moments(a, x, y, solid, f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
+            const float usq = ux * ux + uy * uy;
+            const float fk[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out[i][k] = fk[k] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
+            rr[i] = rho; uu[i] = ux; vv[i] = uy;
+            if ((!last || RULE_LAST) && mine[i] && (x == 0 || x == lx || y == 0 || y == ly || solid)) {
+                Cell q = {out[i][0], out[i][1], out[i][2], out[i][3], out[i][4], out[i][5], out[i][6], out[i][7], out[i][8]};
+                c1_bcs_cell(a, x, y, ux, solid, q);
+                out[i][1] = q.f1; out[i][2] = q.f2; out[i][3] = q.f3; out[i][4] = q.f4;
+                out[i][5] = q.f5; out[i][6] = q.f6; out[i][7] = q.f7; out[i][8] = q.f8;
+            }
+            if (last && mine[i]) {                      // (the cells still computed in the fourth step are exactly the tile)
+                float *d = a.fs + (long long)y * P + x;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) d[k * S] = out[i][k];
+                if (MACRO) { const long long m = (long long)y * a.fpitch + x; a.rho[m] = rr[i]; a.u[m] = uu[i]; a.v[m] = vv[i]; }
+            }
+        }
+        if (last) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            if (act[i]) {
+                const int c = tid + i * THREADS;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) lds[k][c] = out[i][k];
+            }
+        __syncthreads();
+    }
 }
 
 // ---- macroscopic fields on demand + device-side health check ---------------------------------------------------

@@ -249,7 +249,7 @@ void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, b
 // profiles/r01_sweep_variants.txt):
 //   >= 1024^2 / 1280^2 cells on this GPU : temporal blocking -- three / four time steps per pass (marching
 //                                          kernels; nx >= 512 and enough rows, else they do not apply)
-//   lattice pair >= 1 GB (4096^2 up)     : + non-temporal stores (+3..6 %), and 4 rows x 256 cells per
+//   lattice pair >= 450 MB (3072^2 up)   : + non-temporal stores (+3..10 %), and 4 rows x 256 cells per
 //                                          workgroup wherever the single-step kernel runs (with contiguous
 //                                          planes 2 x 512 was the better shape; with interleaved rows 4 x 256
 //                                          streams 3..8 % faster at 4096^2 / 8192^2: profiles/r02_experiments.txt)
@@ -259,7 +259,11 @@ int effective_variant(const lb_sim *s)
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
-    int v = pair_bytes >= 1.0e9 ? ((s->p.flags & LB_FLAG_PLANAR) ? 9 : 1) : 16;
+    // non-temporal stores from ~450 MB per lattice pair, i.e. once the pair no longer fits the 256 MB Infinity Cache with room
+    // to spare (round 3, k_step4, plain vs non-temporal: 311 MB 235.8 / 235.5 k MLUPS, 302 MB 232 / 227 k, 604 MB 241 / 265 k,
+    // 613 MB 247 / 273 k -- the slab of one of eight GPUs at 8192^2 --, 680 MB 255 / 257 k, 1.2 GB 278 / 294 k:
+    // profiles/r03_experiments.txt; the threshold was 1 GB)
+    int v = pair_bytes >= 4.5e8 ? ((s->p.flags & LB_FLAG_PLANAR) ? 9 : 1) : 16;
     // from 1024^2 cells: three steps per pass (110 k MLUPS at 1024^2 against 87 k single-step); from 1280^2:
     // four (125 k at 1280^2, 158 k at 1536^2, 170 k at 2048^2, 220 k from 3072^2), whole grids and slabs alike,
     // in every boundary family, with and without obstacles (profiles/r01_sweep_variants.txt,
@@ -1148,6 +1152,10 @@ int corners_patch(lb_sim *s, int which)
 // steps a quick (one-round) tuning pass consumes at most: 10 candidates x 2 samples x 12 (36) steps + 1
 int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 : 12) + 1; }
 
+// the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
+// explicit variant without bit 9 asks for single steps (k1_fstep)
+bool cython_tiles(const lb_sim *s) { return s->p.nx >= 64 && s->H >= 64 && (s->variant < 0 || (s->variant & 512)); }
+
 bool autotune_applies(const lb_sim *s)
 {
     return !s->multi_slab() && s->p.semantics != LB_SEM_CYTHON &&
@@ -1697,14 +1705,46 @@ int lb_run(lb_sim *s, int n_steps)
     DeviceGuard guard(s->p.device);
     int rc;
     if (s->p.semantics == LB_SEM_CYTHON) {
-        // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles -- the boundary phase
-        // in place (k1_bcs), the other four fused into one pass from the current lattice into the other (k1_step);
-        // bitwise equal to the five phase calls (test_cython_path_fused_run_equals_phase_calls)
-        for (int it = 0; it < n_steps; ++it) {
+        // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles.  The boundary phase of the
+        // FIRST step in place (k1_bcs); then one pass per step (k1_fstep: restricted pull, moments with their overrides,
+        // equilibrium, relaxation and -- all but the last -- the NEXT step's boundary rule on the cells it concerns, which
+        // only needs what the pass has in registers); bitwise equal to the five phase calls per step
+        // (test_cython_path_fused_run_equals_phase_calls)
+        if (n_steps > 0) {
             hipLaunchKernelGGL(k1_bcs, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
             HIP_TRY(hipGetLastError());
-            if (it == n_steps - 1) hipLaunchKernelGGL(k1_step<true>, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
-            else hipLaunchKernelGGL(k1_step<false>, cells_grid(s, 1), dim3(256), 0, s->stream, phase_args(s));
+        }
+        // n = 4a + rem: the remainder first, step by step (k1_fstep: four cells per lane, 16-byte accesses, at the streaming
+        // ceiling of a pass that moves 72 B per cell), then a launches of four steps each through LDS tiles (k1_tile4);
+        // grids too small for tiles, or LB_VARIANT / lb_set_variant bit 9 clear with an explicit variant: single steps only
+        const dim3 blk(64, 4), grd((unsigned)((s->pitch / 4 + 63) / 64), (unsigned)((s->H + 3) / 4));
+        const bool tiles = cython_tiles(s);
+        int left = n_steps;
+        while (left > 0) {
+            const PhaseArgs a = phase_args(s);
+            if (tiles && left % TILE_T == 0) {
+                const int tiles_x = (s->p.nx + 31) / 32, tiles_y = (s->H + 15) / 16;
+                const dim3 tg(tiles_x * tiles_y), tb(TileShape<32, 16, 2>::THREADS);
+                const bool lastp = (left == TILE_T);
+#define LB_LAUNCH1T(MASK)                                                                                         \
+                do {                                                                                              \
+                    if (lastp) hipLaunchKernelGGL((k1_tile4<MASK, true, false>), tg, tb, 0, s->stream, a, tiles_x); \
+                    else hipLaunchKernelGGL((k1_tile4<MASK, false, true>), tg, tb, 0, s->stream, a, tiles_x);       \
+                } while (0)
+                if (s->has_mask) LB_LAUNCH1T(true); else LB_LAUNCH1T(false);
+#undef LB_LAUNCH1T
+                left -= TILE_T;
+            } else {
+                const bool lastp = (left == 1);
+                if (s->has_mask) {
+                    if (lastp) hipLaunchKernelGGL((k1_fstep<true, false, true>), grd, blk, 0, s->stream, a);
+                    else hipLaunchKernelGGL((k1_fstep<true, true, false>), grd, blk, 0, s->stream, a);
+                } else {
+                    if (lastp) hipLaunchKernelGGL((k1_fstep<false, false, true>), grd, blk, 0, s->stream, a);
+                    else hipLaunchKernelGGL((k1_fstep<false, true, false>), grd, blk, 0, s->stream, a);
+                }
+                left -= 1;
+            }
             HIP_TRY(hipGetLastError());
             s->cur ^= 1;
         }
@@ -2135,6 +2175,7 @@ int lb_steps_per_launch(lb_sim *s)
 {
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int n = 1;
+    if (s->p.semantics == LB_SEM_CYTHON) return cython_tiles(s) ? TILE_T : 1;
     if (!s->multi_slab()) {
         const int depths = whole_grid_depths(s);
         for (int d = 2; d <= 4; ++d)
@@ -2172,7 +2213,8 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     if (!s || !buf || buflen < 1) return fail(LB_ERR_ARG, "bad argument");
     static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET", "PIPE, D2Q9i"};
     const char *kernel = "k_step";
-    if (s->p.semantics == LB_SEM_CYTHON) kernel = "k1_bcs + k1_step";
+    if (s->p.semantics == LB_SEM_CYTHON)
+        kernel = cython_tiles(s) ? "k1_tile4 (Cython path, LDS tiles)" : "k1_fstep (Cython path)";
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";

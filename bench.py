@@ -278,7 +278,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one node: bootstrap over the loopback interface
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # rendezvous on this node: bootstrap over the loopback interface
+                                                                # (a multi-node launch names a routable MASTER_ADDR and keeps RCCL's choice)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from LB_D2Q9.simulation import Simulation

@@ -13,7 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # Single-node runs: RCCL's bootstrap sockets on the loopback interface (the container's other interfaces / hostname are
 # not always usable: "use 127.0.0.1 for any rendezvous").
-os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 
 def pytest_configure(config):

@@ -98,27 +98,38 @@ def test_cython_semantics_restrictions(lbhip):
 
 
 def test_cython_path_fused_run_equals_phase_calls(lbhip):
-    """run(n) on the Cython-path classes = boundary phase + ONE fused pass (restricted pull, moments, equilibrium,
-    relaxation) per step; it must equal the five phase calls of the reference's loop (cython_dim.pyx:346-359) bit
+    """run(n) on the Cython-path classes = the first step's boundary phase + ONE fused pass per step (restricted pull,
+    moments, equilibrium, relaxation, the next step's boundary rule; four cells per lane); it must equal the five phase calls of the reference's loop (cython_dim.pyx:346-359) bit
     for bit, with and without an obstacle, on sizes that are not multiples of the launch shape."""
     from LB_D2Q9.dimensionless import cython_dim as lb
-    for cls, extra in ((lb.Pipe_Flow, {}), (lb.Pipe_Flow_Cylinder, dict(cylinder_center=[.6, .5], cylinder_radius=.12))):
+    # (N = 37: 101 x 38 cells, too small for LDS tiles -> single-step passes k1_fstep only; the other two: four steps per
+    #  launch through k1_tile4 + single steps for the remainder of a run)
+    for cls, extra in ((lb.Pipe_Flow, {}), (lb.Pipe_Flow, dict(N=150)),
+                       (lb.Pipe_Flow_Cylinder, dict(N=90, cylinder_center=[.6, .5], cylinder_radius=.12))):
         kw = dict(diameter=1., rho=1., viscosity=.2, pressure_grad=-1.5, pipe_length=2.7, N=37, time_prefactor=.2,
                   verbose=False)
-        if extra:
-            kw.update(N=90)                          # N counts lattice points per cylinder radius there
-        kw.update(extra)
+        kw.update(extra)                             # (N counts lattice points per cylinder radius in the cylinder class)
         np.random.seed(3)
         a = cls(**kw)
+        assert ("k1_tile4" in a._sim.hot_kernel()) == bool(extra) and a._sim.steps_per_launch() == (4 if extra else 1)
         f0 = a.get_fields()["f"]
         b = cls(**kw)
         b.set_f(f0)
         g0 = a.get_fields()
         b.set_fields(g0["rho"], g0["u"], g0["v"])
-        a.run(23)
-        for _ in range(23):
+        a.run(1); a.run(10); a.run(12)              # (every run starts with the boundary phase as a launch of its own and ends
+        for _ in range(23):                          #  with a pass that leaves the post-collision populations alone)
             b.move_bcs(); b.move(); b.update_hydro(); b.update_feq(); b.collide_particles()
         ga, gb = a.get_fields(), b.get_fields()
         for k in ("f", "rho", "u", "v", "feq"):
-            assert np.array_equal(ga[k], gb[k]), (cls.__name__, k)
+            assert np.array_equal(ga[k], gb[k]), (cls.__name__, kw["N"], k)
         assert np.all(np.isfinite(ga["f"]))
+        # single steps only (explicit variant without the tile bit): the same bits again
+        c = cls(**kw)
+        c._sim.set_variant(0)
+        c.set_f(f0)
+        c.set_fields(g0["rho"], g0["u"], g0["v"])
+        c.run(23)
+        gc = c.get_fields()
+        for k in ("f", "rho", "u", "v"):
+            assert np.array_equal(ga[k], gc[k]), (cls.__name__, kw["N"], "single steps", k)

@@ -26,6 +26,9 @@ def _env():
     return env
 
 
+# (the subprocess timeouts stay below the pytest timeout of these tests, so that a hung multi-rank run is reaped by
+#  subprocess.run -- which kills its child -- before pytest's thread-method timeout ends the whole session)
+@pytest.mark.timeout(2400, method="thread")
 def test_slabs_over_rccl_equal_the_undivided_run_bitwise(lbhip):
     """tools/multi_gpu_check.py under torch.distributed.run: automatic kernel choice (eight-step halo cycle on
     k_step4) and every explicit schedule x three boundary families x obstacle mask, each rank against the
@@ -43,6 +46,7 @@ def test_slabs_over_rccl_equal_the_undivided_run_bitwise(lbhip):
     assert "= False" not in p.stdout
 
 
+@pytest.mark.timeout(1800, method="thread")
 def test_bench_spawns_its_own_ranks(lbhip):
     """`python bench.py --gpus N` as the driver calls it (no launcher): one JSON line, n_gpus = N, RCCL transport."""
     n = _gpus(lbhip)

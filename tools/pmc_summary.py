@@ -55,6 +55,7 @@ def main():
             if r["Counter_Name"] == cname:
                 pmc.setdefault((short(r["Kernel_Name"]), cname), []).append(float(r["Counter_Value"]))
 
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     lines = ["# rocprofv3 summary %s (grid %dx%d)" % (tag, side, side), "",
              "Command: `tools/gpu_profile.sh` = `rocprofv3 --kernel-trace --stats` and two `--pmc` passes "
              "(FETCH_SIZE, WRITE_SIZE) around `bench.py --steps 20 --warmup 5 --calibrate 5`.", "",
@@ -63,6 +64,14 @@ def main():
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         lines.append("| %s | %d | %.1f | %.1f | %.1f | %s | %s | %s | %s |" % (
             k, len(v), st.mean(v) / 1e3, min(v) / 1e3, max(v) / 1e3, *vg[k.split(" [")[0]]))
+
+    # the same table as CSV, one row per kernel AND launch geometry (rocprofv3's own --stats file merges the geometries
+    # lb_autotune samples into one average: 929 us where the timed region's launches take 870)
+    with open(os.path.join(ROOT, "profiles", "%s_kernel_stats_by_geometry.csv" % tag), "w") as fh:
+        fh.write("kernel,grid_size_x,calls,avg_us,min_us,max_us,total_us\n")
+        for k, geos in sorted(by_geo.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
+            for g, v in sorted(geos.items(), key=lambda gv: -len(gv[1])):
+                fh.write('"%s",%s,%d,%.1f,%.1f,%.1f,%.1f\n' % (k, g, len(v), st.mean(v) / 1e3, min(v) / 1e3, max(v) / 1e3, sum(v) / 1e3))
 
     # the bench line of the same (kernel-trace) run: its HIP-event launch time must agree with the table
     try:
@@ -102,7 +111,6 @@ def main():
             out["%d/%d" % (side, spl)] = {"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
                    "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
                    "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     # rocprofv3's own --stats table of the SAME kernel-trace run, verbatim (never left over from another run)
     stats = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:

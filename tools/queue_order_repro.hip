@@ -2,7 +2,8 @@
 // processes share the GPU?  Stand-alone (no liblbhip): the question behind lb_run_group's rare mismatches under
 // contention, reduced to its pattern.
 //
-// NB buffers, NS streams (the first NHI created with the device's highest priority when `prio` = 1).  Every operation
+// NB buffers, NS streams (argument 5, default 12: more than the runtime's hardware queues, as lb_run_group's three streams
+// per member are; the first NS / 3 created with the device's highest priority when `prio` = 1).  Every operation
 // picks a stream, a destination buffer and two source buffers at random, makes its stream wait for the event of the LAST
 // ACCESS of each of the three (read or write: every buffer sees a total order of accesses, enforced by events only),
 // launches one kernel -- it checks that both sources hold the value their last writer stored and then overwrites the
@@ -29,10 +30,12 @@ int main(int argc, char **argv)
 {
     const int ops = argc > 1 ? atoi(argv[1]) : 20000, seed = argc > 2 ? atoi(argv[2]) : 1, prio = argc > 3 ? atoi(argv[3]) : 1;
     const int sync_every = argc > 4 ? atoi(argv[4]) : 0;          // > 0: hipDeviceSynchronize every so many operations
-    constexpr int NB = 6, NS = 4, NHI = 2, N = 1 << 18;
+    constexpr int NB = 8, NSMAX = 16, N = 1 << 18;
+    const int NS = argc > 5 ? atoi(argv[5]) : 12, NHI = NS / 3;       // streams (lb_run_group: three per member, one of them high priority)
     int lo = 0, hi = 0, *buf[NB], val[NB] = {0};
     unsigned *bad, host_bad = 0;
-    hipStream_t st[NS];
+    hipStream_t st[NSMAX];
+    if (NS < 1 || NS > NSMAX) return 2;
     hipEvent_t ev[NB];
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     for (int s = 0; s < NS; ++s) CK(hipStreamCreateWithPriority(&st[s], hipStreamNonBlocking, (prio && s < NHI) ? hi : lo));
@@ -61,7 +64,7 @@ int main(int argc, char **argv)
     }
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(&host_bad, bad, sizeof(unsigned), hipMemcpyDeviceToHost));
-    printf("queue_order_repro: ops %d seed %d priorities %s sync_every %d -> %u out-of-order element reads\n", ops, seed,
-           prio ? "on" : "off", sync_every, host_bad);
+    printf("queue_order_repro: ops %d seed %d streams %d (%d high priority: %s) sync_every %d -> %u out-of-order element reads\n",
+           ops, seed, NS, NHI, prio ? "on" : "off", sync_every, host_bad);
     return host_bad ? 1 : 0;
 }
