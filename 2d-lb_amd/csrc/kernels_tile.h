@@ -116,12 +116,17 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         q.f6 = lds[6][c - TILE_L + 1];
         q.f7 = lds[7][c + TILE_L + 1];
         q.f8 = lds[8][c + TILE_L - 1];
-        if (decltype(wall)::value) {
-            const bool w = (gx == 0), e = (gx == a.nx - 1), so = (gy == 0), no = (gy == a.ny - 1);
-            boundary_rule<BC>(a, q, w, e, so, no);
+        float rho = 0.f, ux = 0.f, uy = 0.f;
+#ifdef LB_DIAG
+        if (!(a.diag & 1))                              // timing only: data movement and barriers alone (tools/ablate.py --tile)
+#endif
+        {
+            if (decltype(wall)::value) {
+                const bool w = (gx == 0), e = (gx == a.nx - 1), so = (gy == 0), no = (gy == a.ny - 1);
+                boundary_rule<BC>(a, q, w, e, so, no);
+            }
+            finish_cell<BC, MASK>(a, gx, gy - a.y0, q, MASK && lmask[c] != 0, rho, ux, uy);
         }
-        float rho, ux, uy;
-        finish_cell<BC, MASK>(a, gx, gy - a.y0, q, MASK && lmask[c] != 0, rho, ux, uy);
         if (last && mine) {
             const long long o = (long long)gy * P + gx;
             float *d = a.dst + o;
@@ -137,6 +142,9 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
 
 #pragma unroll 1
     for (int s = 1; s <= TILE_T; ++s) {
+#ifdef LB_DIAG
+        if ((a.diag & 2) && s < TILE_T) continue;       // timing only: load, ONE step, store (what the three steps in LDS cost)
+#endif
         const bool last = (s == TILE_T);
         Cell cs[TILE_CPT], wq;
         bool act[TILE_CPT], wact = false;
@@ -159,6 +167,85 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         for (int i = 0; i < TILE_CPT; ++i)
             if (act[i]) cell_put(tid + i * TILE_THREADS, cs[i]);
         if (wact) cell_put(wc, wq);
+        __syncthreads();
+    }
+}
+
+// ---- the velocity-inlet family's wall-row bands, D time steps in one launch ---------------------------------------
+// A three- or four-step marching pass of that family covers rows [D, ny-D); the 2D rows next to each wall, stacked, are a
+// velocity-inlet lattice of 4D rows of their own (lb_hip.cpp vel_band_pass: the north row's pull reaches "row ny-2" = band
+// row 4D-2, the south row's "row 1" = band row 1; the seam in the middle spreads one row of garbage per step and reaches
+// exactly the rows that are not kept).  Round 2 copied them into a second handle, ran D single steps there and copied
+// the outer rows back: a dozen dependent launches.  Here one workgroup holds a column chunk of the band -- TW columns + D
+// halo columns on either side, all 4D rows, nine planes -- in LDS, advances it D steps (after step s the outermost s
+// columns are stale and no longer computed; rows wrap onto each other inside the band, so there is no halo in y) and
+// stores the outer D + D rows.  Same cell functions as k_step on the band handle: same bits.
+// band row j <-> grid row j (j < 2D) or ny - 4D + j (j >= 2D)
+template <bool MASK, bool MACRO, int D>
+__global__ __launch_bounds__(256) void k_vel_band(const StepArgs a)
+{
+    constexpr int HB = 4 * D, LW = 64, TW = LW - 2 * D, CELLS = LW * HB, CPT = CELLS / 256;
+    static_assert(CELLS % 256 == 0, "region cells per thread");
+    __shared__ float lds[9][CELLS];
+    __shared__ unsigned char lmask[CELLS];
+    const int tid = threadIdx.x;
+    const int gx0 = blockIdx.x * TW - D;                        // grid column of region column 0
+    const long long P = a.pitch, S = a.plane;
+    auto grid_row = [&](int j) { return j < 2 * D ? j : a.ny - HB + j; };
+    int cxs[CPT], cys[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * 256;
+        const int cx = c % LW, cy = c / LW;
+        cxs[i] = cx; cys[i] = cy;
+        // (columns outside the box: copies of the nearest one inside; the rule overwrites every link pulled from them)
+        const int sx = min(max(gx0 + cx, 0), a.nx - 1);
+        const long long o = (long long)grid_row(cy) * P + sx;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
+        lmask[c] = (MASK && sx == gx0 + cx) ? a.mask[(long long)grid_row(cy) * a.fpitch + sx] : 0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s <= D; ++s) {
+        const bool last = (s == D);
+        Cell out[CPT];
+        bool act[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256, cx = cxs[i], cy = cys[i], x = gx0 + cx;
+            act[i] = cx >= s && cx < LW - s;
+            if (!act[i]) continue;
+            // rows the cy = +1 / cy = -1 links come from: the band is a velocity-inlet lattice of HB rows (wrap_y == 2)
+            const int rm = (cy == 0 ? HB - 2 : cy - 1) * LW + cx, r0 = c, rp = (cy == HB - 1 ? 1 : cy + 1) * LW + cx;
+            Cell q = {lds[0][r0], lds[1][r0 - 1], lds[2][rm], lds[3][r0 + 1], lds[4][rp], lds[5][rm - 1], lds[6][rm + 1],
+                      lds[7][rp + 1], lds[8][rp - 1]};
+            const bool in_box = x >= 0 && x < a.nx;
+            const bool w = (x == 0), e = (x == a.nx - 1), so = (cy == 0), no = (cy == HB - 1);
+            if (w || e) bc_vel_cell(q, w, e, so, no, a.u_w, a.u_e, a.corner);
+            if (MASK) bounce_cell(q, lmask[c] != 0);
+            float rho, ux, uy;
+            moments_cell(q, rho, ux, uy);
+            const long long m = (long long)grid_row(cy) * a.fpitch + (in_box ? x : 0);
+            if (w || e) vel_moments_cell(q, w, so, no, a.u_w, a.u_e, a.u[m], a.v[m], rho, ux, uy);
+            equilibrate_cell(q, a.omega, rho, ux, uy);
+            out[i] = q;
+            if (last && in_box && cx >= D && cx < LW - D && (cy < D || cy >= 3 * D)) {
+                float *d = a.dst + (long long)grid_row(cy) * P + x;
+                d[0] = q.f0; d[S] = q.f1; d[2 * S] = q.f2; d[3 * S] = q.f3; d[4 * S] = q.f4;
+                d[5 * S] = q.f5; d[6 * S] = q.f6; d[7 * S] = q.f7; d[8 * S] = q.f8;
+                if (MACRO) { a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy; }
+            }
+        }
+        if (last) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            if (act[i]) {
+                const int c = tid + i * 256;
+                lds[0][c] = out[i].f0; lds[1][c] = out[i].f1; lds[2][c] = out[i].f2; lds[3][c] = out[i].f3; lds[4][c] = out[i].f4;
+                lds[5][c] = out[i].f5; lds[6][c] = out[i].f6; lds[7][c] = out[i].f7; lds[8][c] = out[i].f8;
+            }
         __syncthreads();
     }
 }

@@ -140,7 +140,6 @@ struct lb_sim {
     float *rho = nullptr, *u = nullptr, *v = nullptr;
     float *stage = nullptr;     // [H][pitch], lazily: one plane on its way between the host and interleaved rows (lattice_plane_*)
     float *vi_corner = nullptr; // VELOCITY_INLET: the eight corner links nothing ever writes (bc_vel_cell), device
-    lb_sim *band[2] = {nullptr, nullptr};   // VELOCITY_INLET: the wall-row bands of a three- / four-step pass (vel_band_pass)
     uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
     bool has_mask = false;
     int cu_count = 256;
@@ -928,7 +927,11 @@ bool use_tile_kernel(const lb_sim *s)
     if (s->tuned_steps) return s->tuned_wpc < 0;
     // (walled boxes likewise: pipe 24 / 74 / 112 / 123 k at 256^2 / 512^2 / 1024^2 / 1280^2 against 16.5 / 55 / 95 / 113 k;
     //  marching from 1536^2: 136 against 130 k)
-    return (double)s->p.nx * s->H < 1600.0 * 1600.0 || !step4_applicable(s);
+    // (round 3: the four-step marching kernel on segment pairs, against the tiles: periodic 1024^2 124 / 153 k MLUPS, 1280^2
+    //  173 / 169 k, 1536^2 216 / 179 k, 2048^2 248 / 187 k; cavity 1024^2 99 / 148 k, 1280^2 146 / 166 k, 1536^2 180 / 176 k,
+    //  2048^2 217 / 183 k: profiles/r03_experiments.txt; the change-over was at 1600^2)
+    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1250.0 : 1450.0;
+    return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 
 int whole_grid_depths(const lb_sim *s)
@@ -944,60 +947,31 @@ int whole_grid_depths(const lb_sim *s)
 // A d-step pass (d = 3, 4) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
 // the marching kernel takes them, treating the wall rows as don't-care like any wall.  The 2d wall-side rows are advanced
 // as a lattice of their own: the 2d rows next to each wall, stacked, ARE a velocity-inlet lattice of 4d rows -- row 0's pull
-// reaches "row ny-2" = local row 4d-2, row ny-1's "row 1" = local row 1 -- except at the seam in the middle, whose garbage
-// travels one row per step and after d steps has reached exactly the rows that are not needed.  So: copy the bands into a
-// 4d-row handle, d single steps there, copy its outer d + d rows (and their rho,u,v on a MACRO pass) into place.
+// reaches "row ny-2" = band row 4d-2, row ny-1's "row 1" = band row 1 -- except at the seam in the middle, whose garbage
+// travels one row per step and after d steps has reached exactly the rows that are not needed.  One launch (k_vel_band:
+// column chunks of the band in LDS, d steps there, the outer d + d rows stored) on the edge stream beside the interior's:
+// both only read the current lattice and write disjoint rows of the other one.  (Round 2: the bands were copied into a
+// second handle, stepped d times there and copied back -- a chain of a dozen small launches.)
 int vel_band_pass(lb_sim *s, int d, bool macro)
 {
     int rc;
-    const int H = s->H, hb = 4 * d;
-    lb_sim *&b = s->band[d - 3];
-    if (!b) {
-        lb_params p = s->p;
-        p.ny = p.local_ny = hb;
-        p.y0 = 0;
-        if ((rc = lb_create(&p, &b))) return rc;
-        b->variant = 16;                        // single-step kernel, plain stores (the band lives in the caches)
-    }
-    // The band chain (copy in, d small steps, copy out: ~10 tiny dependent launches) runs on the edge stream, beside the
-    // interior launch on the compute stream: both only read the current lattice and write disjoint rows of the other one.
+    const int H = s->H;
     const hipStream_t q = s->edge_stream;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));          // everything enqueued so far (the previous pass included)
     HIP_TRY(hipStreamWaitEvent(q, s->ev_interior, 0));
-    b->stream = q;
-    b->has_mask = s->has_mask;
-    b->cur = 0;
-    const dim3 blk(256), grid((unsigned)((s->pitch / 4 + 255) / 256), (unsigned)hb, 9);
-    // bands of the current lattice, of the stored u, v (the inlet / outlet columns read them) and of the mask -> band handle
-    hipLaunchKernelGGL(k_rows_copy, grid, blk, 0, q, (const float *)s->origin(s->cur), b->origin(0), s->plane, b->plane,
-                       (int)s->pitch, s->rowp, b->rowp, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
-    const dim3 grid1(grid.x, grid.y, 1);
-    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->u, b->u, 0LL, 0LL, (int)s->pitch, s->pitch, s->pitch,
-                       2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
-    hipLaunchKernelGGL(k_rows_copy, grid1, blk, 0, q, (const float *)s->v, b->v, 0LL, 0LL, (int)s->pitch, s->pitch, s->pitch,
-                       2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
-    if (s->has_mask)       // (rows of pitch bytes = pitch / 4 floats)
-        hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)((s->pitch / 16 + 255) / 256), (unsigned)hb, 1), blk, 0, q,
-                           reinterpret_cast<const float *>(s->mask), reinterpret_cast<float *>(b->mask), 0LL, 0LL,
-                           (int)(s->pitch / 4), s->pitch / 4, s->pitch / 4, 2 * d, 0, 0, 2 * d, H - 2 * d, 2 * d);
-    HIP_TRY(hipMemcpyAsync(b->vi_corner, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToDevice, q));
+    const StepArgs a = step_args(s, 0, 1, H);
+    const dim3 grid((unsigned)((s->p.nx + (64 - 2 * d) - 1) / (64 - 2 * d))), blk(256);
+#define LB_LAUNCHB(MASK, MACRO)                                                                          \
+    do {                                                                                                 \
+        if (d == 4) hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 4>), grid, blk, 0, q, a);                \
+        else hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 3>), grid, blk, 0, q, a);                       \
+    } while (0)
+    if (s->has_mask) { if (macro) LB_LAUNCHB(true, true); else LB_LAUNCHB(true, false); }
+    else             { if (macro) LB_LAUNCHB(false, true); else LB_LAUNCHB(false, false); }
+#undef LB_LAUNCHB
     HIP_TRY(hipGetLastError());
     // the interior, from the same source lattice, on the compute stream
     if ((rc = launch_step2(s, s->stream, d, H - d, macro, 0, 0, 0, 0, d))) return rc;
-    for (int i = 0; i < d; ++i) {
-        if ((rc = launch_step(b, 0, 1, hb, macro && i == d - 1))) return rc;
-        b->cur ^= 1;
-    }
-    // the band handle's outer rows -> the lattice being written
-    hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 9), blk, 0, q, (const float *)b->origin(b->cur),
-                       s->origin(s->cur ^ 1), b->plane, s->plane, (int)s->pitch, b->rowp, s->rowp, d, 0, 0, d, 3 * d, H - d);
-    if (macro) {
-        float *const from[3] = {b->rho, b->u, b->v}, *const to[3] = {s->rho, s->u, s->v};
-        for (int i = 0; i < 3; ++i)
-            hipLaunchKernelGGL(k_rows_copy, dim3(grid.x, (unsigned)(2 * d), 1), blk, 0, q, (const float *)from[i], to[i], 0LL,
-                               0LL, (int)s->pitch, s->pitch, s->pitch, d, 0, 0, d, 3 * d, H - d);
-    }
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_boundary, q));
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));   // the next pass (or the caller) sees the bands in place
     return LB_OK;
@@ -1288,9 +1262,6 @@ int lb_destroy(lb_sim *s)
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     drop_graph(s);
-    for (lb_sim *&b : s->band) {
-        if (b) { b->stream = b->own_stream; lb_destroy(b); b = nullptr; }
-    }
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner, s->stage})
         if (p) (void)hipFree(p);

@@ -153,11 +153,13 @@ int lb_init_pop(lb_sim *s);             /* f = f_streamed = feq (device side of 
 
 /* ---- the hot path: n time steps (replaces the body of Pipe_Flow.run, opencl_dim.py:372-387:
  *      move -> move_bcs(+obstacle) -> update_hydro -> update_feq -> collide_particles, 6-8 launches and
- *      as many host waits per step) by fused launches that advance one, two or three time steps each
- *      (k_step, k_step2, k_step3, k_step4; results bitwise independent of which) and no host wait.
- *      rho,u,v of the LAST step are stored (they are only observable through get_fields); feq is
- *      rebuilt from them on demand.  Handles with
- *      LB_SEM_CYTHON run their boundary phase + one fused pass per step.
+ *      as many host waits per step) by fused launches that advance one to four time steps each
+ *      (k_step, k_step2, k_step3, k_step4, k_tile4; results bitwise independent of which) and no host wait.
+ *      rho,u,v are those of the LAST step: rebuilt on demand from the populations it left in the plain
+ *      families (see LB_FLAG_EAGER_MACRO), stored by the last launch in the others; feq is rebuilt from them on
+ *      demand.  Handles with LB_SEM_CYTHON run the first step's boundary phase as a launch of its own, then one
+ *      pass per step (k1_fstep) or per four steps (k1_tile4, LDS tiles), each pass ending with the next step's
+ *      boundary rule.
  *      Multi-slab handles exchange their halo rows inside lb_run when a communicator is attached
  *      (lb_comm_init), otherwise the caller drives lb_step_boundary / lb_halo_export /
  *      lb_halo_import / lb_step_interior. */
@@ -206,7 +208,8 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps);
  * unique_id is the 128-byte ncclUniqueId: rank 0 obtains it with
  * lb_comm_unique_id and the caller broadcasts it (torch.distributed).
  * lb_comm_init is collective (every rank of the communicator calls it: the ranks agree on the smallest
- * slab height there, which decides the kernels and the exchange rhythm).  Afterwards lb_run on a slab
+ * slab height there, which decides the kernels and the exchange rhythm).  lb_check(across_ranks = 1) is the only
+ * other collective (two all-reduces of three scalars, outside the data path).  Afterwards lb_run on a slab
  * handle exchanges halos itself: two four-step (slabs of >= 64 rows) or three-step (>= 32 rows) launches per
  * exchange with ghost zones eight / six rows deep when nx >= 512, otherwise one exchange of the 3-deep halo
  * per launch. */
@@ -227,7 +230,7 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
 int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach, double *sum_rho);
 /* lb_run_group joins the device at chosen points (bits: 1 after every launch phase, 2 after every exchange, 4 after every
  * step, 8 at entry and exit); 0 = events only, the schedule lb_run itself relies on.  Process-wide; initial value from the
- * environment variable LB_DEBUG_SYNC, default 0.  Returns the previous value. */
+ * environment variable LB_DEBUG_SYNC (DESIGN.md section 8 for the default and why).  Returns the previous value. */
 int lb_set_debug_sync(int bits);
 
 /* ---- measurement --------------------------------------------------------- */

@@ -95,25 +95,37 @@ def test_config4_shear_layer_8192_properties(lbhip):
 
 
 def test_config4_shear_layer_8192_four_step_kernel_equals_single_step_kernel_bitwise(lbhip):
-    """8192x8192, the bench workload: the default kernel (k_step4, two launches) against the single-step kernel
-    (variant 9, eight launches) on the populations themselves, bit for bit.  The single-step kernel is the one the
+    """8192x8192, the bench workload: the default kernel (k_step4, two launches; then the driver's 5 + 10 x 20 steps) against
+    the single-step kernel (variant 9) on the populations themselves, bit for bit.  The single-step kernel is the one the
     oracle comparisons at <= 4096^2 pin; this carries them to the size the metric is quoted on."""
     from LB_D2Q9.simulation import Simulation
     import bench
     n = 8192
-    out = []
-    for variant in (-1, 9):
+    ref = None
+    for variant in (9, -1):
         sim = Simulation(n, n, 1.7, bc="periodic")
         sim.set_variant(variant)
         assert sim.steps_per_launch() == (4 if variant < 0 else 1)
         sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
+        f0 = sim.get_fields(("f",))["f"] if ref is None else None
         sim.run(8)
-        out.append(sim.get_fields(("f",))["f"])
+        f8 = sim.get_fields(("f",))["f"]
+        # ... and over the driver's whole bench run: 5 warm-up steps, then blocks of 20 (3 + 4 x 4 / 5 x 4 launches of the default
+        # kernel, segment pairs and all), 213 steps in all: still the single-step kernel's bits
+        sim.run(5)
+        for _ in range(10):
+            sim.run(20)
+        f213 = sim.get_fields(("f",))["f"]
+        chk = sim.check()
         sim.close()
-    assert np.all(np.isfinite(out[0]))
-    assert np.array_equal(out[0], out[1])
-    # and the flow has actually evolved: the v-perturbation has been advected (not the initial state)
-    assert out[0].std() > 0
+        if ref is None:
+            assert np.all(np.isfinite(f8)) and f8.std() > 0 and not np.array_equal(f0, f8)     # the flow has evolved
+            del f0
+            ref = (f8, f213, chk)
+        else:
+            assert np.array_equal(f8, ref[0])
+            assert np.array_equal(f213, ref[1]) and chk == ref[2]
+            assert chk["n_nonfinite"] == 0 and abs(chk["sum_rho"] / (n * n) - 1.0) < 1e-4
 
 
 @pytest.mark.parametrize("bc,masked", [("pipe", True), ("cavity", False), ("periodic", True)])

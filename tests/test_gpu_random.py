@@ -56,11 +56,23 @@ def test_random_configuration(lbhip, oracle, seed):
     assert_fields_close(want, o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
 
 
+@pytest.mark.parametrize("sync_bits", [0, 2])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LB_RANDOM_SLAB_SEEDS", "12"))))
-def test_random_slab_partition(lbhip, seed):
+def test_random_slab_partition(lbhip, seed, sync_bits):
     """Random row-slab partitions run through the in-library multi-GPU schedule (lb_run_group: halo cycles of two
     four- or three-step launches, launch-by-launch remainders, walls with bands of unequal height, masks) must
-    equal the undivided run bit for bit."""
+    equal the undivided run bit for bit -- with the members' streams ordered by events alone (sync_bits 0: what lb_run
+    relies on with RCCL) and with a device join after every exchange (2)."""
+    from LB_D2Q9.simulation import Simulation
+    from LB_D2Q9.slabs import LocalSlabRing
+    prev = lbhip.lb_set_debug_sync(sync_bits)
+    try:
+        _random_slab_partition_case(seed)
+    finally:
+        lbhip.lb_set_debug_sync(prev)
+
+
+def _random_slab_partition_case(seed):
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing
     rng = np.random.default_rng(5000 + seed)

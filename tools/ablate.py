@@ -28,6 +28,18 @@ def main():
     configs = ((33, "k_step2"), (9, "k_step"))
     if "--step3" in sys.argv:
         configs = ((97, "k_step3"),)
+    if "--tile" in sys.argv:
+        # k_tile4 hooks: 1 = no arithmetic at all (load, 4 x {LDS pull, barrier, write-back, barrier}, store), 2 = load, one step,
+        # store (no steps inside LDS), 3 = both: what a launch costs in data movement alone
+        bc = "cavity" if "--cavity" in sys.argv else "periodic"
+        child = CHILD.replace('bc="periodic"', 'bc="%s", lid_u=0.1' % bc).replace("sim.timed_run(20)", "sim.timed_run(400)").replace("n * n * 20", "n * n * 400")
+        for diag, what in ((0, "full"), (1, "no arithmetic"), (2, "one step per launch (no steps in LDS)"),
+                           (3, "load + one pull + store, no arithmetic"), (0, "full again")):
+            env = dict(os.environ, LB_LIB=lib, LB_DIAG=str(diag))
+            out = subprocess.run([sys.executable, "-c", child, str(n), str(864)], env=env, capture_output=True, text=True)
+            val = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "ERR " + out.stderr[-200:]
+            print("k_tile4 %s %d^2 diag=%d %-42s %s MLUPS-equivalent (4 steps per launch counted)" % (bc, n, diag, what, val), flush=True)
+        return
     if "--step4" in sys.argv:
         # k_step4 hooks: 1 / 2 / 4 / 2048 = skip the collide of stage 1 / 2 / 3 / 4, 1024 = skip the halo cells' stages
         pf = 1024 if "--pf" in sys.argv else 0

@@ -5,7 +5,10 @@
 the bytes of a wide coalesced read, so the read side is calibrated on the k_copy4 launches of the
 same run, whose byte count is known; WRITE_SIZE is taken as is (checked the same way).
 
-    python tools/pmc_summary.py gpurun_out/prof_<tag> <round-tag> <grid-side>
+    python tools/pmc_summary.py gpurun_out/prof_<tag> <round-tag> <grid-side> [<BASELINE config, 1-based; default 4>]
+
+Configurations other than 4 are keyed "c<config>/<side>/<steps per launch>" in profiles/pmc_traffic.json (bench.py looks them up
+that way); a kernel instantiated with an obstacle mask is priced at 73 B per cell.
 """
 import csv
 import glob
@@ -33,6 +36,7 @@ def short(name):
 
 def main():
     src, tag, side = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    config = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     kt = rows_of(os.path.join(src, "kt", "**", "*_kernel_trace.csv"))
     # Launches of one marching kernel differ in geometry while lb_autotune samples its candidates (8 or 4 waves
     # per CU): the table keeps them apart by grid size, "name" alone = the geometry with the most launches, i.e.
@@ -58,7 +62,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     lines = ["# rocprofv3 summary %s (grid %dx%d)" % (tag, side, side), "",
              "Command: `tools/gpu_profile.sh` = `rocprofv3 --kernel-trace --stats` and two `--pmc` passes "
-             "(FETCH_SIZE, WRITE_SIZE) around `bench.py --steps 20 --warmup 5 --calibrate 5`.", "",
+             "(FETCH_SIZE, WRITE_SIZE) around `bench.py --config %d --steps 20 --warmup 5 --calibrate 5`." % config, "",
              "## Kernel time (--kernel-trace)", "",
              "| kernel | calls | avg us | min us | max us | VGPR | SGPR | scratch | LDS |", "|---|---|---|---|---|---|---|---|---|"]
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -94,21 +98,22 @@ def main():
               "Calibration on `k_copy4<false>` (reads %.0f B, writes the same): FETCH_SIZE x 1024 = %.4g B -> "
               "read correction x%.3f; WRITE_SIZE x 1024 = %.4g B -> write correction x%.3f." % (
                   copy_bytes, copy_fetch, fetch_corr, copy_write, write_corr), "",
-              "| kernel | FETCH_SIZE (KiB) | WRITE_SIZE (KiB) | HBM read B (corrected) | HBM write B | total B | compulsory B (72 B x cells) | ratio |",
+              "| kernel | FETCH_SIZE (KiB) | WRITE_SIZE (KiB) | HBM read B (corrected) | HBM write B | total B | compulsory B (72 B x cells; 73 with a mask) | ratio |",
               "|---|---|---|---|---|---|---|---|"]
     out = {}
     for k in sorted(dur):
-        if (k, "FETCH_SIZE") not in pmc or not k.startswith("k_step"):
+        if (k, "FETCH_SIZE") not in pmc or not (k.startswith("k_step") or k.startswith("k_tile4")):
             continue
         f = st.mean(pmc[(k, "FETCH_SIZE")])
         w = st.mean(pmc[(k, "WRITE_SIZE")])
         rd, wr = f * 1024 * fetch_corr, w * 1024 * write_corr
-        macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS>
-        spl = int(k[6]) if k[6:7].isdigit() else 1        # k_step2/3/4: time steps per launch
-        alg = 72.0 * side * side + (12.0 * side * side if macro else 0.0)      # compulsory bytes of one launch, whatever spl
+        macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS> / k_tile4<BC, MASK, MACRO, ...>
+        masked = k.split(",")[1].strip() == "true"
+        spl = 4 if k.startswith("k_tile4") else (int(k[6]) if k[6:7].isdigit() else 1)        # time steps per launch
+        alg = (73.0 if masked else 72.0) * side * side + (12.0 * side * side if macro else 0.0)      # compulsory bytes of one launch, whatever spl
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
         if not macro:
-            out["%d/%d" % (side, spl)] = {"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
+            out[("%d/%d" % (side, spl)) if config == 4 else ("c%d/%d/%d" % (config, side, spl))] = {"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
                    "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
                    "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
     # rocprofv3's own --stats table of the SAME kernel-trace run, verbatim (never left over from another run)

@@ -3,6 +3,7 @@
 multi-stream schedule of lb_run_group must not depend on timing.  Prints where a mismatch sits.
     python tools/slab_stress.py [seeds] [noise processes]"""
 import os
+import signal
 import subprocess
 import sys
 
@@ -23,6 +24,7 @@ while True:
 
 
 def main():
+    signal.signal(signal.SIGTERM, lambda *a: sys.exit(143))       # (`timeout` must not leave the noise processes behind)
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     nnoise = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     from LB_D2Q9.simulation import Simulation
