@@ -100,10 +100,14 @@ __global__ void k_feq_i(const PhaseArgs a)     // D2Q9i.cl:2-64
 }
 
 // equilibrium of link k (one expression, shared by k_feq and the fused Cython-path step so that both round alike)
+// (the lattice constants as compile-time tables: every caller unrolls k, so the velocities fold into the expression instead
+//  of being fetched from constant memory and converted to float per link -- same operations on the same values, same bits)
 __device__ __forceinline__ float feq_link(int k, float rho, float ux, float uy, float usq)
 {
-    const float cu = d_cx[k] * ux + d_cy[k] * uy;
-    return d_w[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
+    constexpr int CX[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1}, CY[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+    constexpr float W[9] = {4.f / 9.f, 1.f / 9.f, 1.f / 9.f, 1.f / 9.f, 1.f / 9.f, 1.f / 36.f, 1.f / 36.f, 1.f / 36.f, 1.f / 36.f};
+    const float cu = CX[k] * ux + CY[k] * uy;
+    return W[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
 }
 
 __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64

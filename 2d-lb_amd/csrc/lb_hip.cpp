@@ -1218,10 +1218,18 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->stream = s->own_stream;
     CREATE_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     {
-        int lo = 0, hi = 0;   // edge bands and halo first: highest priority the device offers
+        // The edge stream (edge bands, halo pack / RCCL / unpack) at NORMAL priority.  Rounds 1-2 created it at the device's
+        // highest priority; with it, ~2 % of random slab partitions run through lb_run_group with events alone differed
+        // from the undivided run when four other processes kept the GPU busy (17 of ~900, tools/slab_stress.py; 7 of 1000 in
+        // round 2), none of 650 without -- while a stand-alone stress of HIP's cross-queue ordering, priorities included,
+        // finds nothing (tools/queue_order_repro.hip): cause not found, ingredient identified.  The priority buys nothing
+        // measurable (slab path of one of eight GPUs 255.1 k MLUPS with, 255.0 k without; the band launch is enqueued ahead
+        // of the interior's and the interior leaves it its wave slots): profiles/r03_experiments.txt section 6.
+        // LB_EDGE_PRIO=1 restores the high-priority stream (diagnosis).
+        int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        static const bool flat = getenv("LB_EDGE_PRIO") && atoi(getenv("LB_EDGE_PRIO")) == 0;   // diagnostic: no priority
-        CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, flat ? lo : hi));
+        static const bool high = getenv("LB_EDGE_PRIO") && atoi(getenv("LB_EDGE_PRIO")) == 1;
+        CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, high ? hi : lo));
     }
     const unsigned ev_flags = hipEventDisableTiming;
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, ev_flags));
@@ -1806,17 +1814,16 @@ int lb_run(lb_sim *s, int n_steps)
 // schedule and same halo tables as the RCCL path; exists so that the slab code can be verified
 // bitwise against the undivided run on a single GPU.
 // Full device synchronisation at chosen points of lb_run_group (bits: 1 after every launch phase, 2 after every exchange,
-// 4 after every step, 8 at entry and exit).  Default 2: with the GPU shared by several processes, rare partitions (a few
-// in a thousand) differed from the undivided run when the members' streams were ordered by events alone -- never in a
-// process that had the GPU to itself, never with one hardware queue per process (GPU_MAX_HW_QUEUES=1), never with the edge
-// stream at normal priority (LB_EDGE_PRIO=0), never in lb_run's own schedule (tools/slab_stress.py, tools/ring_stress.py,
-// profiles/r02_experiments.txt): it looks like barriers between a high-priority and a normal hardware queue going wrong
-// while queues are time-sliced, but a missing wait here has not been ruled out.  A verification harness must
-// not raise false alarms, so it joins the device after every exchange; LB_DEBUG_SYNC=0 gives the event-only schedule.
+// 4 after every step, 8 at entry and exit); default 0 = the members' streams are ordered by events alone, as lb_run's are.
+// History: with the edge streams at the device's highest priority and several processes sharing the GPU, rare partitions
+// (1-2 in a hundred) differed from the undivided run in the event-only schedule; round 2 hid that behind a join after every
+// exchange (bit 2).  Round 3: the edge stream runs at normal priority (lb_create) and the event-only schedule passes 650 of
+// 650 random partitions under the same contention, so the harness checks what lb_run relies on again.  lb_set_debug_sync /
+// LB_DEBUG_SYNC remain for diagnosis.
 static int g_debug_sync = -1;         // < 0: not read from the environment yet
 static int debug_sync_bits()
 {
-    if (g_debug_sync < 0) g_debug_sync = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) & 15 : 2;
+    if (g_debug_sync < 0) g_debug_sync = getenv("LB_DEBUG_SYNC") ? atoi(getenv("LB_DEBUG_SYNC")) & 15 : 0;
     return g_debug_sync;
 }
 int lb_set_debug_sync(int bits)

@@ -193,7 +193,7 @@ int lb_halo_import(lb_sim *s, int side, const void *buf);
 int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_rows);
 /* Advance `count` slab handles that tile one grid on ONE device in lock step: the multi-GPU schedule and kernels
  * without a second GPU (verification).  Halos move through the pack / unpack kernels of the RCCL path, the receiver
- * reading the sender's buffer; the device is joined after every exchange (environment LB_DEBUG_SYNC=0: events only). */
+ * reading the sender's buffer; the members' streams are ordered by events alone, as lb_run's are (lb_set_debug_sync adds device joins for diagnosis). */
 int lb_run_group(lb_sim **sims, int count, int n_steps);
 
 /* Population sets (the periodic multi-population lattices of the reference's research forks: porous_media/
@@ -230,7 +230,7 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
 int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach, double *sum_rho);
 /* lb_run_group joins the device at chosen points (bits: 1 after every launch phase, 2 after every exchange, 4 after every
  * step, 8 at entry and exit); 0 = events only, the schedule lb_run itself relies on.  Process-wide; initial value from the
- * environment variable LB_DEBUG_SYNC (DESIGN.md section 8 for the default and why).  Returns the previous value. */
+ * environment variable LB_DEBUG_SYNC, default 0.  Returns the previous value. */
 int lb_set_debug_sync(int bits);
 
 /* ---- measurement --------------------------------------------------------- */

@@ -99,14 +99,17 @@ def _ckpt_worker(rank, world, port, bc, phase, steps, ckpt_dir, out_dir):
     try:
         nx, ny, f0, mask = _case(bc)
         if phase == "save":
+            # (numpy scalars as parameters: they must reach the manifest like Python floats; np.float32(1.01) is not 1.01)
             slab = DistributedSlab(nx, ny, 1.4, bc=bc, obstacle_mask=mask, transport="torch",
-                                   engine_factory=OracleSlabEngine, inlet_rho=1.01, lid_u=0.05)
+                                   engine_factory=OracleSlabEngine, inlet_rho=np.float64(1.01), lid_u=np.float32(0.05))
             slab.set_f(f0)
             slab.run(steps)
             slab.save_checkpoint(ckpt_dir)
         else:
             slab = DistributedSlab.from_checkpoint(ckpt_dir, transport="torch", engine_factory=OracleSlabEngine)
             assert slab.nranks == world and (slab.nx, slab.ny) == (nx, ny)
+            from LB_D2Q9.slabs import _bc_code
+            assert _bc_code(bc) == _bc_code(_bc_code(bc))        # a family named by number or by name is the same family
             slab.run(steps)
             g = slab.get_fields(("f", "rho", "u", "v"))
             if rank == 0:
@@ -133,6 +136,7 @@ def test_multirank_checkpoint_written_by_two_ranks_resumes_on_three(oracle, tmp_
     mp.spawn(_ckpt_worker, args=(2, _free_port(), bc, "save", 5, ckpt, str(tmp_path)), nprocs=2, join=True)
     man = json.load(open(os.path.join(ckpt, "manifest.json")))
     assert man["nranks"] == 2 and man["partition_rows"] == [[0, 12], [12, 11]] and man["has_mask"]
+    assert man["params"] == {"inlet_rho": 1.01, "lid_u": float(np.float32(0.05))}            # numpy scalars are kept
     assert sorted(os.listdir(ckpt)) == ["manifest.json", "shard_0000.npz", "shard_0001.npz"]
     mp.spawn(_ckpt_worker, args=(3, _free_port(), bc, "resume", 7, ckpt, str(tmp_path)), nprocs=3, join=True)
     got = np.load(os.path.join(str(tmp_path), "resumed_%s.npz" % bc))

@@ -112,8 +112,15 @@ def main():
         spl = 4 if k.startswith("k_tile4") else (int(k[6]) if k[6:7].isdigit() else 1)        # time steps per launch
         alg = (73.0 if masked else 72.0) * side * side + (12.0 * side * side if macro else 0.0)      # compulsory bytes of one launch, whatever spl
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
+        key = ("%d/%d" % (side, spl)) if config == 4 else ("c%d/%d/%d" % (config, side, spl))
+        # (k_step4 and k_tile4 both advance four steps: the key goes to the one the run launched more often -- the other is one
+        #  of lb_autotune's samples -- and the other is kept under "<key>:k_tile4" / "<key>:k_step4")
+        if not macro and key in out and out[key]["calls_profiled"] >= len(dur[k]):
+            key += ":" + k.split("<")[0]
+        elif not macro and key in out:
+            out[key + ":" + out[key]["kernel"].split("<")[0]] = out[key]
         if not macro:
-            out[("%d/%d" % (side, spl)) if config == 4 else ("c%d/%d/%d" % (config, side, spl))] = {"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
+            out[key] = {"calls_profiled": len(dur[k]),"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
                    "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
                    "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
     # rocprofv3's own --stats table of the SAME kernel-trace run, verbatim (never left over from another run)
