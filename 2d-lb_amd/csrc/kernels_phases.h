@@ -99,15 +99,25 @@ __global__ void k_feq_i(const PhaseArgs a)     // D2Q9i.cl:2-64
     }
 }
 
-// equilibrium of link k (one expression, shared by k_feq and the fused Cython-path step so that both round alike)
-// (the lattice constants as compile-time tables: every caller unrolls k, so the velocities fold into the expression instead
-//  of being fetched from constant memory and converted to float per link -- same operations on the same values, same bits)
-__device__ __forceinline__ float feq_link(int k, float rho, float ux, float uy, float usq)
+// Equilibrium of one cell, all nine links: w_k rho (1 + 3 cu + 4.5 cu^2 - 1.5 u^2), written the way the fused kernels'
+// equilibrate_cell writes it -- 1 - 1.5 u^2 once, the weight times rho once per weight class, c.u as +-ux, +-uy, ux +- uy instead of
+// integer velocities times components -- so that the un-fused k_feq, the fused Cython-path passes and the fused OpenCL-path kernels all
+// round alike (k_feq's output is bitwise what k_step's relaxation used).  ~40 vector instructions per cell instead of ~75.
+__device__ __forceinline__ void feq_cell(float rho, float ux, float uy, float (&fe)[9])
 {
-    constexpr int CX[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1}, CY[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
-    constexpr float W[9] = {4.f / 9.f, 1.f / 9.f, 1.f / 9.f, 1.f / 9.f, 1.f / 9.f, 1.f / 36.f, 1.f / 36.f, 1.f / 36.f, 1.f / 36.f};
-    const float cu = CX[k] * ux + CY[k] * uy;
-    return W[k] * rho * (1.f + 3.f * cu + 4.5f * cu * cu - 1.5f * usq);
+    const float usq = ux * ux + uy * uy;
+    const float base = 1.f - 1.5f * usq;
+    const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+    fe[0] = r0 * base;
+    fe[1] = r1 * (base + 3.f * ux + 4.5f * ux * ux);
+    fe[3] = r1 * (base - 3.f * ux + 4.5f * ux * ux);
+    fe[2] = r1 * (base + 3.f * uy + 4.5f * uy * uy);
+    fe[4] = r1 * (base - 3.f * uy + 4.5f * uy * uy);
+    const float p = ux + uy, m = ux - uy;
+    fe[5] = r2 * (base + 3.f * p + 4.5f * p * p);
+    fe[7] = r2 * (base - 3.f * p + 4.5f * p * p);
+    fe[8] = r2 * (base + 3.f * m + 4.5f * m * m);
+    fe[6] = r2 * (base - 3.f * m + 4.5f * m * m);
 }
 
 __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
@@ -115,10 +125,10 @@ __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.nx) return;
     const long long o = (long long)y * a.pitch + x, m = (long long)y * a.fpitch + x;
-    const float rho = a.rho[m], ux = a.u[m], uy = a.v[m];
-    const float usq = ux * ux + uy * uy;
+    float fe[9];
+    feq_cell(a.rho[m], a.u[m], a.v[m], fe);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a.feq[k * a.plane + o] = feq_link(k, rho, ux, uy, usq);
+    for (int k = 0; k < 9; ++k) a.feq[k * a.plane + o] = fe[k];
 }
 
 __global__ void k_collide(const PhaseArgs a) // D2Q9.cl:102-121
@@ -222,9 +232,7 @@ __global__ void k_hydro_vel(const PhaseArgs a)
 // boundary rules BEFORE streaming and fed by the stored inlet/outlet velocity of the previous step, plain
 // bounce-back walls, an in-place streaming whose loop bounds leave four tangential links unmoved on one
 // wall row/column each, and overrides in the moment update.  These three kernels restate it phase by
-// phase (one thread per cell); k_feq and k_collide are shared.  lb_run fuses all but the boundary phase into
-// k1_step below: a compatibility path, ~3x slower than the fused OpenCL-path kernels and four orders of
-// magnitude faster than the reference's CPU loop.
+// phase (one thread per cell); k_feq and k_collide are shared.  lb_run fuses them into k1_fstep / k1_tile4 below.
 // x = i (0..lx), y = j (0..ly) in the .pyx's notation.
 
 // cython_dim.pyx:204-269 `move_bcs` (+ :468-513 obstacle swap) of one cell; u_here = the stored u of this cell (inlet /
@@ -307,7 +315,7 @@ __device__ __forceinline__ void c1_moments(const PhaseArgs &a, int x, int y, boo
 {
     const int lx = a.nx - 1, ly = a.ny - 1;
     rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
-    const float inv = 1.0f / rho;
+    const float inv = __builtin_amdgcn_rcpf(rho);               // (v_rcp_f32, 1 ulp, as moments_cell; the reference divides in float64)
     ux = (f1 - f3 + f5 - f6 - f7 + f8) * inv;
     uy = (f5 + f2 + f6 - f7 - f4 - f8) * inv;
     if (y == 0 || y == ly) { ux = 0.f; uy = 0.f; }              // walls
@@ -335,40 +343,6 @@ __global__ void k1_hydro(const PhaseArgs a)
     a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy;
 }
 
-// One Cython-path time step after its boundary phase, fused: the restricted pull of k1_move, the moments of
-// k1_hydro, the equilibrium of k_feq and the relaxation of k_collide for one cell, from lattice a.f (already through
-// k1_bcs) into lattice a.fs -- the same expressions, hence the same bits as the five un-fused launches, at a
-// fifth of their traffic.  rho, u, v are stored by the last step of a run (MACRO); every step stores u on the inlet /
-// outlet columns, which is all the next boundary phase reads (cython_dim.pyx:217-224).
-template <bool MACRO>
-__global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.nx) return;
-    const int lx = a.nx - 1, ly = a.ny - 1;
-    const long long o = (long long)y * a.pitch + x, S = a.plane, P = a.pitch, m = (long long)y * a.fpitch + x;
-    const bool up = (y >= 1), dn = (y <= ly - 1), le = (x >= 1), ri = (x <= lx - 1);
-    // k: moved (cython_dim.pyx:271-299)                    source when moved
-    const float f0 = a.f[o];
-    const float f1 = a.f[1 * S + ((up && le) ? o - 1 : o)];              // 1,5: j >= 1, i >= 1
-    const float f5 = a.f[5 * S + ((up && le) ? o - P - 1 : o)];
-    const float f2 = a.f[2 * S + ((up && ri) ? o - P : o)];              // 2,6: j >= 1, i <= lx-1
-    const float f6 = a.f[6 * S + ((up && ri) ? o - P + 1 : o)];
-    const float f4 = a.f[4 * S + ((dn && le) ? o + P : o)];              // 4,8: j <= ly-1, i >= 1
-    const float f8 = a.f[8 * S + ((dn && le) ? o + P - 1 : o)];
-    const float f3 = a.f[3 * S + ((dn && ri) ? o + 1 : o)];              // 3,7: j <= ly-1, i <= lx-1
-    const float f7 = a.f[7 * S + ((dn && ri) ? o + P + 1 : o)];
-    float rho, ux, uy;
-    c1_moments(a, x, y, a.mask && a.mask[m], f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
-    if (MACRO) { a.rho[m] = rho; a.u[m] = ux; a.v[m] = uy; }
-    else if (x == 0 || x == lx) a.u[m] = ux;
-    const float usq = ux * ux + uy * uy;
-    const float fk[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-        a.fs[k * S + o] = fk[k] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
-}
-
 // The Cython path, one launch per time step, four cells per lane.  Its step is rule -> stream -> moments -> relax
 // (cython_dim.pyx:346-359); the rule of step n+1 only touches the cell's own populations (and, on the inlet / outlet
 // columns, the u that step n's moments produced for this very cell), so it rides at the END of step n's pass: restricted
@@ -376,7 +350,7 @@ __global__ __launch_bounds__(256) void k1_step(const PhaseArgs a)
 // relaxation, then -- RULE -- next step's rule on the cells it concerns, then nine aligned 16-byte stores.  A run is
 // k1_bcs once (the first step's rule), n passes, the last one without RULE so that the populations it leaves are the
 // post-collision ones the reference holds after run().  Same expressions as k1_bcs + k1_move + k1_hydro + k_feq +
-// k_collide (c1_bcs_cell, c1_moments, feq_link): the same bits (test_cython_path_fused_run_equals_phase_calls).
+// k_collide (c1_bcs_cell, c1_moments, feq_cell): the same bits (test_cython_path_fused_run_equals_phase_calls).
 // Loads: the three links with cx = 0 aligned, the six others through 16-byte loads displaced by one element, as in
 // k_step; "a link outside its loop range keeps its value" becomes: rows 0 / ny-1 read their own row for the links that do
 // not move there (wave-uniform), and the single cells at x = 0 / x = nx-1 get their own value patched in.
@@ -425,9 +399,10 @@ __global__ __launch_bounds__(256) void k1_fstep(const PhaseArgs a)
         float rho, ux, uy;
         c1_moments(a, x, y, solid, q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j], rho, ux, uy);
         r4[j] = rho; u4[j] = ux; v4[j] = uy;
-        const float usq = ux * ux + uy * uy;
+        float fe[9];
+        feq_cell(rho, ux, uy, fe);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) q[k][j] = q[k][j] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
+        for (int k = 0; k < 9; ++k) q[k][j] = q[k][j] * (1.f - a.omega) + a.omega * fe[k];
         if (RULE && x <= lx && (wall_row || x == 0 || x == lx || solid)) {
             Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
             c1_bcs_cell(a, x, y, ux, solid, c);                 // (ux: what this pass would store as u on the inlet / outlet columns)
@@ -454,7 +429,7 @@ __global__ __launch_bounds__(256) void k1_fstep(const PhaseArgs a)
 // edges (no cell ever pulls from outside), the tile form needs no wall pass.  RULE_LAST: the fourth step is also followed
 // by the next step's boundary rule (false for the last launch of a run).  Same cell functions: same bits.
 template <bool MASK, bool MACRO, bool RULE_LAST>
-__global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS)) void k1_tile4(const PhaseArgs a, int tiles_x)
+__global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS), 8) void k1_tile4(const PhaseArgs a, int tiles_x)   // (8 waves per SIMD: four workgroups per CU, as the LDS allows)
 {
     typedef TileShape<32, 16, 2> T;
     constexpr int L = T::LW, LH = T::LH, CELLS = T::CELLS, THREADS = T::THREADS, CPT = T::CPT;
@@ -509,10 +484,11 @@ __global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS)) void k1_tile4(cons
             const bool solid = MASK && lmask[c] != 0;
             float rho, ux, uy;
             c1_moments(a, x, y, solid, f0, f1, f2, f3, f4, f5, f6, f7, f8, rho, ux, uy);
-            const float usq = ux * ux + uy * uy;
             const float fk[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
+            float fe[9];
+            feq_cell(rho, ux, uy, fe);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) out[i][k] = fk[k] * (1.f - a.omega) + a.omega * feq_link(k, rho, ux, uy, usq);
+            for (int k = 0; k < 9; ++k) out[i][k] = fk[k] * (1.f - a.omega) + a.omega * fe[k];
             rr[i] = rho; uu[i] = ux; vv[i] = uy;
             if ((!last || RULE_LAST) && mine[i] && (x == 0 || x == lx || y == 0 || y == ly || solid)) {
                 Cell q = {out[i][0], out[i][1], out[i][2], out[i][3], out[i][4], out[i][5], out[i][6], out[i][7], out[i][8]};
