@@ -1735,7 +1735,7 @@ int lb_run(lb_sim *s, int n_steps)
         return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
     if (n_steps == 0) return LB_OK;
     if (s->H < 6) return fail(LB_ERR_ARG, "a slab needs at least 6 rows (has %d)", s->H);
-    // Two queues.  The edge stream (high priority) carries the dependency chain of the slab as it is:
+    // Two queues.  The edge stream carries the dependency chain of the slab as it is:
     // edge rows of step t -> pack -> RCCL send/recv -> unpack -> edge rows of step t+1, in order, no
     // events in between.  The compute stream carries the interior rows.  Across the two, per launch:
     // the edge kernel waits for the previous interior kernel (it reads 3 rows past the band), the

@@ -15,8 +15,9 @@ A "step" = one pass of the hot path (stream + BC + moments + feq + BGK collide) 
 grid is fixed as N grows (strong scaling, as the north-star states its 8-GPU target).  Rank 0 prints ONE JSON
 line.
 
-Timing.  After W warm-up steps the K-step block -- barrier + device sync, K steps, barrier + device sync,
-MAX over ranks -- is repeated until at least MIN_BLOCKS blocks and MIN_TIMED_S seconds have been timed;
+Timing.  After W warm-up steps the K-step block -- barrier + device sync, K steps, barrier + device sync;
+every rank's time runs from the common start to the completion of its own K steps (the HIP event behind them), MAX over
+ranks -- is repeated until at least MIN_BLOCKS blocks and MIN_TIMED_S seconds have been timed;
 `ms_per_step` / `value` come from the MEDIAN block (`timing` lists min / max / count), so a 5 ms sample on a
 fresh box no longer decides the line.
 
@@ -339,19 +340,21 @@ def main():
     sim.run(args.warmup, wait=False)
 
     # ---- timed region: blocks of exactly K steps, each bracketed by barrier + device sync -------------------
-    walls, evs, total = [], [], 0.0
+    walls, evs, walls_incl, total = [], [], [], 0.0
     while len(walls) < MAX_BLOCKS and (len(walls) < args.min_blocks or total < args.min_timed_s):
         barrier()
         t0 = time.perf_counter()
-        ev_ms = sim.timed_run(args.steps)      # enqueue K steps between two HIP events on the engine's stream, wait
-        barrier()
-        wall = time.perf_counter() - t0
+        ev_ms = sim.timed_run(args.steps)      # enqueue K steps between two HIP events on the engine's stream, wait for the last
+        wall = time.perf_counter() - t0        # this rank's K steps, from the common start to its own completion ...
+        barrier()                              # ... (the closing bracket itself -- a device join and a collective -- is not a time step;
+        wall_incl = time.perf_counter() - t0   #      the time with it is reported beside: timing.ms_per_step_with_closing_barrier)
         if dist is not None:                   # MAX over ranks; also makes every rank take the same loop decision
-            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall, ev_ms, wall_incl], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall, ev_ms = float(t[0]), float(t[1])
+            wall, ev_ms, wall_incl = float(t[0]), float(t[1]), float(t[2])
         walls.append(wall)
         evs.append(ev_ms)
+        walls_incl.append(wall_incl)
         total += wall
     wall, ev_ms = statistics.median(walls), statistics.median(evs)
 
@@ -425,6 +428,7 @@ def main():
             "timing": {"blocks": len(walls), "block_steps": args.steps, "statistic": "median",
                        "min_ms_per_step": round(min(walls) * 1e3 / args.steps, 4),
                        "max_ms_per_step": round(max(walls) * 1e3 / args.steps, 4),
+                       "ms_per_step_with_closing_barrier": round(statistics.median(walls_incl) * 1e3 / args.steps, 4),
                        "timed_s": round(total, 3)},
             "config": {"workload": what or "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
                                            "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
