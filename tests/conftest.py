@@ -23,12 +23,13 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """A GPU test that hangs (a wedged device, a bootstrap that never returns) must fail, not stall the run: every
-    one of them finishes in seconds, the largest in under a minute."""
+    one of them finishes in seconds, the largest in under a minute (one suite run in each of rounds 2 and 3 stalled inside
+    lb_run_group on an otherwise idle box, not reproduced: profiles/r03_experiments.txt section 6)."""
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:
         if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(900, method="thread"))      # (a hang inside a C call: the signal method never fires)
+            item.add_marker(pytest.mark.timeout(400, method="thread"))      # (a hang inside a C call: the signal method never fires)
 
 
 def golden(name):
