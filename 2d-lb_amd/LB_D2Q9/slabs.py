@@ -323,11 +323,12 @@ class DistributedSlab(_SlabSet):
     def get_local_fields(self, which=("f", "feq", "u", "v", "rho")):
         return self.engine.get_fields(which)
 
-    def check(self, warn=False, raise_nonfinite=False):
+    def check(self, warn=False, raise_nonfinite=False, in_engine=False):
         """Collective.  Health of the whole lattice (Simulation.check over every rank's rows): non-finite cells and
-        mass summed, Mach number maximised over the ranks -- inside the engine with ncclAllReduce when RCCL carries
-        the halos, otherwise with torch.distributed on the three scalars."""
-        if self.transport == "rccl":
+        mass summed, Mach number maximised over the ranks -- with torch.distributed on the three scalars (any backend), or,
+        in_engine=True on the RCCL transport, inside the engine with ncclAllReduce on its own communicator
+        (lb_check(across_ranks = 1))."""
+        if in_engine and self.transport == "rccl":
             return self.engine.check(across_ranks=True, warn=warn, raise_nonfinite=raise_nonfinite)
         import torch
         c = self.engine.check()
