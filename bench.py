@@ -16,8 +16,8 @@ grid is fixed as N grows (strong scaling, as the north-star states its 8-GPU tar
 line.
 
 Timing.  After W warm-up steps the K-step block -- barrier + device sync, K steps, barrier + device sync;
-every rank's time runs from the common start to the completion of its own K steps (the HIP event behind them), MAX over
-ranks -- is repeated until at least MIN_BLOCKS blocks and MIN_TIMED_S seconds have been timed;
+every rank's time runs from the common start to its own device synchronisation behind the K steps, MAX over ranks (the
+closing barrier's own latency, 20-50 us of collective, is reported beside, not counted as time steps) -- is repeated until at least MIN_BLOCKS blocks and MIN_TIMED_S seconds have been timed;
 `ms_per_step` / `value` come from the MEDIAN block (`timing` lists min / max / count), so a 5 ms sample on a
 fresh box no longer decides the line.
 
@@ -345,9 +345,11 @@ def main():
         barrier()
         t0 = time.perf_counter()
         ev_ms = sim.timed_run(args.steps)      # enqueue K steps between two HIP events on the engine's stream, wait for the last
-        wall = time.perf_counter() - t0        # this rank's K steps, from the common start to its own completion ...
-        barrier()                              # ... (the closing bracket itself -- a device join and a collective -- is not a time step;
-        wall_incl = time.perf_counter() - t0   #      the time with it is reported beside: timing.ms_per_step_with_closing_barrier)
+        eng.sync()
+        torch.cuda.synchronize()               # the device has finished this rank's K steps ...
+        wall = time.perf_counter() - t0        # ... = this rank's time, from the common start to its own synchronised completion
+        barrier()                              # closing bracket; the collective itself is not a time step (MAX over ranks below says
+        wall_incl = time.perf_counter() - t0   #   when the slowest rank was done); the time with it: timing.ms_per_step_with_closing_barrier
         if dist is not None:                   # MAX over ranks; also makes every rank take the same loop decision
             t = torch.tensor([wall, ev_ms, wall_incl], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
