@@ -61,6 +61,33 @@ def test_bench_with_several_gpus_spawns_ranks_and_fails_loudly_without_gpus(lbhi
     assert not any(l.startswith("{") for l in p.stdout.splitlines())
 
 
+def test_bench_config_flag_is_validated_before_anything_touches_a_gpu():
+    """--config 2 | 3 | 5 are single-GPU cases: asking for several ranks is refused up front (exit status != 0, no line)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--gpus", "2", "--steps", "4", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "single-GPU" in (p.stderr + p.stdout)
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "7"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "invalid choice" in p.stderr
+
+
+def test_committed_per_configuration_lines_name_their_workload():
+    """profiles/r03_bench_c{2,3,4,5}.json: one line per single-GPU configuration of BASELINE.json, each with a roofline object."""
+    want = {2: ("1024x1024", "cavity", 72.0), 3: ("4096x4096", "Kelvin-Helmholtz", 72.0), 4: ("8192x8192", "shear layer", 72.0),
+            5: ("4096x4096", "porous", 73.0)}
+    for c, (grid, word, bpc) in want.items():
+        d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_c%d.json" % c)).read())
+        assert d["config"]["baseline_config"] == c and grid in d["config"]["workload"] and word in d["config"]["workload"]
+        r = d["roofline"]
+        n = d["config"]["grid"][0]
+        assert r["bound"] == "hbm" and 0 < r["frac"] <= 1 and r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-3)
+        assert r["algorithmic_bytes_per_launch"] == pytest.approx(bpc * n * n, rel=1e-6)
+        assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9, rel=2e-3)
+        assert d["health"]["n_nonfinite"] == 0 and d["value"] > 0 and d["unit"] == "MLUPS"
+        assert r["traffic"] is None or "committed profile" in r["traffic_source"]
+
+
 def _committed_bench_lines():
     import glob
     out = []
