@@ -25,6 +25,7 @@ struct StepArgs {
     int edge_seg_rows;     // k_step4: > 0: the first and the last strip march segments of this many rows (see the kernel)
     int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
     int prio_turns;        // k_step4: the two waves of a SIMD alternate their issue priority (bit of the 100 MHz clock)
+    int tile_launch_order; // k_tile4: 1 = tile = blockIdx (A/B switch; default: one band of tile rows per XCD)
     float omega, rho_in, rho_out, lid_u, rho0;
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)

@@ -429,14 +429,16 @@ __global__ __launch_bounds__(256) void k1_fstep(const PhaseArgs a)
 // edges (no cell ever pulls from outside), the tile form needs no wall pass.  RULE_LAST: the fourth step is also followed
 // by the next step's boundary rule (false for the last launch of a run).  Same cell functions: same bits.
 template <bool MASK, bool MACRO, bool RULE_LAST>
-__global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS), 8) void k1_tile4(const PhaseArgs a, int tiles_x)   // (8 waves per SIMD: four workgroups per CU, as the LDS allows)
+__global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS), 8) void k1_tile4(const PhaseArgs a, int tiles_x, int n_tiles)   // (8 waves per SIMD: four workgroups per CU, as the LDS allows)
 {
     typedef TileShape<32, 16, 2> T;
     constexpr int L = T::LW, LH = T::LH, CELLS = T::CELLS, THREADS = T::THREADS, CPT = T::CPT;
     __shared__ float lds[9][CELLS];
     __shared__ unsigned char lmask[CELLS];
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tile = xcd_band_tile(blockIdx.x, n_tiles);             // (one band of tile rows per XCD: kernels_tile.h)
+    if (tile >= n_tiles) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int gx0 = tx * 32 - TILE_T, gy0 = ty * 16 - TILE_T;        // global coordinates of region cell (0,0)
     const int lx = a.nx - 1, ly = a.ny - 1;
     const long long P = a.pitch, S = a.plane;

@@ -27,8 +27,21 @@ struct TileShape {
     static constexpr int THREADS = ((CELLS + CPT - 1) / CPT + 63) / 64 * 64;
 };
 
+// Which tile a workgroup takes.  Workgroups go to the eight XCDs round-robin (blockIdx % 8) and every XCD has an L2 of its
+// own: in launch order a tile's neighbours all sit on OTHER XCDs, and the 88 % of halo cells a 40 x 24 region shares with
+// them (plus the partial cache lines of its 160-byte rows) were fetched over the fabric once per XCD that touched them --
+// 2.98 x the compulsory bytes at 1024^2 (profiles/r03_experiments.txt), which is what bounded the kernel.  Here XCD j takes
+// the j-th eighth of the tiles in row-major order, a band of tile rows, in the order its workgroups are started: tiles
+// that share halo cells run on one XCD at about the same time.  The grid is rounded up to eight equal shares (n_tiles
+// need not divide): a workgroup whose index falls behind the last tile leaves at once.
+__device__ __forceinline__ int xcd_band_tile(int b, int n_tiles)
+{
+    const int share = (n_tiles + 7) >> 3;
+    return (b & 7) * share + (b >> 3);
+}
+
 template <int BC, bool MASK, bool MACRO, int TW, int TH, int CPT>
-__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(const StepArgs a, int tiles_x)
+__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(const StepArgs a, int tiles_x, int n_tiles)
 {
     constexpr int TILE_L = TileShape<TW, TH, CPT>::LW, TILE_LH = TileShape<TW, TH, CPT>::LH;
     constexpr int TILE_CELLS = TileShape<TW, TH, CPT>::CELLS, TILE_THREADS = TileShape<TW, TH, CPT>::THREADS;
@@ -36,7 +49,9 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
     __shared__ float lds[9][TILE_CELLS];
     __shared__ unsigned char lmask[TILE_CELLS];
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tile = a.tile_launch_order ? (int)blockIdx.x : xcd_band_tile(blockIdx.x, n_tiles);   // (A/B switch: variant bit 13)
+    if (tile >= n_tiles) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int gx0 = tx * TW - TILE_T, gy0 = ty * TH - TILE_T;         // global coordinates of region cell (0,0)
     const long long P = a.pitch, S = a.plane;
 

@@ -207,6 +207,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.ghost_n = (s->multi_slab() && (periodic || s->p.y0 + s->H < s->p.ny)) ? 1 : 0;
     a.seg_stride = 0;
     a.edge_seg_rows = 0;
+    a.tile_launch_order = (s->variant >= 0 && (s->variant & 8192)) ? 1 : 0;    // (A/B switch: explicit variants only)
     a.diag = s->diag;
     a.prio_turns = 0;      // (set by launch_step2 from the variant)
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
@@ -472,10 +473,10 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
 template <int BC, int TW, int TH, int CPT>
 void launch_tile_shape(const lb_sim *s, const StepArgs &a, bool macro)
 {
-    const int tiles_x = (s->p.nx + TW - 1) / TW, tiles_y = (s->H + TH - 1) / TH;
-    const dim3 grid(tiles_x * tiles_y), block(TileShape<TW, TH, CPT>::THREADS);
+    const int tiles_x = (s->p.nx + TW - 1) / TW, tiles_y = (s->H + TH - 1) / TH, n_tiles = tiles_x * tiles_y;
+    const dim3 grid((n_tiles + 7) / 8 * 8), block(TileShape<TW, TH, CPT>::THREADS);     // (eight equal shares: xcd_band_tile)
 #define LB_LAUNCHT(MASK, MACRO) \
-    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO, TW, TH, CPT>), grid, block, 0, s->stream, a, tiles_x)
+    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO, TW, TH, CPT>), grid, block, 0, s->stream, a, tiles_x, n_tiles)
     if (s->has_mask) { if (macro) LB_LAUNCHT(true, true); else LB_LAUNCHT(true, false); }
     else             { if (macro) LB_LAUNCHT(false, true); else LB_LAUNCHT(false, false); }
 #undef LB_LAUNCHT
@@ -929,8 +930,11 @@ bool use_tile_kernel(const lb_sim *s)
     //  marching from 1536^2: 136 against 130 k)
     // (round 3: the four-step marching kernel on segment pairs, against the tiles: periodic 1024^2 124 / 153 k MLUPS, 1280^2
     //  173 / 169 k, 1536^2 216 / 179 k, 2048^2 248 / 187 k; cavity 1024^2 99 / 148 k, 1280^2 146 / 166 k, 1536^2 180 / 176 k,
-    //  2048^2 217 / 183 k: profiles/r03_experiments.txt; the change-over was at 1600^2)
-    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1250.0 : 1450.0;
+    //  2048^2 217 / 183 k: profiles/r03_experiments.txt; the change-over was at 1600^2, then 1250^2 / 1450^2)
+    // (later in round 3: the tiles with one band of tile rows per XCD, marching / tiles: periodic 1536^2 198 / 206 k, 1664^2
+    //  207 / 213 k, 1792^2 220 / 216 k, 1920^2 230 / 216 k; cavity 1664^2 181 / 199 k, 1792^2 192 / 204 k, 1920^2 198 / 203 k,
+    //  2048^2 213 / 186 k)
+    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1750.0 : 1950.0;
     return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 
@@ -1702,13 +1706,13 @@ int lb_run(lb_sim *s, int n_steps)
         while (left > 0) {
             const PhaseArgs a = phase_args(s);
             if (tiles && left % TILE_T == 0) {
-                const int tiles_x = (s->p.nx + 31) / 32, tiles_y = (s->H + 15) / 16;
-                const dim3 tg(tiles_x * tiles_y), tb(TileShape<32, 16, 2>::THREADS);
+                const int tiles_x = (s->p.nx + 31) / 32, tiles_y = (s->H + 15) / 16, n_tiles = tiles_x * tiles_y;
+                const dim3 tg((n_tiles + 7) / 8 * 8), tb(TileShape<32, 16, 2>::THREADS);    // (eight equal shares: xcd_band_tile)
                 const bool lastp = (left == TILE_T);
-#define LB_LAUNCH1T(MASK)                                                                                         \
-                do {                                                                                              \
-                    if (lastp) hipLaunchKernelGGL((k1_tile4<MASK, true, false>), tg, tb, 0, s->stream, a, tiles_x); \
-                    else hipLaunchKernelGGL((k1_tile4<MASK, false, true>), tg, tb, 0, s->stream, a, tiles_x);       \
+#define LB_LAUNCH1T(MASK)                                                                                                  \
+                do {                                                                                                       \
+                    if (lastp) hipLaunchKernelGGL((k1_tile4<MASK, true, false>), tg, tb, 0, s->stream, a, tiles_x, n_tiles); \
+                    else hipLaunchKernelGGL((k1_tile4<MASK, false, true>), tg, tb, 0, s->stream, a, tiles_x, n_tiles);       \
                 } while (0)
                 if (s->has_mask) LB_LAUNCH1T(true); else LB_LAUNCH1T(false);
 #undef LB_LAUNCH1T

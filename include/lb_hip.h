@@ -267,9 +267,10 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * bit 4 XCD-aware tile order, bit 5 two time steps per pass where applicable (nx >= 512), bit 6 three
  * time steps per pass, bit 7 slabs exchange their halo after every launch instead of every two (no
  * halo cycle), bit 8 four time steps per pass (nx >= 512; whole-grid handles of >= 128 rows, slabs of >= 64), bit 9
- * four time steps per pass through 32 x 32 LDS tiles (whole-grid handles of >= 64 x 64 cells; for small grids), bit 10
- * k_step4 without its one-row-ahead gather, bit 11 k_step4 without the priority turns of the two waves of a SIMD (both
- * on by default; A/B switches).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
+ * four time steps per pass through 32 x 16 LDS tiles (whole-grid handles of >= 64 x 64 cells; for small grids), bit 10
+ * k_step4 without its one-row-ahead gather, bit 11 k_step4 without the priority turns of the two waves of a SIMD, bit 13
+ * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (all three on by
+ * default; A/B switches).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);
 
 #ifdef __cplusplus
