@@ -54,6 +54,11 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int gx0 = tx * TW - TILE_T, gy0 = ty * TH - TILE_T;         // global coordinates of region cell (0,0)
     const long long P = a.pitch, S = a.plane;
+#ifdef LB_DIAG
+    const bool flip = (a.diag & 8) && ((blockIdx.x >> 3) & 1);
+#else
+    constexpr bool flip = false;
+#endif
 
     // Wall cells (x = 0, nx-1; y = 0, ny-1) are not processed in the main pass but in one extra pass in which
     // thread t takes the t-th wall cell of the region (west column, east column, south row, north row; corners
@@ -95,8 +100,10 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         mine[i] = BC == LB_BC_PERIODIC ? (gx0 + lx == gx && gy0 + ly == gy) : (gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny);
         if (c < TILE_CELLS) {
             const long long o = (long long)sy * P + sx;
+            if (!flip) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
+                for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
+            }
             lmask[c] = (MASK && sx == gx && sy == gy) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
         }
     }
@@ -155,35 +162,68 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         lds[5][c] = q.f5; lds[6][c] = q.f6; lds[7][c] = q.f7; lds[8][c] = q.f8;
     };
 
+    auto steps = [&](const bool store) {
 #pragma unroll 1
-    for (int s = 1; s <= TILE_T; ++s) {
+        for (int s = 1; s <= TILE_T; ++s) {
 #ifdef LB_DIAG
-        if ((a.diag & 2) && s < TILE_T) continue;       // timing only: load, ONE step, store (what the three steps in LDS cost)
+            if ((a.diag & 2) && s < TILE_T) continue;       // timing only: load, ONE step, store (what the three steps in LDS cost)
 #endif
-        const bool last = (s == TILE_T);
-        Cell cs[TILE_CPT], wq;
-        bool act[TILE_CPT], wact = false;
-        // ---- main pass: every cell that is not on a wall ----------------------------------------------------
+            const bool last = (s == TILE_T);
+            Cell cs[TILE_CPT], wq;
+            bool act[TILE_CPT], wact = false;
+            // ---- main pass: every cell that is not on a wall ----------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < TILE_CPT; ++i) {
+                const int c = tid + i * TILE_THREADS;
+                act[i] = ring[i] >= s;
+                if (act[i]) cell_step(c, gxs[i], gys[i], std::false_type(), last && store, mine[i], cs[i]);
+            }
+            // ---- wall pass ------------------------------------------------------------------------------------------
+            if (wall_tile) {
+                wact = wring >= s;
+                if (wact) cell_step(wc, gx0 + wlx, gy0 + wly, std::true_type(), last && store, true, wq);
+            }
+            if (last) break;
+            __syncthreads();
+            // ---- post-collision values back in place ------------------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < TILE_CPT; ++i)
+                if (act[i]) cell_put(tid + i * TILE_THREADS, cs[i]);
+            if (wact) cell_put(wc, wq);
+            __syncthreads();
+        }
+    };
+#ifdef LB_DIAG
+    // timing only (tools/ablate.py --tile, bit 3): every other workgroup of an XCD runs its four steps FIRST (on whatever LDS
+    // holds) and loads and stores afterwards -- the workgroups of a CU out of phase with each other: what would overlapping
+    // one workgroup's loads with another's steps be worth?
+    if (flip) {
+        steps(false);
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < TILE_CPT; ++i) {
             const int c = tid + i * TILE_THREADS;
-            act[i] = ring[i] >= s;
-            if (act[i]) cell_step(c, gxs[i], gys[i], std::false_type(), last, mine[i], cs[i]);
-        }
-        // ---- wall pass ------------------------------------------------------------------------------------------
-        if (wall_tile) {
-            wact = wring >= s;
-            if (wact) cell_step(wc, gx0 + wlx, gy0 + wly, std::true_type(), last, true, wq);
-        }
-        if (last) break;
-        __syncthreads();
-        // ---- post-collision values back in place ------------------------------------------------------------
+            if (c < TILE_CELLS) {
+                const int sx = min(max(gxs[i], 0), a.nx - 1), sy = min(max(gys[i], 0), a.ny - 1);
+                const long long o = (long long)sy * P + sx;
 #pragma unroll
-        for (int i = 0; i < TILE_CPT; ++i)
-            if (act[i]) cell_put(tid + i * TILE_THREADS, cs[i]);
-        if (wact) cell_put(wc, wq);
+                for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
+            }
+        }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TILE_CPT; ++i) {
+            const int c = tid + i * TILE_THREADS;
+            if (ring[i] >= TILE_T && mine[i]) {
+                float *d = a.dst + (long long)gys[i] * P + gxs[i];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) d[k * S] = lds[k][c];
+            }
+        }
+        return;
     }
+#endif
+    steps(true);
 }
 
 // ---- the velocity-inlet family's wall-row bands, D time steps in one launch ---------------------------------------

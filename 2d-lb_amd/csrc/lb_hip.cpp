@@ -490,6 +490,8 @@ void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
     // the LDS round trips); 16 x 16 tiles, one cell per thread, for grids that would not give every CU a workgroup
     // (two cells per thread from 900^2: 145 against 134 k at 1024^2; one below: 90 against 83 k at 512^2)
     const long long cells = (long long)s->p.nx * s->H;
+    // (with one band of tile rows per XCD, two cells per thread: 32 x 32 tiles 150 k, 64 x 16 154-158 k against 175 k at 1024^2
+    //  periodic, and further behind on larger grids: profiles/r03_experiments.txt section 15)
     if (cells >= 900LL * 900) launch_tile_shape<BC, 32, 16, 2>(s, a, macro);
     else if (cells >= 330LL * 330) launch_tile_shape<BC, 32, 16, 1>(s, a, macro);
     else launch_tile_shape<BC, 16, 16, 1>(s, a, macro);

@@ -30,11 +30,12 @@ def main():
         configs = ((97, "k_step3"),)
     if "--tile" in sys.argv:
         # k_tile4 hooks: 1 = no arithmetic at all (load, 4 x {LDS pull, barrier, write-back, barrier}, store), 2 = load, one step,
-        # store (no steps inside LDS), 3 = both: what a launch costs in data movement alone
+        # store (no steps inside LDS), 3 = both: what a launch costs in data movement alone; 8 = every other workgroup of an XCD steps
+        # first and loads afterwards (the workgroups of a CU out of phase: what overlapping loads with steps would be worth)
         bc = "cavity" if "--cavity" in sys.argv else "periodic"
         child = CHILD.replace('bc="periodic"', 'bc="%s", lid_u=0.1' % bc).replace("sim.timed_run(20)", "sim.timed_run(400)").replace("n * n * 20", "n * n * 400")
         for diag, what in ((0, "full"), (1, "no arithmetic"), (2, "one step per launch (no steps in LDS)"),
-                           (3, "load + one pull + store, no arithmetic"), (0, "full again")):
+                           (3, "load + one pull + store, no arithmetic"), (8, "every other workgroup out of phase"), (0, "full again")):
             env = dict(os.environ, LB_LIB=lib, LB_DIAG=str(diag))
             out = subprocess.run([sys.executable, "-c", child, str(n), str(864)], env=env, capture_output=True, text=True)
             val = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "ERR " + out.stderr[-200:]
