@@ -225,8 +225,9 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
                                       ("pipe", 301, 101)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_tile_kernel_equals_single_step_kernel_small_grids(lbhip, bc, nx, ny, masked):
-    """k_tile4 (variant bit 9): four time steps per pass inside 32 x 32 LDS tiles, for the small grids the
-    marching kernels do not serve; tile edges that are not multiples of 32, periodic images, walls, masks."""
+    """k_tile4 (variant bit 9): four time steps per pass inside 32 x 16 LDS tiles, for the small grids the
+    marching kernels do not serve; tile edges that are not multiples of 32, periodic images, walls, masks; one band of
+    tile rows per XCD (default; tile counts that do not divide by eight) and tiles in launch order (variant bit 13)."""
     from LB_D2Q9.simulation import Simulation
     rng = np.random.default_rng(7 * nx + ny)
     f0 = _random_state(rng, nx, ny)
@@ -238,15 +239,17 @@ def test_tile_kernel_equals_single_step_kernel_small_grids(lbhip, bc, nx, ny, ma
             mask[:, 0] = mask[:, -1] = False
     kw = dict(inlet_rho=1.004, lid_u=0.06)
     out = []
-    for variant in (0, 512):
+    for variant in (0, 512, 512 | 8192):
         s = Simulation(nx, ny, 1.45, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
         s.set_f(f0)
         s.run(9)                      # 9 = 1 + 4 + 4
         s.run(8)
         out.append(s.get_fields(("f", "rho", "u", "v")))
+        s.close()
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(out[0][k], out[1][k]), k
+        assert np.array_equal(out[0][k], out[2][k]), k
 
 
 # ---- row slabs ---------------------------------------------------------------------------------------
