@@ -442,25 +442,33 @@ __global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS), 8) void k1_tile4(c
     const int gx0 = tx * 32 - TILE_T, gy0 = ty * 16 - TILE_T;        // global coordinates of region cell (0,0)
     const int lx = a.nx - 1, ly = a.ny - 1;
     const long long P = a.pitch, S = a.plane;
-    int gxs[CPT], gys[CPT], ring[CPT];
-    bool mine[CPT];
+    // the region into LDS in linear order ...
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int c = tid + i * THREADS;
-        const int cx = c % L, cy = c / L;
-        const int gx = gx0 + cx, gy = gy0 + cy;
-        // (cells outside the box are computed from copies of the nearest cells inside; nothing consumes them: a cell on
-        //  the box's edge keeps its own value for every link that would come from outside)
-        const int sx = min(max(gx, 0), lx), sy = min(max(gy, 0), ly);
-        gxs[i] = gx; gys[i] = gy;
-        ring[i] = c < CELLS ? min(min(cx, L - 1 - cx), min(cy, LH - 1 - cy)) : -1;
-        mine[i] = gx >= 0 && gx <= lx && gy >= 0 && gy <= ly;
         if (c < CELLS) {
+            const int gx = gx0 + c % L, gy = gy0 + c / L;
+            // (cells outside the box are computed from copies of the nearest cells inside; nothing consumes them: a cell on
+            //  the box's edge keeps its own value for every link that would come from outside)
+            const int sx = min(max(gx, 0), lx), sy = min(max(gy, 0), ly);
             const long long o = (long long)sy * P + sx;
 #pragma unroll
             for (int k = 0; k < 9; ++k) lds[k][c] = a.f[k * S + o];
-            lmask[c] = (MASK && mine[i]) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
+            lmask[c] = (MASK && sx == gx && sy == gy) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
         }
+    }
+    // ... and the cells I step: the tile itself and the halo rings from the inside out (tile_step_cell, kernels_tile.h)
+    int cc[CPT], gxs[CPT], gys[CPT], ring[CPT];
+    bool mine[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int cx, cy;
+        const bool have = tile_step_cell<32, 16>(tid, i, cx, cy);
+        const int gx = gx0 + cx, gy = gy0 + cy;
+        cc[i] = cy * L + cx;
+        gxs[i] = gx; gys[i] = gy;
+        ring[i] = have ? min(min(cx, L - 1 - cx), min(cy, LH - 1 - cy)) : -1;
+        mine[i] = gx >= 0 && gx <= lx && gy >= 0 && gy <= ly;
     }
     __syncthreads();
 #pragma unroll 1
@@ -470,7 +478,7 @@ __global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS), 8) void k1_tile4(c
         bool act[CPT];
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * THREADS, x = gxs[i], y = gys[i];
+            const int c = cc[i], x = gxs[i], y = gys[i];
             act[i] = ring[i] >= s;
             if (!act[i]) continue;
             const bool up = (y >= 1), dn = (y <= ly - 1), le = (x >= 1), ri = (x <= lx - 1);      // cython_dim.pyx:271-299
@@ -510,7 +518,7 @@ __global__ __launch_bounds__((TileShape<32, 16, 2>::THREADS), 8) void k1_tile4(c
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
             if (act[i]) {
-                const int c = tid + i * THREADS;
+                const int c = cc[i];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) lds[k][c] = out[i][k];
             }

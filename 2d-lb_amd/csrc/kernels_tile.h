@@ -40,8 +40,39 @@ __device__ __forceinline__ int xcd_band_tile(int b, int n_tiles)
     return (b & 7) * share + (b >> 3);
 }
 
+// Which region cell a thread STEPS, as opposed to loads (the region goes into LDS in linear order, rows coalesced).  With two
+// cells per thread: slot 0 = the tile itself, stepped four times; slot 1 = the halo rings from the inside out -- ring r is stepped
+// in steps 1..r --, so the waves of slot 1 leave the later steps as wholes instead of every wave of the region keeping a few live
+// lanes: 44 wave bodies per tile and four steps instead of 52 (the kernel is bound by its vector instructions, not by bytes:
+// profiles/r03_experiments.txt section 15).  Ring 0 is never stepped.  false = no cell in this slot.
+template <int TW, int TH>
+__device__ __forceinline__ bool tile_step_cell(int tid, int slot, int &lx, int &ly)
+{
+    constexpr int L = TW + 2 * TILE_T, LH = TH + 2 * TILE_T;
+    lx = ly = 0;
+    if (slot == 0) {
+        lx = TILE_T + tid % TW; ly = TILE_T + tid / TW;
+        return tid < TW * TH;
+    }
+    int j = tid;
+#pragma unroll
+    for (int r = TILE_T - 1; r >= 1; --r) {
+        const int W = L - 2 * r, H = LH - 2 * r, n = 2 * (W + H) - 4;
+        if (j >= 0 && j < n) {
+            if (j < W) { lx = r + j; ly = r; }                                          // its row nearest row 0
+            else if (j < 2 * W) { lx = r + j - W; ly = LH - 1 - r; }                    // the opposite one
+            else if (j < 2 * W + H - 2) { lx = r; ly = r + 1 + (j - 2 * W); }           // the columns between them
+            else { lx = L - 1 - r; ly = r + 1 + (j - 2 * W - (H - 2)); }
+            return true;
+        }
+        j -= n;
+    }
+    return false;
+}
+
 template <int BC, bool MASK, bool MACRO, int TW, int TH, int CPT>
-__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(const StepArgs a, int tiles_x, int n_tiles)
+__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), 8) void k_tile4(    // (<= 64 VGPR: four 512-thread workgroups per CU, as the LDS allows)
+    const StepArgs a, int tiles_x, int n_tiles)
 {
     constexpr int TILE_L = TileShape<TW, TH, CPT>::LW, TILE_LH = TileShape<TW, TH, CPT>::LH;
     constexpr int TILE_CELLS = TileShape<TW, TH, CPT>::CELLS, TILE_THREADS = TileShape<TW, TH, CPT>::THREADS;
@@ -74,19 +105,19 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
     }
     const bool wall_tile = BC != LB_BC_PERIODIC && (lxw >= 0 || lxe >= 0 || lys >= 0 || lyn >= 0);
 
-    // my cells: linear index c = ly * TILE_L + lx, global (gx, gy) wrapped where the box is periodic; ring = how
-    // many steps the cell stays in the computed part of the region (-1: never -- padding lanes, wall cells)
-    int gxs[TILE_CPT], gys[TILE_CPT], ring[TILE_CPT];
-    bool mine[TILE_CPT];                                // mine to store: not a periodic image / inside the walled box
-#pragma unroll
-    for (int i = 0; i < TILE_CPT; ++i) {
-        const int c = tid + i * TILE_THREADS;
-        const int lx = c % TILE_L, ly = c / TILE_L;
-        int gx = gx0 + lx, gy = gy0 + ly;
-        int sx = gx, sy = gy;                           // where the cell's data comes from
+    // The region into LDS -- thread t loads cells t, t + THREADS, ... in linear order c = ly * TILE_L + lx, rows coalesced -- and the
+    // cells I step: region index cc, global (gx, gy) wrapped where the box is periodic, ring = how many steps the cell stays
+    // in the computed part of the region (-1: never -- no cell, wall cells).  Two cells per thread and no obstacle mask:
+    // the tile and the rings (tile_step_cell; with a mask those instantiations would need 66-70 registers and drop to
+    // three workgroups per CU, or spill 12-36 B per lane within 64: 5-6 % slower than the linear order either way).
+    // Otherwise: the cells I load.
+    constexpr bool RINGS = (TILE_CPT == 2 && TILE_THREADS >= TW * TH && !MASK);
+    auto load_cell = [&](int c, int lx, int ly) {
+        const int gx = gx0 + lx, gy = gy0 + ly;
+        int sx, sy;                                     // where the cell's data comes from
         if (BC == LB_BC_PERIODIC) {
-            gx = sx = gx < 0 ? gx + a.nx : (gx >= a.nx ? gx - a.nx : gx);
-            gy = sy = gy < 0 ? gy + a.ny : (gy >= a.ny ? gy - a.ny : gy);
+            sx = gx < 0 ? gx + a.nx : (gx >= a.nx ? gx - a.nx : gx);
+            sy = gy < 0 ? gy + a.ny : (gy >= a.ny ? gy - a.ny : gy);
         } else {
             // cells outside a walled box are computed like any other, from copies of the nearest cells inside:
             // nothing valid consumes them (the boundary rule overwrites every link pulled from outside), and
@@ -94,17 +125,43 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
             sx = min(max(gx, 0), a.nx - 1);
             sy = min(max(gy, 0), a.ny - 1);
         }
+        const long long o = (long long)sy * P + sx;
+        if (!flip) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
+        }
+        const bool inside = BC == LB_BC_PERIODIC || (sx == gx && sy == gy);
+        lmask[c] = (MASK && inside) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
+    };
+    int cc[TILE_CPT], gxs[TILE_CPT], gys[TILE_CPT], ring[TILE_CPT];
+    bool mine[TILE_CPT];                                // mine to store: not a periodic image / inside the walled box
+#pragma unroll
+    for (int i = 0; i < TILE_CPT; ++i) {
+        int lx, ly;
+        bool have;
+        if (RINGS) have = tile_step_cell<TW, TH>(tid, i, lx, ly);
+        else {
+            const int c = tid + i * TILE_THREADS;
+            lx = c % TILE_L; ly = c / TILE_L;
+            have = c < TILE_CELLS;
+        }
+        int gx = gx0 + lx, gy = gy0 + ly;
+        if (BC == LB_BC_PERIODIC) {
+            gx = gx < 0 ? gx + a.nx : (gx >= a.nx ? gx - a.nx : gx);
+            gy = gy < 0 ? gy + a.ny : (gy >= a.ny ? gy - a.ny : gy);
+        }
+        cc[i] = ly * TILE_L + lx;
         gxs[i] = gx; gys[i] = gy;
-        ring[i] = c < TILE_CELLS ? min(min(lx, TILE_L - 1 - lx), min(ly, TILE_LH - 1 - ly)) : -1;
+        ring[i] = have ? min(min(lx, TILE_L - 1 - lx), min(ly, TILE_LH - 1 - ly)) : -1;
         if (BC != LB_BC_PERIODIC && (lx == lxw || lx == lxe || ly == lys || ly == lyn)) ring[i] = -1;
         mine[i] = BC == LB_BC_PERIODIC ? (gx0 + lx == gx && gy0 + ly == gy) : (gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny);
-        if (c < TILE_CELLS) {
-            const long long o = (long long)sy * P + sx;
-            if (!flip) {
+        if (!RINGS && have) load_cell(cc[i], lx, ly);
+    }
+    if (RINGS) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) lds[k][c] = a.src[k * S + o];
-            }
-            lmask[c] = (MASK && sx == gx && sy == gy) ? a.mask[(long long)sy * a.fpitch + sx] : 0;
+        for (int i = 0; i < TILE_CPT; ++i) {
+            const int c = tid + i * TILE_THREADS;
+            if (c < TILE_CELLS) load_cell(c, c % TILE_L, c / TILE_L);
         }
     }
     __syncthreads();
@@ -174,9 +231,8 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
             // ---- main pass: every cell that is not on a wall ----------------------------------------------------
 #pragma unroll
             for (int i = 0; i < TILE_CPT; ++i) {
-                const int c = tid + i * TILE_THREADS;
                 act[i] = ring[i] >= s;
-                if (act[i]) cell_step(c, gxs[i], gys[i], std::false_type(), last && store, mine[i], cs[i]);
+                if (act[i]) cell_step(cc[i], gxs[i], gys[i], std::false_type(), last && store, mine[i], cs[i]);
             }
             // ---- wall pass ------------------------------------------------------------------------------------------
             if (wall_tile) {
@@ -188,7 +244,7 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
             // ---- post-collision values back in place ------------------------------------------------------------
 #pragma unroll
             for (int i = 0; i < TILE_CPT; ++i)
-                if (act[i]) cell_put(tid + i * TILE_THREADS, cs[i]);
+                if (act[i]) cell_put(cc[i], cs[i]);
             if (wact) cell_put(wc, wq);
             __syncthreads();
         }
@@ -213,11 +269,10 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS)) void k_tile4(con
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TILE_CPT; ++i) {
-            const int c = tid + i * TILE_THREADS;
             if (ring[i] >= TILE_T && mine[i]) {
                 float *d = a.dst + (long long)gys[i] * P + gxs[i];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) d[k * S] = lds[k][c];
+                for (int k = 0; k < 9; ++k) d[k * S] = lds[k][cc[i]];
             }
         }
         return;

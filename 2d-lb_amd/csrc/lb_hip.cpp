@@ -933,10 +933,11 @@ bool use_tile_kernel(const lb_sim *s)
     // (round 3: the four-step marching kernel on segment pairs, against the tiles: periodic 1024^2 124 / 153 k MLUPS, 1280^2
     //  173 / 169 k, 1536^2 216 / 179 k, 2048^2 248 / 187 k; cavity 1024^2 99 / 148 k, 1280^2 146 / 166 k, 1536^2 180 / 176 k,
     //  2048^2 217 / 183 k: profiles/r03_experiments.txt; the change-over was at 1600^2, then 1250^2 / 1450^2)
-    // (later in round 3: the tiles with one band of tile rows per XCD, marching / tiles: periodic 1536^2 198 / 206 k, 1664^2
-    //  207 / 213 k, 1792^2 220 / 216 k, 1920^2 230 / 216 k; cavity 1664^2 181 / 199 k, 1792^2 192 / 204 k, 1920^2 198 / 203 k,
-    //  2048^2 213 / 186 k)
-    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1750.0 : 1950.0;
+    // (later in round 3: the tiles with one band of tile rows per XCD and the rings stepped by whole waves, marching / tiles:
+    //  periodic 1792^2 220 / 235 k, 1920^2 229 / 239 k, 2048^2 243 / 207 k; cavity 1920^2 200 / 228 k, 2048^2 214 / 201 k; pipe
+    //  1920^2 193 / 231 k, 2048^2 208 / 204 k, 2176^2 218 / 197 k: the tiles hold while the lattice pair fits the 256 MB
+    //  Infinity Cache -- 1920^2 is 265 MB, 2048^2 302 MB -- in every family)
+    const double side = 1950.0;
     return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 
