@@ -107,11 +107,11 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), 8) void k_tile4(
 
     // The region into LDS -- thread t loads cells t, t + THREADS, ... in linear order c = ly * TILE_L + lx, rows coalesced -- and the
     // cells I step: region index cc, global (gx, gy) wrapped where the box is periodic, ring = how many steps the cell stays
-    // in the computed part of the region (-1: never -- no cell, wall cells).  Two cells per thread and no obstacle mask:
-    // the tile and the rings (tile_step_cell; with a mask those instantiations would need 66-70 registers and drop to
-    // three workgroups per CU, or spill 12-36 B per lane within 64: 5-6 % slower than the linear order either way).
-    // Otherwise: the cells I load.
-    constexpr bool RINGS = (TILE_CPT == 2 && TILE_THREADS >= TW * TH && !MASK);
+    // in the computed part of the region (-1: never -- no cell, wall cells).  Two cells per thread: the tile and the rings
+    // (tile_step_cell) -- except the pipe families with an obstacle mask, whose instantiations then spill 20-24 B per lane
+    // within the 64 registers that four workgroups per CU allow and run 3-4 % slower than in the linear order.  Otherwise:
+    // the cells I load.
+    constexpr bool RINGS = (TILE_CPT == 2 && TILE_THREADS >= TW * TH && !(MASK && (BC == LB_BC_PIPE || BC == LB_BC_PIPE_I)));
     auto load_cell = [&](int c, int lx, int ly) {
         const int gx = gx0 + lx, gy = gy0 + ly;
         int sx, sy;                                     // where the cell's data comes from
@@ -232,7 +232,8 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), 8) void k_tile4(
 #pragma unroll
             for (int i = 0; i < TILE_CPT; ++i) {
                 act[i] = ring[i] >= s;
-                if (act[i]) cell_step(cc[i], gxs[i], gys[i], std::false_type(), last && store, mine[i], cs[i]);
+                // (stepped by rings, only slot 0 -- the tile -- is ever stored: slot 1's coordinates are dead values)
+                if (act[i]) cell_step(cc[i], gxs[i], gys[i], std::false_type(), last && store && (i == 0 || !RINGS), mine[i], cs[i]);
             }
             // ---- wall pass ------------------------------------------------------------------------------------------
             if (wall_tile) {
