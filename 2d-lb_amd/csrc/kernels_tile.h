@@ -166,10 +166,15 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), 8) void k_tile4(
     }
     __syncthreads();
 
-    // my wall cell (thread t: [0,LH) west column, [LH,2LH) east, [2LH,2LH+L) south row, [2LH+L,2LH+2L) north)
+    // my wall cell (thread t: [0,LH) west column, [LH,2LH) east, [2LH,2LH+L) south row, [2LH+L,2LH+2L) north).  Stepped by
+    // rings, the wall cells go to the LAST threads of the workgroup: their waves have no ring cell in slot 1 (324 ring cells
+    // for 512 threads), so the wall pass fills a hole instead of making the first two waves -- and with them, at the
+    // barrier, the whole tile -- a body late in every step.
+    constexpr int WALL_CELLS = 2 * (TILE_L + TILE_LH);
+    constexpr int WALL_T0 = (RINGS && TILE_THREADS - WALL_CELLS >= (TILE_L - 2) * (TILE_LH - 2) - TW * TH) ? TILE_THREADS - WALL_CELLS : 0;
     int wlx = -1, wly = -1;
-    if (wall_tile) {
-        int t = tid;
+    if (wall_tile && tid >= WALL_T0) {
+        int t = tid - WALL_T0;
         if (t < TILE_LH) { wlx = lxw; wly = t; }
         else if ((t -= TILE_LH) < TILE_LH) { wlx = lxe; wly = t; }
         else if ((t -= TILE_LH) < TILE_L) { wlx = t; wly = lys; if (t == lxw || t == lxe) wlx = -1; }
