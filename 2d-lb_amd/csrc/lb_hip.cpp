@@ -488,11 +488,15 @@ void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
     // 32 x 16 tiles (512 threads, two cells per thread, 49-60 VGPR: four workgroups per CU -- with 32 x 32 tiles and
     // four cells per thread the same kernel ran at 117 instead of 144 k MLUPS at 1024^2: occupancy is what hides
     // the LDS round trips); 16 x 16 tiles, one cell per thread, for grids that would not give every CU a workgroup
-    // (two cells per thread from 900^2: 145 against 134 k at 1024^2; one below: 90 against 83 k at 512^2)
+    // (round 1: two cells per thread from 900^2: 145 against 134 k at 1024^2; one below: 90 against 83 k at 512^2)
     const long long cells = (long long)s->p.nx * s->H;
     // (with one band of tile rows per XCD, two cells per thread: 32 x 32 tiles 150 k, 64 x 16 154-158 k against 175 k at 1024^2
     //  periodic, and further behind on larger grids: profiles/r03_experiments.txt section 15)
-    if (cells >= 900LL * 900) launch_tile_shape<BC, 32, 16, 2>(s, a, macro);
+    // (two cells per thread from 576^2 -- 900^2 until the rings were stepped by whole waves: one / two cells per thread, MLUPS,
+    //  periodic 512^2 122-124 / 123 k, 640^2 125-128 / 133-135 k, 768^2 145 / 156 k, 896^2 152 / 170 k; cavity 512^2 110 / 107 k,
+    //  640^2 112 / 121 k, 896^2 139 / 156 k: profiles/r03_experiments.txt section 16)
+    static const long long cpt2_env = getenv("LB_TILE_CPT2_SIDE") ? atoll(getenv("LB_TILE_CPT2_SIDE")) : 576;     // tuning knob
+    if (cells >= cpt2_env * cpt2_env) launch_tile_shape<BC, 32, 16, 2>(s, a, macro);
     else if (cells >= 330LL * 330) launch_tile_shape<BC, 32, 16, 1>(s, a, macro);
     else launch_tile_shape<BC, 16, 16, 1>(s, a, macro);
 }
