@@ -385,7 +385,7 @@ bool step4_applicable(const lb_sim *s)
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
 {
-    return s->p.bc_mode != LB_BC_VELOCITY_INLET && s->p.semantics != LB_SEM_OPENCL_D2Q9I && !s->multi_slab() &&
+    return s->p.bc_mode != LB_BC_VELOCITY_INLET && !s->multi_slab() &&
            s->p.nx >= 64 && s->H >= 64;
 }
 
@@ -506,7 +506,8 @@ int launch_tile4(lb_sim *s, bool macro)
 {
     macro = macro && !lazy_macro(s);
     const StepArgs a = step_args(s, 0, 1, s->H);
-    switch (s->p.bc_mode) {
+    switch (kernel_bc(s)) {
+    case LB_BC_PIPE_I: launch_tile_bc<LB_BC_PIPE_I>(s, a, macro); break;
     case LB_BC_PIPE: launch_tile_bc<LB_BC_PIPE>(s, a, macro); break;
     case LB_BC_PERIODIC: launch_tile_bc<LB_BC_PERIODIC>(s, a, macro); break;
     default: launch_tile_bc<LB_BC_CAVITY>(s, a, macro); break;
