@@ -71,7 +71,7 @@ __device__ __forceinline__ bool tile_step_cell(int tid, int slot, int &lx, int &
 }
 
 template <int BC, bool MASK, bool MACRO, int TW, int TH, int CPT>
-__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), 8) void k_tile4(    // (<= 64 VGPR: four 512-thread workgroups per CU, as the LDS allows)
+__global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), (CPT == 2 ? 8 : 1)) void k_tile4(    // (two cells per thread: <= 64 VGPR, four 512-thread workgroups per CU, as the LDS allows)
     const StepArgs a, int tiles_x, int n_tiles)
 {
     constexpr int TILE_L = TileShape<TW, TH, CPT>::LW, TILE_LH = TileShape<TW, TH, CPT>::LH;
