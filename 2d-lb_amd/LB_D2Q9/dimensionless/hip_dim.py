@@ -141,9 +141,17 @@ class Pipe_Flow(object):
         self.ly = self.N
         self.nx, self.ny = self.lx + 1, self.ly + 1
 
+    # The reference-named classes keep the reference's observable fields: rho, u, v are what update_hydro stored in the last
+    # step (the moments of the PRE-collision populations, opencl_dim.py:384-385), written by the last launch of every run().
+    # The lattice-unit class (LB_D2Q9.simulation.Simulation) defaults to rebuilding them on demand from the post-collision
+    # populations instead (equal up to rounding, <= 3.6e-7; include/lb_hip.h LB_FLAG_EAGER_MACRO); set this attribute to
+    # False on a subclass or an instance before init_hip() to get that behaviour here.
+    eager_macro = True
+
     def _engine(self):
         rin, rout = self._boundary_densities()
-        return Simulation(self.nx, self.ny, self.omega, bc='pipe', inlet_rho=rin, outlet_rho=rout, device=self.device)
+        return Simulation(self.nx, self.ny, self.omega, bc='pipe', inlet_rho=rin, outlet_rho=rout, device=self.device,
+                          eager_macro=self.eager_macro)
 
     def init_hip(self):
         """Replaces init_opencl (:203-242): report the HIP devices and create the engine handle."""

@@ -351,8 +351,11 @@ class Simulation(object):
         check(self._lib.lb_set_corner_state(self._h, v.ctypes.data))
 
     @classmethod
-    def from_checkpoint(cls, path, device=0):
-        """Build a new Simulation from a checkpoint file."""
+    def from_checkpoint(cls, path, device=0, eager_macro=False):
+        """Build a new Simulation from a checkpoint file.  eager_macro is a property of the handle, not of the state: a
+        checkpoint written by a handle that rebuilds rho, u, v on demand holds the moments of the post-collision
+        populations, one written by an eager handle the pre-collision ones (equal up to rounding, include/lb_hip.h); the
+        populations, and hence every later step, are the same bits either way."""
         with np.load(cls._ckpt_path(path)) as d:
             if int(d["version"]) != cls.CHECKPOINT_VERSION:
                 raise ValueError("checkpoint format %d, this build reads %d" % (int(d["version"]), cls.CHECKPOINT_VERSION))
@@ -360,7 +363,7 @@ class Simulation(object):
                       inlet_rho=float(d["inlet_rho"]), outlet_rho=float(d["outlet_rho"]), lid_u=float(d["lid_u"]),
                       rho0=float(d["rho0"]), device=device, y0=int(d["y0"]), local_ny=int(d["local_ny"]),
                       halo=bool(int(d["halo"])), semantics=str(d["semantics"]),
-                      inlet_u=float(d["inlet_u"]), outlet_u=float(d["outlet_u"]))
+                      inlet_u=float(d["inlet_u"]), outlet_u=float(d["outlet_u"]), eager_macro=eager_macro)
             sim.restore_arrays(d)
         return sim
 

@@ -627,6 +627,13 @@ int macro_check_pass(lb_sim *s, bool store)
 int ensure_macro(lb_sim *s)
 {
     if (s->macro_valid) return LB_OK;
+    // Only the families whose fields ARE the plain moments are ever rebuilt.  On the others (velocity inlet, D2Q9i, Cython
+    // path) rho, u, v carry state the kernels read back (the inlet / outlet v, the corner u): a rebuild would overwrite it,
+    // so a stale flag there -- e.g. left by a tuning pass that bailed out -- must never reach k_macro_check<STORE>.
+    if (!lazy_macro(s)) {
+        s->macro_valid = true;
+        return LB_OK;
+    }
     // (a run on a slab ends with both of its other streams joined into s->stream: lb_run's tail)
     int rc = macro_check_pass(s, true);
     if (rc) return rc;
@@ -1020,7 +1027,9 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
     }
     if (n_steps) {
         s->feq_valid = false;
-        s->macro_valid = store_macro || (s->diag & 4096);      // (LB_DIAG bit 12: the rho array carries the diagnostic build's per-wave timeline)
+        // only a family whose fields are rebuilt on demand is ever flagged for a rebuild (see ensure_macro); a tuning pass
+        // (final_macro = false) on the others leaves the fields of an earlier step in place until its closing MACRO step
+        s->macro_valid = store_macro || !lazy_macro(s) || (s->diag & 4096);      // (LB_DIAG bit 12: the rho array carries the diagnostic build's per-wave timeline)
     }
     return LB_OK;
 }
@@ -1230,17 +1239,20 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->stream = s->own_stream;
     CREATE_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     {
-        // The edge stream (edge bands, halo pack / RCCL / unpack) at NORMAL priority.  Rounds 1-2 created it at the device's
-        // highest priority; with it, ~2 % of random slab partitions run through lb_run_group with events alone differed
-        // from the undivided run when four other processes kept the GPU busy (17 of ~900, tools/slab_stress.py; 7 of 1000 in
-        // round 2), none of 650 without -- while a stand-alone stress of HIP's cross-queue ordering, priorities included,
-        // finds nothing (tools/queue_order_repro.hip): cause not found, ingredient identified.  The priority buys nothing
-        // measurable (slab path of one of eight GPUs 255.1 k MLUPS with, 255.0 k without; the band launch is enqueued ahead
-        // of the interior's and the interior leaves it its wave slots): profiles/r03_experiments.txt section 6.
-        // LB_EDGE_PRIO=1 restores the high-priority stream (diagnosis).
+        // The edge stream (edge bands, halo push / RCCL) at NORMAL priority.  Rounds 1-2 created it at the device's highest
+        // priority; with it, ~2 % of random slab partitions run through lb_run_group with events alone differed from the
+        // undivided run when four other processes kept the GPU busy (17 of ~900, tools/slab_stress.py), none of 1650 without,
+        // while a stand-alone stress of HIP's cross-queue ordering finds nothing (tools/queue_order_repro.hip) and an audit of
+        // every read-after-write and write-after-read pair of the cycle finds every one ordered.  The
+        // priority bought nothing measurable (profiles/r03_experiments.txt section 6), so the product has no such stream and
+        // no switch for one; the DIAGNOSTIC build (-DLB_DIAG, never loaded by the product) keeps LB_EDGE_PRIO=1 as the
+        // known-bad control for tools/slab_stress.py.
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        static const bool high = getenv("LB_EDGE_PRIO") && atoi(getenv("LB_EDGE_PRIO")) == 1;
+        bool high = false;
+#ifdef LB_DIAG
+        high = getenv("LB_EDGE_PRIO") && atoi(getenv("LB_EDGE_PRIO")) == 1;
+#endif
         CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, high ? hi : lo));
     }
     const unsigned ev_flags = hipEventDisableTiming;
@@ -2131,7 +2143,7 @@ int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach,
     if (across_ranks && !s->comm) return fail(LB_ERR_STATE, "lb_check across ranks needs lb_comm_init");
     DeviceGuard guard(s->p.device);
     // the pass that rebuilds rho, u, v reduces the same three numbers: one pass serves both when the fields are due
-    int rc = macro_check_pass(s, !s->macro_valid);
+    int rc = macro_check_pass(s, !s->macro_valid && lazy_macro(s));
     if (rc) return rc;
     s->macro_valid = true;
     CheckPartial *res = s->check_part + (s->check_cap - 1);

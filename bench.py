@@ -33,6 +33,12 @@ Extra objects in the line:
                  for the same MLUPS; exceeds the peak when several steps share one pass) is reported beside it,
                  never as `frac`.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of
                  this same command (profiles/pmc_traffic.json; see `traffic_source`), not measured in this run.
+  other_configs - (N = 1, default configuration only) the other single-GPU configurations of BASELINE.json -- 2, 3, 5 --
+                 timed by this same process after the headline's timed region, through the same code path as
+                 `--config N` (about a second each: median of >= 5 K-step blocks): value (MLUPS), ms_per_step,
+                 launch_ms, roofline_frac, kernel.  So that the driver's clock covers every configuration.
+  methodology  - a tag naming how the timed region is bracketed and which launch `roofline.frac` prices; it changes
+                 whenever a line stops being comparable with an older one (rounds 1-2: "r2").
   cpu_baseline - oracle port of the reference's Cython CPU path (oracle/d2q9_oracle.c o1_run, in the mode that is
                  pinned bit-exact to the imported reference: numpy2=True), 1 core, bounded samples at 256^2, 1024^2 and
                  4096^2 (`value` = the 4096^2 sample); reported, not a target.  Rank 0, N=1 only.
@@ -53,6 +59,14 @@ B_ALG = 72.0              # algorithmic bytes per lattice update: 9 fp32 read + 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling quoted by the same guide
 MIN_BLOCKS, MIN_TIMED_S, MAX_BLOCKS = 5, 0.5, 2000
+# How the numbers of a line are made (bump when that changes, so that lines of different rounds are not compared blindly):
+#   r3-block-avg: a rank's time runs from the common start (barrier + device sync) to its OWN device sync behind the K steps,
+#   MAX over ranks (the closing barrier is bracketing: timing.ms_per_step_with_closing_barrier has it); median block of
+#   >= 5 blocks and >= 0.5 s; rho, u, v are rebuilt on demand, so no launch of a block stores them (--eager-macro: round 2's
+#   behaviour); roofline.frac prices the K-step block average launch (frac_plain_launch: a launch inside a long run).
+#   Rounds 1-2 ("r2"): wall time included the closing barrier, the last launch of every block stored rho, u, v, and frac
+#   priced the plain launch.
+METHODOLOGY = "r3-block-avg"
 
 
 def shear_layer(nx, ny, y0, h, U=0.04, seed=0):
@@ -164,6 +178,44 @@ def workload(config, n, omega, local_rank, eager_macro=False):
     raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU plumbing case: tests/test_config1.py)")
 
 
+def measure_config(config, local_rank, steps, warmup, min_blocks, min_timed_s, size=None):
+    """One single-GPU configuration through the code path of `bench.py --config N`: build the workload on the device,
+    tune, warm up, time K-step blocks (device sync on both sides; HIP events on the engine's stream around each), median
+    block.  Returns the summary dict that goes into `other_configs`."""
+    import torch
+    n = size or {2: 1024, 3: 4096, 5: 4096}[config]
+    sim, what, bytes_per_cell = workload(config, n, None, local_rank)
+    try:
+        sim.autotune()
+        sim.run(warmup, wait=False)
+        walls, evs, total = [], [], 0.0
+        while len(walls) < MAX_BLOCKS and (len(walls) < min_blocks or total < min_timed_s):
+            sim.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev_ms = sim.timed_run(steps)
+            sim.sync()
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+            evs.append(ev_ms)
+            total += walls[-1]
+        wall, ev_ms = statistics.median(walls), statistics.median(evs)
+        health = sim.check()
+        mean_rho = health["sum_rho"] / (float(n) * n)
+        if health["n_nonfinite"] or abs(mean_rho - 1.0) > 1e-3 or not health["max_mach"] < 0.3:
+            raise SystemExit("bench: non-physical state after config %d (%r)" % (config, health))
+        spl = sim.steps_per_launch()
+        launch_s = ev_ms / 1e3 / steps * spl
+        achieved = bytes_per_cell * n * n / launch_s / 1e9
+        return {"config": config, "workload": what, "value": round(n * float(n) * steps / wall / 1e6, 1), "unit": "MLUPS",
+                "ms_per_step": round(wall * 1e3 / steps, 4), "steps": steps, "warmup": warmup, "blocks": len(walls),
+                "timed_s": round(total, 3), "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
+                "roofline_frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_GBps": round(achieved, 1),
+                "bytes_per_cell_per_launch": bytes_per_cell, "kernel": sim.hot_kernel(), "health": health}
+    finally:
+        sim.close()
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start one rank process per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* as torch.distributed.run would set them), wait, forward rank 0's line.  This parent
@@ -230,6 +282,8 @@ def main():
     ap.add_argument("--omega", type=float, default=None, help="BGK relaxation rate (default: the configuration's own; 1.7 for config 4)")
     ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="do not time BASELINE configurations 2, 3 and 5 behind the headline (N = 1, default configuration)")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning)")
     ap.add_argument("--eager-macro", action="store_true",
                     help="the last launch of every run() stores rho, u, v (LB_FLAG_EAGER_MACRO; round-2 behaviour) instead of "
@@ -439,9 +493,15 @@ def main():
             "health": health,
             "roofline": roof,
         }
+        line["methodology"] = METHODOLOGY
         if copy_gbs is not None:
             line["copy_GBps"] = copy_gbs
             roof["frac_of_copy_on_this_device"] = round(achieved / max(copy_gbs.values()), 4)
+        if world == 1 and dist is None and args.config == 4 and not args.no_other_configs:
+            # the other single-GPU configurations, on the driver's clock too: after the headline's timed region, the
+            # headline's lattice released first (same code path as `--config N`; about a second each)
+            eng.close()
+            line["other_configs"] = [measure_config(c, local_rank, 20, 8, args.min_blocks, args.min_timed_s) for c in (2, 3, 5)]
         if world == 1 and not args.no_cpu_baseline and args.config == 4:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=result_out, flush=True)

@@ -57,6 +57,10 @@ typedef struct {
 void o2_stream(const float *f, float *fs, int nx, int ny, int wrap_x, int wrap_y)
 {
     const size_t plane = (size_t)nx * ny;
+    /* (every (k, x, y) writes its own target: the loops are independent.  The omp pragmas of the o2_* routines only take
+     *  effect in the -fopenmp build, which tests/test_gpu_fullsize.py uses to hold the 8192^2 run to this oracle in seconds;
+     *  each cell's arithmetic is untouched, so both builds give the same bits: tests/test_oracle_golden.py.) */
+#pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < 9; ++k)
         for (int y = 0; y < ny; ++y)
             for (int x = 0; x < nx; ++x) {
@@ -71,7 +75,9 @@ void o2_stream(const float *f, float *fs, int nx, int ny, int wrap_x, int wrap_y
 /* D2Q9.cl:123-137 `copy_buffer` */
 void o2_copy(const float *src, float *dst, int nx, int ny)
 {
-    memcpy(dst, src, sizeof(float) * 9u * (size_t)nx * ny);
+    const size_t plane = (size_t)nx * ny;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < 9; ++k) memcpy(dst + k * plane, src + k * plane, sizeof(float) * plane);
 }
 
 /* D2Q9.cl:173-261 `move_bcs`: Zou-He pressure inlet (x=0) / outlet (x=nx-1),
@@ -282,6 +288,7 @@ void o2_zero_velocity(const int32_t *mask, float *u, float *v, int nx, int ny)
 void o2_moments(const float *f, float *rho, float *u, float *v, int nx, int ny)
 {
     const size_t plane = (size_t)nx * ny;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < plane; ++i) {
         const float f0 = f[P(0) + i], f1 = f[P(1) + i], f2 = f[P(2) + i], f3 = f[P(3) + i],
                     f4 = f[P(4) + i], f5 = f[P(5) + i], f6 = f[P(6) + i], f7 = f[P(7) + i],
@@ -304,6 +311,7 @@ void o2_feq(float *feq, const float *rho, const float *u, const float *v,
                                (float)(1. / 9.), (float)(1. / 9.), (float)(1. / 36.),
                                (float)(1. / 36.), (float)(1. / 36.), (float)(1. / 36.)};
     const size_t plane = (size_t)nx * ny;
+#pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < 9; ++k)
         for (size_t i = 0; i < plane; ++i) {
             float cu = CX[k] * u[i] + CY[k] * v[i];
@@ -317,6 +325,7 @@ void o2_feq(float *feq, const float *rho, const float *u, const float *v,
 void o2_collide(float *f, const float *feq, float omega, int nx, int ny)
 {
     const size_t n = 9u * (size_t)nx * ny;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i)
         f[i] = f[i] * (1 - omega) + omega * feq[i];
 }

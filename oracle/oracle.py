@@ -71,14 +71,17 @@ _lib_omp = None
 
 
 def lib_omp():
-    """The -fopenmp build of the same source: only the o1_* phase entry points, only for timing the
-    Cython-path port on all host cores (bench.py cpu_baseline)."""
+    """The -fopenmp build of the same source: o1_run for timing the Cython-path port on all host cores (bench.py
+    cpu_baseline), o2_run so that the full-size GPU tests can hold an 8192^2 run to the oracle in seconds (the loops that
+    carry a pragma are independent per cell: same bits as the serial build, tests/test_oracle_golden.py)."""
     global _lib_omp
     if _lib_omp is None:
         build()
         L = ct.CDLL(_LIB_OMP_PATH)
         L.o1_run.argtypes = [ct.POINTER(_O1State), ct.c_int]
         L.o1_run.restype = None
+        L.o2_run.argtypes = [ct.POINTER(_O2State), ct.c_int]
+        L.o2_run.restype = None
         _lib_omp = L
     return _lib_omp
 
@@ -287,8 +290,8 @@ class O2Sim(object):
             self.f *= np.asarray(perturb_xyk, np.float64).transpose(2, 1, 0)
         self.fs[...] = self.f
 
-    def run(self, n):
-        lib().o2_run(ct.byref(self._state()), int(n))
+    def run(self, n, openmp=False):
+        (lib_omp() if openmp else lib()).o2_run(ct.byref(self._state()), int(n))
 
     def get_fields(self):
         """Same shapes/orders as opencl_dim.py:390-415."""

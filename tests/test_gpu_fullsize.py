@@ -94,6 +94,38 @@ def test_config4_shear_layer_8192_properties(lbhip):
     assert abs(g["u"]).max() < 0.06 and abs(g["v"]).max() < 0.01
 
 
+def test_config4_shear_layer_8192_default_kernel_vs_oracle(lbhip, oracle):
+    """8192x8192, the bench workload, the bench's initial state, the kernel the bench times (k_step4 on segment pairs: one
+    launch = 4 steps, two launches = 8) DIRECTLY against the oracle at the size the metric is quoted on -- the same-size field
+    comparison the reference's own check makes (testing/Bryan/opencl_check_03.ipynb:593, 778).  The oracle runs its
+    -fopenmp build (same bits as the serial one: tests/test_oracle_golden.py).  Tolerances of the 4096^2 test."""
+    from LB_D2Q9.simulation import Simulation
+    import bench
+    n = 8192
+    sim = Simulation(n, n, 1.7, bc="periodic")
+    assert sim.steps_per_launch() == 4 and "k_step4" in sim.hot_kernel()
+    sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))          # f = feq, built on the device, as bench.py does
+    f0 = sim.get_fields(("f",))["f"]
+    ref = oracle.O2Sim(n, n, 1.7, oracle.BC_PERIODIC)
+    ref.set_f(f0)
+    del f0
+    done = 0
+    for steps, tol in ((4, dict(f=5e-7, rho=1e-6, u=1e-6, v=1e-6)), (8, dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))):
+        sim.run(steps - done)
+        ref.run(steps - done, openmp=True)
+        done = steps
+        g = sim.get_fields(("f", "rho", "u", "v"))
+        # (nx, ny, 9) F-ordered on the GPU side is the oracle's (9, ny, nx) C-ordered array: compare without copies
+        gf = np.asarray(g["f"]).transpose(2, 1, 0)
+        assert gf.flags.c_contiguous
+        for k9 in range(9):                                        # (plane by plane: no 5 GB float64 temporaries)
+            assert maxdiff(gf[k9], ref.f[k9]) <= tol["f"], (steps, k9)
+        for k in ("rho", "u", "v"):
+            assert maxdiff(np.asarray(g[k]).T, getattr(ref, k)) <= tol[k], (steps, k)
+        del g
+    assert float(np.abs(ref.u).max()) > 0.03                       # the shear layer is there
+
+
 def test_config4_shear_layer_8192_four_step_kernel_equals_single_step_kernel_bitwise(lbhip):
     """8192x8192, the bench workload: the default kernel (k_step4, two launches; then the driver's 5 + 10 x 20 steps) against
     the single-step kernel (variant 9) on the populations themselves, bit for bit.  The single-step kernel is the one the

@@ -93,6 +93,35 @@ def test_fields_on_demand_are_those_of_the_last_step_whatever_happens_next(lbhip
         assert np.array_equal(a.get_fields((k,))[k], c.get_fields((k,))[k]), k
 
 
+def test_checkpoint_written_lazy_restored_eager_continues_bitwise(lbhip, tmp_path):
+    """A checkpoint written by a handle that rebuilds rho, u, v on demand, restored into one that stores them (and the
+    other way round): the populations of every later step are the same bits; only the stored fields differ, by rounding."""
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 192, 160
+    rng = np.random.default_rng(11)
+    mask = (rng.random((nx, ny)) < 0.03).astype(np.int32)
+    mask[0, :] = mask[-1, :] = 0
+    mask[:, 0] = mask[:, -1] = 0
+    f0 = _random_state(rng, nx, ny)
+    ref = Simulation(nx, ny, 1.5, bc="pipe", inlet_rho=1.004, outlet_rho=1.0, obstacle_mask=mask)
+    ref.set_f(f0)
+    ref.run(9 + 14)
+    want = ref.get_fields(("f",))["f"]
+    for first, second in ((False, True), (True, False)):
+        a = Simulation(nx, ny, 1.5, bc="pipe", inlet_rho=1.004, outlet_rho=1.0, obstacle_mask=mask, eager_macro=first)
+        a.set_f(f0)
+        a.run(9)
+        path = str(tmp_path / ("ck_%d" % int(first)))
+        a.save_checkpoint(path)
+        b = Simulation.from_checkpoint(path, eager_macro=second)
+        assert b.eager_macro == second
+        b.run(14)
+        got = b.get_fields(("f", "rho", "u", "v"))
+        assert np.array_equal(got["f"], want)
+        full = ref.get_fields(("rho", "u", "v"))
+        assert maxdiff(got["rho"], full["rho"]) <= 3.6e-7 and maxdiff(got["u"], full["u"]) <= 2.5e-7
+
+
 @pytest.mark.parametrize("bc,kw", FAMILIES + [("velocity_inlet", {"inlet_u": 0.04})])
 @pytest.mark.parametrize("nx,ny", [(67, 29), (1030, 70), (1024, 300)])
 def test_health_check_vs_numpy(lbhip, bc, kw, nx, ny):
@@ -150,12 +179,18 @@ def test_mach_warning_like_the_forks(lbhip):
 
 def test_d2q9i_class_raises_when_the_fork_diverges(lbhip):
     """The executed D2Q9i fork overflows within tens of steps (tests/golden/o2_d2q9i_53x27 is NaN by step 60; this docs-sized
-    cylinder case, inlet density 1.9, within ten: oracle, float64 moments); the module's classes check after every run()
-    and raise on the first one that leaves non-finite cells instead of handing back NaN fields later."""
+    cylinder case, inlet density 1.9, within ten: oracle, float64 moments).  By default the module's classes behave like
+    the reference's (run() never raises, NaN fields come back); with raise_on_divergence=True they check after every run()
+    and raise on the first one that leaves non-finite cells."""
     from LB_D2Q9.dimensionless import opencl_dim_D2Q9i as lb
+    args = dict(cylinder_center=[.75, .5], cylinder_radius=.1, verbose=False, diameter=1., rho=1., viscosity=1.,
+                pressure_grad=-10., pipe_length=3., N=8)
     np.random.seed(4)
-    c = lb.Pipe_Flow_Cylinder(cylinder_center=[.75, .5], cylinder_radius=.1, verbose=False, diameter=1., rho=1., viscosity=1.,
-                              pressure_grad=-10., pipe_length=3., N=8)
+    ref_like = lb.Pipe_Flow_Cylinder(**args)
+    ref_like.run(60)                                   # the reference's behaviour: no exception ...
+    assert not np.all(np.isfinite(ref_like.get_fields()["f"]))      # ... and non-finite populations handed back
+    np.random.seed(4)
+    c = lb.Pipe_Flow_Cylinder(raise_on_divergence=True, **args)
     c.run(2)                                           # still finite
     assert np.all(np.isfinite(c.get_fields()["f"])) and c.check()["n_nonfinite"] == 0
     steps = 2

@@ -317,3 +317,24 @@ def test_periodic_streaming_is_the_forks_move_periodic(oracle):
             o.set_f(f[:, :, i, :].astype(np.float32))
             o.move()
             assert np.array_equal(o.get_fields()["f"], want[:, :, i, :].astype(np.float32)), (tag, i)
+
+
+def test_o2_openmp_build_gives_the_serial_build_its_bits(oracle):
+    """The -fopenmp build of the OpenCL-path oracle (used to hold the 8192^2 GPU run to the oracle in seconds,
+    tests/test_gpu_fullsize.py) runs the same per-cell arithmetic over independent loops: bitwise equal to the serial
+    build -- which the fixtures pin -- in every family, with an obstacle mask."""
+    rng = np.random.default_rng(5)
+    nx, ny = 61, 47
+    w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+    f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)
+    mask = rng.random((nx, ny)) < 0.05
+    mask[0, :] = mask[-1, :] = False
+    mask[:, 0] = mask[:, -1] = False
+    for bc, kw in ((oracle.BC_PERIODIC, {}), (oracle.BC_PIPE, dict(inlet_rho=1.01, outlet_rho=1.0)),
+                   (oracle.BC_CAVITY, dict(lid_u=0.07, rho0=1.0))):
+        a = oracle.O2Sim(nx, ny, 1.7, bc, mask=mask, **kw)
+        b = oracle.O2Sim(nx, ny, 1.7, bc, mask=mask, **kw)
+        a.set_f(f0); b.set_f(f0)
+        a.run(12); b.run(12, openmp=True)
+        for k in ("f", "rho", "u", "v", "feq"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), (bc, k)
