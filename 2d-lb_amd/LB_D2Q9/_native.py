@@ -13,11 +13,12 @@ LB_FLAG_HALO = 1
 LB_FLAG_PLANAR = 2
 LB_FLAG_EAGER_MACRO = 4
 LB_MASK_HALO_ROWS = 7
+LB_PEER_HANDLE_BYTES = 384
 LB_SEM_OPENCL, LB_SEM_CYTHON, LB_SEM_OPENCL_D2Q9I = 0, 1, 2
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
             "velocity_inlet": LB_BC_VELOCITY_INLET}
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/lb_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -29,6 +30,7 @@ EXPORTS = (
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group", "lb_run_batch",
     "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
     "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state", "lb_check", "lb_set_debug_sync",
+    "lb_peer_export", "lb_peer_connect",
 )
 
 
@@ -80,6 +82,11 @@ def lib():
     L.lb_run_group.argtypes = [ct.POINTER(h), I, I]
     L.lb_run_batch.argtypes = [ct.POINTER(h), I, I]
     L.lb_comm_unique_id.argtypes = [vp]
+    # (an older diagnostic build selected with LB_LIB -- A/B timing of kernels across rounds -- lacks the newest entry points)
+    older = bool(os.environ.get("LB_LIB")) and L.lb_abi_version() < ABI_VERSION
+    if not older:
+        L.lb_peer_export.argtypes = [h, vp]
+        L.lb_peer_connect.argtypes = [h, I, I, vp, vp, I]
     L.lb_comm_init.argtypes = [h, vp, I, I]
     L.lb_timer_stop.argtypes = [h, fp]
     L.lb_layout.argtypes = [h, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64)]
@@ -91,7 +98,7 @@ def lib():
     L.lb_hot_kernel.argtypes = [h, ct.c_char_p, I]
     L.lb_check.argtypes = [h, I, ct.POINTER(ct.c_int64), fp, ct.POINTER(ct.c_double)]
     L.lb_set_debug_sync.argtypes = [I]
-    if L.lb_abi_version() != ABI_VERSION:
+    if L.lb_abi_version() != ABI_VERSION and not older:
         raise LbError("liblbhip.so ABI %d != binding ABI %d: rebuild" % (L.lb_abi_version(), ABI_VERSION))
     _lib = L
     return L

@@ -414,6 +414,18 @@ class Simulation(object):
         """Attach an RCCL communicator: run() then exchanges halos itself (lb_comm_init)."""
         check(self._lib.lb_comm_init(self._h, unique_id, int(rank), int(nranks)))
 
+    def peer_export(self):
+        """This handle's descriptor for the peer transport (lb_peer_export): IPC handles of its lattices and flag block,
+        LB_PEER_HANDLE_BYTES bytes to be carried to the two neighbouring ranks."""
+        buf = (ct.c_char * _native.LB_PEER_HANDLE_BYTES)()
+        check(self._lib.lb_peer_export(self._h, buf))
+        return bytes(buf.raw)
+
+    def peer_connect(self, rank, nranks, south, north, min_h):
+        """Map the neighbours' descriptors (bytes from their peer_export(); None at a wall) and switch run() on this slab
+        to the peer transport: halo rows stored straight into the neighbours' ghost rows (lb_peer_connect)."""
+        check(self._lib.lb_peer_connect(self._h, int(rank), int(nranks), south, north, int(min_h)))
+
     # -- tuning / introspection ------------------------------------------------
     def copy_calibration(self, iters=10, nontemporal=False):
         """Time `iters` plain float4 copies of one lattice into the other (known bytes).

@@ -12,7 +12,10 @@ import) is the 3-deep one (18 row segments, include/lb_hip.h).  There is no coll
                           prove that a partitioned run equals the single-slab run bit for bit.
 * ``DistributedSlab``   - one process per GPU under ``torch.distributed``.  transport='rccl': the
                           engine exchanges halos itself inside ``lb_run`` (RCCL send/recv on a side
-                          HIP stream, overlapped with the interior rows).  transport='torch': the
+                          HIP stream, overlapped with the interior rows).  transport='peer': the same
+                          schedule, the halo rows stored straight into the neighbours' ghost rows through
+                          device memory mapped across the rank processes (lb_peer_connect; works between
+                          processes that share ONE GPU, which RCCL refuses).  transport='torch': the
                           exchange is driven from here with ``torch.distributed`` point-to-point ops
                           (any backend; also the path the CPU/gloo tests exercise with a stand-in
                           engine injected through ``engine_factory``).
@@ -188,8 +191,10 @@ class DistributedSlab(_SlabSet):
         self._bufs = None
         if transport == "rccl":
             self._attach_rccl()
+        elif transport == "peer":
+            self._attach_peer()
         elif transport != "torch":
-            raise ValueError("transport must be 'rccl' or 'torch'")
+            raise ValueError("transport must be 'rccl', 'peer' or 'torch'")
 
     # -- RCCL inside the engine ------------------------------------------------------------------
     def _attach_rccl(self):
@@ -234,6 +239,43 @@ class DistributedSlab(_SlabSet):
             err = exc
         if not all_ok(err is None):
             raise _native.LbError("lb_comm_init failed on a rank (%s)" % (err or "a peer failed"))
+
+    # -- peer transport inside the engine --------------------------------------------------------------
+    def _attach_peer(self):
+        """Collective.  Every rank exports its descriptor (IPC handles of its lattices and flag block), the descriptors
+        travel as bytes over torch.distributed (any backend: CPU tensors under gloo, which is what several rank processes
+        sharing one GPU use), each rank maps its two neighbours.  As with RCCL, every stage ends in an agreement so that a
+        rank that fails raises on ALL ranks instead of leaving its peers waiting."""
+        import torch
+        dist = self._dist
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", self.engine.device) if on_gpu else torch.device("cpu")
+        if on_gpu:
+            torch.cuda.set_device(dev)
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(int(t[0]))
+
+        err, mine = None, bytes(_native.LB_PEER_HANDLE_BYTES)
+        try:
+            mine = self.engine.peer_export()
+        except _native.LbError as exc:
+            err = exc
+        if not all_ok(err is None):
+            raise _native.LbError("lb_peer_export failed on a rank (%s)" % (err or "a peer failed"))
+        t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+        every = [torch.zeros_like(t) for _ in range(self.nranks)]
+        dist.all_gather(every, t, group=self.group)
+        descs = [bytes(e.cpu().numpy().tobytes()) for e in every]
+        try:
+            self.engine.peer_connect(self.rank, self.nranks, descs[self.south] if self.south >= 0 else None,
+                                     descs[self.north] if self.north >= 0 else None, min(h for _, h in self.parts))
+        except _native.LbError as exc:
+            err = exc
+        if not all_ok(err is None):
+            raise _native.LbError("lb_peer_connect failed on a rank (%s)" % (err or "a peer failed"))
 
     # -- torch.distributed driven exchange ----------------------------------------------------------
     def _torch_buffers(self):
@@ -299,7 +341,7 @@ class DistributedSlab(_SlabSet):
         self._ghosts_valid = False
 
     def run(self, n, wait=True):
-        if self.transport == "rccl":
+        if self.transport in ("rccl", "peer"):
             self.engine.run(n, wait=wait)
             return
         if n and not self._ghosts_valid:

@@ -125,33 +125,88 @@ __device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
 // weights, then f (1-omega) + omega feq -- because the rounding of the weights is a *systematic*
 // mass bias (sum_k fl(w_k) = 1 + 7.5e-9); folding omega into the weights would change that bias
 // and make rho drift away from the reference's by ~3e-8 per step in a periodic box.
-__device__ __forceinline__ void moments_cell(const Cell &c, float &rho, float &ux, float &uy)
+// The arithmetic is written once for a scalar cell (T = float: halo cells, tiles, phase kernels) and for a PAIR of
+// x-adjacent cells (T = f2a: the four cells a lane of the row kernels holds are two such pairs, which live in the aligned
+// 64-bit register pairs of the 16-byte loads -- every operation below is then one v_pk_*_f32, with no component shuffled
+// into place first: left to the SLP vectorizer, the scalar form cost ~30 v_mov per row and stage to re-pair its operands).
+// Same operations, same order, explicit fma: the two instantiations round alike, so a cell gets the same bits whichever
+// form (and whichever kernel) computes it.
+typedef float f2a __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ f2a lb_rcp(f2a x) { return f2a{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ float lb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2a lb_fma(f2a a, f2a b, f2a c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename T>
+__device__ __forceinline__ T lb_splat(float x);
+template <>
+__device__ __forceinline__ float lb_splat<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ f2a lb_splat<f2a>(float x) { return f2a{x, x}; }
+
+template <typename T>
+__device__ __forceinline__ void moments_t(T f0, T f1, T f2, T f3, T f4, T f5, T f6, T f7, T f8, T &rho, T &ux, T &uy)
 {
-    rho = c.f0 + c.f1 + c.f2 + c.f3 + c.f4 + c.f5 + c.f6 + c.f7 + c.f8;
+    rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
     // v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division: the three- and four-step kernels are
     // bound by vector-ALU issue, and OpenCL's own '/' (D2Q9.cl:95-96) is only specified to 2.5 ulp
-    const float inv = __builtin_amdgcn_rcpf(rho);
-    ux = (c.f1 - c.f3 + c.f5 - c.f6 - c.f7 + c.f8) * inv;
-    uy = (c.f5 + c.f2 + c.f6 - c.f7 - c.f4 - c.f8) * inv;
+    const T inv = lb_rcp(rho);
+    // the two diagonal differences are shared by both components: (f1-f3) + (f5-f7) + (f8-f6) and (f2-f4) + (f5-f7) - (f8-f6)
+    // -- 8 additions instead of 10; the reference's left-to-right sums (D2Q9.cl:95-96) differ from this by rounding only
+    const T a = f5 - f7, b = f8 - f6;
+    ux = ((f1 - f3) + a + b) * inv;
+    uy = ((f2 - f4) + a - b) * inv;
+}
+
+// Equilibrium of the two links +-c of one direction, weight class r = fl(w rho): feq = r (base + 4.5 cu^2 +- 3 cu) as
+//   sh = fma(4.5 cu, cu, base);  rs = r sh;  feq+- = fma(+-3r, cu, rs)
+// -- five operations for the pair where r * (base +- 3 cu + 4.5 cu^2) takes eight.  Every product still carries the
+// float32 weight through r (the systematic bias of sum_k fl(w_k), see above, is the reference's); measured on the mass
+// drift of a periodic box (test_periodic_mass_drift_tracks_reference): +8.1e-9 per step against the reference's +8.9e-9,
+// the previous form +8.0e-9; with omega folded into r as well it is +3.5e-9 -- which is why the relaxation below keeps
+// omega * feq as a product of its own.
+template <typename T>
+__device__ __forceinline__ void feq_pair(T r, T r3, T cu, T base, T &fp, T &fm)
+{
+    const T sh = lb_fma(4.5f * cu, cu, base);
+    const T rs = r * sh;
+    fp = lb_fma(r3, cu, rs);
+    fm = lb_fma(-r3, cu, rs);
+}
+
+template <typename T>
+__device__ __forceinline__ void equilibrate_t(T &f0, T &f1, T &f2, T &f3, T &f4, T &f5, T &f6, T &f7, T &f8, float omega, T rho,
+                                              T ux, T uy)
+{
+    const T one = lb_splat<T>(1.f);
+    const T usq = lb_fma(ux, ux, uy * uy);
+    const T base = lb_fma(lb_splat<T>(-1.5f), usq, one);
+    const T keep = lb_splat<T>(1.f - omega), om = lb_splat<T>(omega);
+    const T r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+    const T r13 = 3.f * r1, r23 = 3.f * r2;
+    T e1, e2, e3, e4, e5, e6, e7, e8;
+    feq_pair<T>(r1, r13, ux, base, e1, e3);
+    feq_pair<T>(r1, r13, uy, base, e2, e4);
+    feq_pair<T>(r2, r23, ux + uy, base, e5, e7);
+    feq_pair<T>(r2, r23, ux - uy, base, e8, e6);
+    f0 = lb_fma(f0, keep, om * (r0 * base));
+    f1 = lb_fma(f1, keep, om * e1);
+    f3 = lb_fma(f3, keep, om * e3);
+    f2 = lb_fma(f2, keep, om * e2);
+    f4 = lb_fma(f4, keep, om * e4);
+    f5 = lb_fma(f5, keep, om * e5);
+    f7 = lb_fma(f7, keep, om * e7);
+    f8 = lb_fma(f8, keep, om * e8);
+    f6 = lb_fma(f6, keep, om * e6);
+}
+
+__device__ __forceinline__ void moments_cell(const Cell &c, float &rho, float &ux, float &uy)
+{
+    moments_t<float>(c.f0, c.f1, c.f2, c.f3, c.f4, c.f5, c.f6, c.f7, c.f8, rho, ux, uy);
 }
 
 __device__ __forceinline__ void equilibrate_cell(Cell &c, float omega, float rho, float ux, float uy)
 {
-    const float usq = ux * ux + uy * uy;
-    const float base = 1.f - 1.5f * usq;
-    const float keep = 1.f - omega;
-    const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
-    // inner_k = 1 + 3 cu + 4.5 cu^2 - 1.5 usq
-    c.f0 = c.f0 * keep + omega * (r0 * base);
-    c.f1 = c.f1 * keep + omega * (r1 * (base + 3.f * ux + 4.5f * ux * ux));
-    c.f3 = c.f3 * keep + omega * (r1 * (base - 3.f * ux + 4.5f * ux * ux));
-    c.f2 = c.f2 * keep + omega * (r1 * (base + 3.f * uy + 4.5f * uy * uy));
-    c.f4 = c.f4 * keep + omega * (r1 * (base - 3.f * uy + 4.5f * uy * uy));
-    const float p = ux + uy, m = ux - uy;
-    c.f5 = c.f5 * keep + omega * (r2 * (base + 3.f * p + 4.5f * p * p));
-    c.f7 = c.f7 * keep + omega * (r2 * (base - 3.f * p + 4.5f * p * p));
-    c.f8 = c.f8 * keep + omega * (r2 * (base + 3.f * m + 4.5f * m * m));
-    c.f6 = c.f6 * keep + omega * (r2 * (base - 3.f * m + 4.5f * m * m));
+    equilibrate_t<float>(c.f0, c.f1, c.f2, c.f3, c.f4, c.f5, c.f6, c.f7, c.f8, omega, rho, ux, uy);
 }
 
 __device__ __forceinline__ void relax_cell(Cell &c, float omega, float &rho, float &ux, float &uy)

@@ -239,14 +239,44 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
         }
         return;
     }
+    if (BC == LB_BC_PIPE_I) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-        float rho, ux, uy;
-        finish_cell<BC, MASK>(a, x4 + j, yg - a.y0, c, mk[j] != 0, rho, ux, uy);
-        r4[j] = rho; u4[j] = ux; v4[j] = uy;
-        q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
-        q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+        for (int j = 0; j < 4; ++j) {
+            Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
+            float rho, ux, uy;
+            finish_cell<BC, MASK>(a, x4 + j, yg - a.y0, c, mk[j] != 0, rho, ux, uy);
+            r4[j] = rho; u4[j] = ux; v4[j] = uy;
+            q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
+            q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+        }
+        return;
+    }
+    // the plain families: the four cells as two pairs (d2q9_cell.h, T = f2a), each in the aligned register pair its 16-byte
+    // load put it in; finish_cell's sequence -- obstacle swap, moments, equilibrium, relaxation -- on both cells of a pair at once
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f2a f[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = h ? q[k].zw : q[k].xy;
+        if (MASK) {
+            const bool s0 = mk[2 * h] != 0, s1 = mk[2 * h + 1] != 0;
+            auto swap2 = [&](f2a &p, f2a &o) {              // bounce_cell on a pair: exchange opposite links on solid cells
+                const f2a pp = p, oo = o;
+                p = f2a{s0 ? oo.x : pp.x, s1 ? oo.y : pp.y};
+                o = f2a{s0 ? pp.x : oo.x, s1 ? pp.y : oo.y};
+            };
+            swap2(f[1], f[3]); swap2(f[2], f[4]); swap2(f[5], f[7]); swap2(f[6], f[8]);
+        }
+        f2a rho, ux, uy;
+        moments_t<f2a>(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], rho, ux, uy);
+        equilibrate_t<f2a>(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], a.omega, rho, ux, uy);
+        if (h) { r4.zw = rho; u4.zw = ux; v4.zw = uy; }
+        else   { r4.xy = rho; u4.xy = ux; v4.xy = uy; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (h) q[k].zw = f[k];
+            else q[k].xy = f[k];
+        }
     }
 }
 

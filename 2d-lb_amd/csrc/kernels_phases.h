@@ -100,24 +100,20 @@ __global__ void k_feq_i(const PhaseArgs a)     // D2Q9i.cl:2-64
 }
 
 // Equilibrium of one cell, all nine links: w_k rho (1 + 3 cu + 4.5 cu^2 - 1.5 u^2), written the way the fused kernels'
-// equilibrate_cell writes it -- 1 - 1.5 u^2 once, the weight times rho once per weight class, c.u as +-ux, +-uy, ux +- uy instead of
-// integer velocities times components -- so that the un-fused k_feq, the fused Cython-path passes and the fused OpenCL-path kernels all
-// round alike (k_feq's output is bitwise what k_step's relaxation used).  ~40 vector instructions per cell instead of ~75.
+// equilibrate_cell writes it -- 1 - 1.5 u^2 once, the weight times rho once per weight class, the two links of a direction
+// as a pair (feq_pair, d2q9_cell.h) -- so that the un-fused k_feq, the fused Cython-path passes and the fused OpenCL-path
+// kernels all round alike (k_feq's output is bitwise what k_step's relaxation used).  ~30 vector instructions per cell.
 __device__ __forceinline__ void feq_cell(float rho, float ux, float uy, float (&fe)[9])
 {
-    const float usq = ux * ux + uy * uy;
-    const float base = 1.f - 1.5f * usq;
+    const float usq = lb_fma(ux, ux, uy * uy);
+    const float base = lb_fma(-1.5f, usq, 1.f);
     const float r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+    const float r13 = 3.f * r1, r23 = 3.f * r2;
     fe[0] = r0 * base;
-    fe[1] = r1 * (base + 3.f * ux + 4.5f * ux * ux);
-    fe[3] = r1 * (base - 3.f * ux + 4.5f * ux * ux);
-    fe[2] = r1 * (base + 3.f * uy + 4.5f * uy * uy);
-    fe[4] = r1 * (base - 3.f * uy + 4.5f * uy * uy);
-    const float p = ux + uy, m = ux - uy;
-    fe[5] = r2 * (base + 3.f * p + 4.5f * p * p);
-    fe[7] = r2 * (base - 3.f * p + 4.5f * p * p);
-    fe[8] = r2 * (base + 3.f * m + 4.5f * m * m);
-    fe[6] = r2 * (base - 3.f * m + 4.5f * m * m);
+    feq_pair<float>(r1, r13, ux, base, fe[1], fe[3]);
+    feq_pair<float>(r1, r13, uy, base, fe[2], fe[4]);
+    feq_pair<float>(r2, r23, ux + uy, base, fe[5], fe[7]);
+    feq_pair<float>(r2, r23, ux - uy, base, fe[8], fe[6]);
 }
 
 __global__ void k_feq(const PhaseArgs a)     // D2Q9.cl:2-64
@@ -679,6 +675,103 @@ __global__ void k_halo_unpack(float *origin, long long plane, int pitch, int h, 
     const long long row = north ? h + pos.row[seg] : neg.row[seg];
     float *dst = origin + k * plane + row * pitch + x;
     const float *src = buf + (long long)seg * nx + x;
+    if (V == 4) *reinterpret_cast<f4a *>(dst) = *reinterpret_cast<const f4a *>(src);
+    else *dst = *src;
+}
+
+// ---- peer transport (lb_peer_export / lb_peer_connect): halo rows stored straight into the neighbours' ghost rows -------
+// Every rank owns a block of flags (fine-grained device memory, mapped by both neighbours); one 64-byte line per flag:
+//   READY_FROM_SOUTH / _NORTH  written by that neighbour: 2 e + w = "exchange e may be stored into my lattice w"
+//                              (its kernels that read the ghost rows of exchange e - 1 are complete)
+//   DATA_FROM_SOUTH / _NORTH   written by that neighbour: e = "my rows of exchange e are in your ghost rows"
+//   ERR                        local: a wait gave up (lb_sync reports it)
+//   COUNT, WHICH_S, WHICH_N    local: the exchange counter; the lattice index each neighbour announced for this exchange
+// An exchange on the edge stream: k_peer_pre (announce + wait for the neighbours' announcements), k_halo_push (the
+// stores), k_peer_post (publish + wait for the neighbours' rows).  A rank signals before it waits, in both kernels, and every
+// rank runs the same sequence of exchanges, so nobody waits for somebody who waits for him.  The bulk rows are ordinary
+// stores made visible by the end of k_halo_push (stream order, kernel-boundary release) before k_peer_post publishes
+// them; the kernels that read them start after k_peer_post has seen the flag.  Counters live on the device: the kernel
+// arguments of a cycle never change, so a captured cycle can be replayed.
+enum { PEER_READY_FROM_SOUTH = 0, PEER_READY_FROM_NORTH = 8, PEER_DATA_FROM_SOUTH = 16, PEER_DATA_FROM_NORTH = 24, PEER_ERR = 32,
+       PEER_COUNT = 40, PEER_WHICH_S = 48, PEER_WHICH_N = 56, PEER_FLAG_WORDS = 64 };      // (uint64 indices: 64 bytes apart)
+
+struct PeerArgs {
+    unsigned long long *mine, *south, *north;      // flag blocks: my own, my neighbours' (nullptr = wall)
+    unsigned long long timeout_ticks;              // of the 100 MHz clock
+    int which;                                     // pre: the lattice of mine that receives this exchange
+};
+
+__device__ __forceinline__ void peer_signal(unsigned long long *flag, unsigned long long v)
+{
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spin until *flag >= want (shifted right by `shift` first); returns the value seen, or 0 after the timeout
+__device__ __forceinline__ unsigned long long peer_wait(unsigned long long *flag, unsigned long long want, int shift,
+                                                        unsigned long long timeout_ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((v >> shift) >= want) return v;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) return 0;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+__global__ void k_peer_pre(const PeerArgs p)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long e = p.mine[PEER_COUNT] + 1;
+    p.mine[PEER_COUNT] = e;
+    const unsigned long long v = 2 * e + (unsigned)p.which;
+    if (p.south) peer_signal(p.south + PEER_READY_FROM_NORTH, v);       // (I am my southern neighbour's northern one)
+    if (p.north) peer_signal(p.north + PEER_READY_FROM_SOUTH, v);
+    if (p.south) {
+        const unsigned long long r = peer_wait(p.mine + PEER_READY_FROM_SOUTH, e, 1, p.timeout_ticks);
+        if (!r) p.mine[PEER_ERR] = e;
+        p.mine[PEER_WHICH_S] = r & 1;
+    }
+    if (p.north) {
+        const unsigned long long r = peer_wait(p.mine + PEER_READY_FROM_NORTH, e, 1, p.timeout_ticks);
+        if (!r) p.mine[PEER_ERR] = e;
+        p.mine[PEER_WHICH_N] = r & 1;
+    }
+}
+
+__global__ void k_peer_post(const PeerArgs p)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long e = p.mine[PEER_COUNT];
+    __threadfence_system();
+    if (p.south) peer_signal(p.south + PEER_DATA_FROM_NORTH, e);
+    if (p.north) peer_signal(p.north + PEER_DATA_FROM_SOUTH, e);
+    if (p.south && !peer_wait(p.mine + PEER_DATA_FROM_SOUTH, e, 0, p.timeout_ticks)) p.mine[PEER_ERR] = e;
+    if (p.north && !peer_wait(p.mine + PEER_DATA_FROM_NORTH, e, 0, p.timeout_ticks)) p.mine[PEER_ERR] = e;
+}
+
+// My edge rows -> the neighbours' ghost rows.  Same segment tables as k_halo_pack / k_halo_unpack (entry i of an OUT table
+// pairs with entry i of the neighbour's IN table); the destination lattice of each neighbour is the one it announced.
+struct PeerDst {
+    float *lat[2];          // plane 0, row 0, x 0 of the neighbour's two lattices (mapped into this process); nullptr = wall
+    long long plane, rowp;  // its strides
+    int h;                  // its height (a southern neighbour's north ghost rows start at its row h)
+};
+template <int V>
+__global__ void k_halo_push(const float *origin, long long plane, int pitch, int h, int nx, const unsigned long long *mine,
+                            const PeerDst to_n, const PeerDst to_s, const HaloTable neg, const HaloTable pos)
+{
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * V, seg = blockIdx.y, north = (blockIdx.z == 0);
+    if (x >= nx) return;
+    const PeerDst &d = north ? to_n : to_s;
+    if (!d.lat[0]) return;
+    const int w = (int)mine[north ? PEER_WHICH_N : PEER_WHICH_S];
+    // north edge out = my rows h-D..h-1 (neg, +h) -> its south ghost rows -D..-1 (neg, +0);
+    // south edge out = my rows 0..D-1 (pos) -> its north ghost rows (pos, + its h)
+    const int k = north ? neg.k[seg] : pos.k[seg];
+    const long long rs = north ? h + neg.row[seg] : pos.row[seg];
+    const long long rd = north ? neg.row[seg] : d.h + pos.row[seg];
+    const float *src = origin + k * plane + rs * pitch + x;
+    float *dst = d.lat[w] + k * d.plane + rd * d.rowp + x;
     if (V == 4) *reinterpret_cast<f4a *>(dst) = *reinterpret_cast<const f4a *>(src);
     else *dst = *src;
 }

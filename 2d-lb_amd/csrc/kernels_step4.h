@@ -227,215 +227,306 @@ __device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool
 // (Touching the next row's 90 cache lines a row ahead with two one-lane-per-line loads, instead of the register prefetch
 //  PF below, costs more in the texture addresser than the wait it saves: 243 -> 162 k MLUPS at 8192^2,
 //  profiles/r02_experiments.txt.)
-template <int BC, bool MASK, bool MACRO, bool NTS, bool PF, bool DOWN>
-__device__ __forceinline__ void march4(const StepArgs &a, const int x0, const int ym, const int len, const int wy,
-                                       f4a (*lds_win)[2][9][64], HaloXchg &xchg, const unsigned slot)
-{
-    typedef Dir<DOWN> D;
-    const int lane = threadIdx.x;
-    const int xr = x0 + lane * 4;
-    int x4 = xr;
-    if (BC == LB_BC_PERIODIC && xr >= a.nx) x4 = xr - a.nx;
-    const bool store_lane = xr < a.nx;
-    const bool left = (lane < 32);
-    const int hd = left ? lane + 1 : 64 - lane;         // distance of my halo cell from the strip (1..3 in halo lanes)
-    const bool halo1 = (hd <= 3), halo2 = (hd <= 2), halo3 = (hd == 1);   // lanes taking part in halo stages 1, 2, 3
-    const int hx = left ? x0 - hd : x0 + STRIP_W - 1 + hd;                 // my halo cell
-    const int lane_out = left ? lane + 1 : lane - 1;    // owner of the cell one farther out
-    const int lane_in = left ? max(lane - 1, 0) : min(lane + 1, 63);      // owner of the cell one closer in
-    const int hslot = left ? lane : lane - 56;          // my place in the halo exchange (halo lanes: 0,1,2 | 5,6,7)
-    const long long S = a.plane;
-    const int n_iter = len + 3;
-    auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
-
-    f4a(*W2)[64] = lds_win[wy][0];
-    f4a(*W3)[64] = lds_win[wy][1];
-    f4a(*P2)[64] = lds_win[wy ^ 1][0];                  // the other wave's windows
-    f4a(*P3)[64] = lds_win[wy ^ 1][1];
-    Window w1 = {};
+// Everything one wave's march carries from one iteration to the next (besides the two Row1 buffers of the one-row-ahead gather).
+struct March4State {
+    Window w1;                                          // stage window between steps 1 and 2 (registers)
     // delay lines of MY halo cell: stage 1 (centre, toward, away), stage 2 (centre, toward), stage 3 (toward)
-    Tri s1c = {}, s1t = {}, s1a = {}, s2c = {}, s2t = {}, s3t = {};
+    Tri s1c, s1t, s1a, s2c, s2t, s3t;
     // obstacle-mask history: my four cells (per byte: bit 1 = the row loaded one iteration ago, bit 2 = two, bit 3 = three
     // ago); my halo cell (bit 1, bit 2 likewise)
-    unsigned mhist = 0, hmask = 0;
+    unsigned mhist, hmask;
+};
+// ... and what stays fixed
+struct March4Ctx {
+    int lane, x4, hx, hd, lane_out, lane_in, hslot, ym, n_iter, wy;
+    bool store_lane, left, halo1, halo2, halo3;
+    unsigned slot;
+    f4a (*W2)[64], (*W3)[64], (*P2)[64], (*P3)[64];     // my two LDS windows, the other wave's
+    HaloXchg *xchg;
+};
 
-    // PF: the gather of the next row is issued before the current one is computed, so that a wave does not wait a full
-    // memory latency per row (it spent 25 % of its cycles there: profiles/r02_experiments.txt).  46 more registers: only
-    // the instantiations that stay under 256 without spilling are launched with it (launch_step2_bc).
-    Row1 nxt;
-    if (PF) row1_load<BC, MASK>(a, row_at(0), x4, halo1, hx, nxt);
+// One iteration of the march (see march4 below): loads position i (or takes it from `cur`, gathered an iteration ago, and
+// gathers position i + 1 into `nxt`), step 1 on it, step 2 on position i - 1, step 3 on i - 2, step 4 on i - 3 (stored).
+//
+// STEADY = the iterations 3 <= i < len, where every stage has a row, the row loaded is one of the wave's own (inside the
+// slab: `have` is true), the other wave has nothing to hand over any more and the next position exists: no condition on i is
+// left in the body, so nothing has to be zero-filled "for the branch not taken" and no value is copied into a join register
+// (the generic form spends ~110 v_mov per row on those joins: the q2 / q3 arrays of a stage that may not run yet).  march4
+// runs the steady iterations in PAIRS with the two Row1 buffers swapping roles (PAR = i & 1 is then a constant: the LDS ring
+// slots are immediate offsets), so that "cur = nxt" and the windows' rotation are register names, not moves.
+template <int BC, bool MASK, bool MACRO, bool NTS, bool PF, bool DOWN, int NST>
+__device__ __forceinline__ void march4_iter(const StepArgs &a, const March4Ctx &cx, const int i_, March4State &st, Row1 &cur,
+                                            Row1 &nxt)
+{
+    typedef Dir<DOWN> D;
+    const int lane = cx.lane, x4 = cx.x4;
+    const bool left = cx.left, halo1 = cx.halo1, halo2 = cx.halo2, halo3 = cx.halo3;
+    const int lane_out = cx.lane_out, lane_in = cx.lane_in, hslot = cx.hslot, wy = cx.wy;
+    const long long S = a.plane;
+    const int i = NST < 4 ? NST - 1 : i_;               // (the filling iterations: i is a constant)
+    const int it = i;
+    auto row_at = [&](int p) { return DOWN ? cx.ym - 1 - p : cx.ym + p; };
+    f4a(*W2)[64] = cx.W2;
+    f4a(*W3)[64] = cx.W3;
+    Window &w1 = st.w1;
+
     // Two waves share a SIMD, and its arbiters serve the OLDER one first: measured per wave (tools/wave_timeline.py), the
     // wave in slot 0 of every SIMD finished its 134 rows after ~945 us, the one in slot 1 after ~1190 us, i.e. for the last
     // fifth of the launch every SIMD ran a single wave.  Priority outranks age, so the two take turns: both read the same
     // 100 MHz clock at the top of every fourth row and the wave whose slot parity matches bit 13 of it (82 us per turn, ten
     // rows or so) raises its priority -- complementary at (almost) all times without the waves knowing of each other.
-    for (int i = 0; i < n_iter; ++i) {
-        if (a.prio_turns > 0 && (i & 3) == 0) {        // (every fourth row: reading the clock drains the wave's LDS queue)
-            const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> a.prio_turns) & 1u;
-            if (turn == slot) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        // ---- what the other wave published for "position -1" in its previous iteration ---------------------------
-        if (i >= 1 && i <= 3) {
-            const float *hv = &xchg.v[wy][i - 1][0][hslot];
-            if (i == 1) {
-                w1.g2 = W3[6][lane]; w1.g5 = W3[7][lane]; w1.g6 = W3[8][lane];     // (W3 is idle until iteration 2: a mailbox)
-                if (halo1) { s1c.g = hv[0]; s1t.g = hv[8]; s1a.g = hv[16]; }
-            } else if (i == 2) {
-                if (halo1) { s2c.g = hv[0]; s2t.g = hv[8]; }
-            } else {
-                if (halo1) s3t.g = hv[0];
-            }
-        }
-        // ---- step 1 of position i (from memory) --------------------------------------------------------------------
-        Row1 cur;
-        if (PF) {
-            cur = nxt;
-            if (i + 1 < n_iter) row1_load<BC, MASK>(a, row_at(i + 1), x4, halo1, hx, nxt);
-        } else {
-            row1_load<BC, MASK>(a, row_at(i), x4, halo1, hx, cur);
-        }
-        f4a (&q1)[9] = cur.q;
-        f4a r4, u4, v4;
-        const uc4 mk = cur.mk;
-        const bool hsolid = cur.hsolid;
-        HaloCell9 n1 = {};                              // stage-1 links of my halo cell at position i
-        if (cur.have) {
-            gather_merge<BC>(a, x4, q1, cur.wp);          // (periodic wrap elements: merged here, not behind the loads)
-#ifdef LB_DIAG
-            if (!(a.diag & 1024))
-#endif
-            if (halo1) {
-                Cell c = cur.hc;
-                halo_cell_finish<BC, MASK>(a, cur.hxc, cur.rr, c, hsolid);
-                n1 = halo_all<DOWN>(c, left);
-            }
-#ifdef LB_DIAG
-            if (!(a.diag & 1))
-#endif
-            collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
-        }
-        if (i == 0) {                                   // my position 0 after step 1 -> the other wave's register window
-            lds_publish<DOWN>(P3, lane, 6, q1);
-            if (halo1) {
-                float *hv = &xchg.v[wy ^ 1][0][0][hslot];
-                hv[0] = n1.cm; hv[8] = n1.tm; hv[16] = n1.am;
-            }
-        }
-        // ---- step 2 of position i-1 (window 1, registers) ----------------------------------------------------------
-        f4a q2[9];
-        HaloCell9 n2 = {};                              // stage-2 links of my halo cell at position i-1
-        if (i >= 1) {
-            int r2, t0_, t1_;
-            (void)step1_rows(a, row_at(i - 1), r2, t0_, t1_);
-            stage_gather<DOWN>(w1, q1, s1t, n1.tm, lane, q2);   // (lanes 0 / 63 own the innermost cells)
-            const float w1_d3x = w1.d3.x, w1_d1w = w1.d1.w, w1_g6x = w1.g6.x, w1_g5w = w1.g5.w;   // the halo stage's share
-            // every window takes its new row as soon as its old one has been gathered from, not at the end of the
-            // iteration: q1 / q2 / q3 (36 registers each) then die here instead of living through the stages below
-            window_push_dir<DOWN>(w1, q1);
-            // toward links of the cell farther out, away links of the cell closer in (all lanes take part)
-            Tri tw = {__shfl(s1t.d, lane_out), 0.f, __shfl(s1t.g, lane_out)};
-            const float tm_new = __shfl(n1.tm, lane_out);
-            float a0 = __shfl(s1a.d, lane_in), ap = __shfl(s1a.g, lane_in), am = __shfl(n1.am, lane_in);
-            if (hd == 1) {                              // closer in = my own edge cell
-                a0 = left ? w1_d3x : w1_d1w; ap = left ? w1_g6x : w1_g5w; am = left ? q1[D::Cn].x : q1[D::Bn].w;
-            }
-#ifdef LB_DIAG
-            if (!(a.diag & 1024))
-#endif
-            if (halo2) {
-                Cell c;
-                halo_cell_next<BC, MASK, DOWN>(a, hx, a.y0 + r2, left, (hmask & 2u) != 0, s1c, n1.cm, tw, tm_new, a0, ap, am, c);
-                n2 = halo_all<DOWN>(c, left);
-            }
-#ifdef LB_DIAG
-            if (!(a.diag & 2))
-#endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(mhist, 1), r4, u4, v4);
-            if (i == 1) {                               // my position 0 after step 2 -> the other wave's window 2
-                lds_publish<DOWN>(P2, lane, 3, q2);
-                if (halo1) {
-                    float *hv = &xchg.v[wy ^ 1][1][0][hslot];
-                    hv[0] = n2.cm; hv[8] = n2.tm;
-                }
-            }
-        } else {
-            window_push_dir<DOWN>(w1, q1);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- step 3 of position i-2 (window 2, LDS) ----------------------------------------------------------------
-        f4a q3[9];
-        HaloCell9 n3 = {};                              // stage-3 links of my halo cell at position i-2
-        if (i >= 2) {
-            int r3, t0_, t1_;
-            (void)step1_rows(a, row_at(i - 2), r3, t0_, t1_);
-            Window w2;
-            lds_window_load(W2, lane, i, w2);
-            stage_gather<DOWN>(w2, q2, s2t, n2.tm, lane, q3);
-            const float e0 = left ? w2.d3.x : w2.d1.w, ep = left ? w2.g6.x : w2.g5.w, em = left ? q2[D::Cn].x : q2[D::Bn].w;
-            lds_window_push<DOWN>(W2, lane, i, q2);
-            Tri tw = {__shfl(s2t.d, lane_out), 0.f, __shfl(s2t.g, lane_out)};
-            const float tm_new = __shfl(n2.tm, lane_out);
-#ifdef LB_DIAG
-            if (!(a.diag & 1024))
-#endif
-            if (halo3) {
-                Cell c;
-                halo_cell_next<BC, MASK, DOWN>(a, hx, a.y0 + r3, left, (hmask & 4u) != 0, s2c, n2.cm, tw, tm_new, e0, ep, em, c);
-                n3 = halo_all<DOWN>(c, left);
-            }
-#ifdef LB_DIAG
-            if (!(a.diag & 4))
-#endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(mhist, 2), r4, u4, v4);
-            if (i == 2) {                               // my position 0 after step 3 -> the other wave's window 3
-                lds_publish<DOWN>(P3, lane, 6, q3);
-                if (halo1) xchg.v[wy ^ 1][2][0][hslot] = n3.tm;
-            }
-        } else {
-            if (i == 1) lds_window_push<DOWN>(W2, lane, i, q2);     // (iteration 0 has nothing to push: slots 3..5 belong to the mailbox)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) q3[k] = f4a{0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- step 4 of position i-3 (window 3, LDS), stored --------------------------------------------------------
-        if (i >= 3) {
-            int r4_, t0_, t1_;
-            (void)step1_rows(a, row_at(i - 3), r4_, t0_, t1_);
-            Window w3;
-            lds_window_load(W3, lane, i, w3);
-            f4a t[9];
-            stage_gather<DOWN>(w3, q3, s3t, n3.tm, lane, t);
-            lds_window_push<DOWN>(W3, lane, i, q3);
-#ifdef LB_DIAG
-            if (!(a.diag & 2048))
-#endif
-            collide_row<BC, MASK>(a, x4, a.y0 + r4_, t, mask_bits(mhist, 3), r4, u4, v4);
-            if (store_lane) {
-                const long long o = (long long)r4_ * a.pitch;   // row start, uniform
-                float *d = a.dst + o;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
-                if (MACRO) {
-                    const long long m = (long long)r4_ * a.fpitch;
-                    store4<false>(lane_ptr(a.rho + m, x4), r4);
-                    store4<false>(lane_ptr(a.u + m, x4), u4);
-                    store4<false>(lane_ptr(a.v + m, x4), v4);
-                }
-            }
-        } else if (i == 2) {
-            lds_window_push<DOWN>(W3, lane, i, q3);     // position 0 after step 3: the d slots and ring slot 3 (the other
-        }                                               // wave fills ring slot 6; iterations 0, 1 have nothing to push)
-        // ---- slide the halo cells' delay lines -----------------------------------------------------------------------
-        tri_push(s1c, n1.c0, n1.cp); tri_push(s1t, n1.t0, n1.tp); tri_push(s1a, n1.a0, n1.ap);
-        tri_push(s2c, n2.c0, n2.cp); tri_push(s2t, n2.t0, n2.tp);
-        tri_push(s3t, n3.t0, n3.tp);
-        if (MASK) {
-            mhist = ((mhist | mask_word(mk)) << 1) & 0x0e0e0e0eu;
-            hmask = ((hmask | (hsolid ? 1u : 0u)) << 1) & 0x6u;
-        }
-        if (i <= 2) __syncthreads();                    // what was published in this iteration is consumed in the next
+    if (a.prio_turns > 0 && (i & 3) == 0) {            // (every fourth row: reading the clock drains the wave's LDS queue)
+        const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> a.prio_turns) & 1u;
+        if (turn == cx.slot) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
     }
+    // ---- what the other wave published for "position -1" in its previous iteration ---------------------------
+    if (NST >= 2 && i >= 1 && i <= 3) {
+        const float *hv = &cx.xchg->v[wy][i - 1][0][hslot];
+        if (i == 1) {
+            w1.g2 = W3[6][lane]; w1.g5 = W3[7][lane]; w1.g6 = W3[8][lane];     // (W3 is idle until iteration 2: a mailbox)
+            if (halo1) { st.s1c.g = hv[0]; st.s1t.g = hv[8]; st.s1a.g = hv[16]; }
+        } else if (i == 2) {
+            if (halo1) { st.s2c.g = hv[0]; st.s2t.g = hv[8]; }
+        } else {
+            if (halo1) st.s3t.g = hv[0];
+        }
+    }
+    // ---- step 1 of position i (from memory) --------------------------------------------------------------------
+    if (PF) {
+        // (always: behind the last position the last row is gathered once more -- a cache hit that nobody consumes -- so that
+        //  `nxt` is defined on every path: with "if (i + 1 < n_iter)" the compiler keeps the OLD nxt as the value of the path
+        //  not taken, i.e. copies 50 registers into the join registers at the top of every iteration, behind an
+        //  s_waitcnt vmcnt(0) that also waits for the previous row's nine stores)
+        row1_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, halo1, cx.hx, nxt);
+    } else {
+        row1_load<BC, MASK>(a, row_at(i), x4, halo1, cx.hx, cur);
+    }
+    f4a (&q1)[9] = cur.q;
+    f4a r4, u4, v4;
+    const uc4 mk = cur.mk;
+    const bool hsolid = cur.hsolid;
+    HaloCell9 n1 = {};                              // stage-1 links of my halo cell at position i
+    if (cur.have) {
+        gather_merge<BC>(a, x4, q1, cur.wp);          // (periodic wrap elements: merged here, not behind the loads)
+#ifdef LB_DIAG
+        if (!(a.diag & 1024))
+#endif
+        if (halo1) {
+            Cell c = cur.hc;
+            halo_cell_finish<BC, MASK>(a, cur.hxc, cur.rr, c, hsolid);
+            n1 = halo_all<DOWN>(c, left);
+        }
+#ifdef LB_DIAG
+        if (!(a.diag & 1))
+#endif
+        collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
+    }
+    if (NST == 1) {                        // my position 0 after step 1 -> the other wave's register window
+        lds_publish<DOWN>(cx.P3, lane, 6, q1);
+        if (halo1) {
+            float *hv = &cx.xchg->v[wy ^ 1][0][0][hslot];
+            hv[0] = n1.cm; hv[8] = n1.tm; hv[16] = n1.am;
+        }
+    }
+    // ---- step 2 of position i-1 (window 1, registers) ----------------------------------------------------------
+    f4a q2[9];
+    HaloCell9 n2 = {};                              // stage-2 links of my halo cell at position i-1
+    if (NST >= 2) {
+        int r2, t0_, t1_;
+        (void)step1_rows(a, row_at(i - 1), r2, t0_, t1_);
+        stage_gather<DOWN>(w1, q1, st.s1t, n1.tm, lane, q2);   // (lanes 0 / 63 own the innermost cells)
+        const float w1_d3x = w1.d3.x, w1_d1w = w1.d1.w, w1_g6x = w1.g6.x, w1_g5w = w1.g5.w;   // the halo stage's share
+        // every window takes its new row as soon as its old one has been gathered from, not at the end of the
+        // iteration: q1 / q2 / q3 (36 registers each) then die here instead of living through the stages below
+        window_push_dir<DOWN>(w1, q1);
+        // toward links of the cell farther out, away links of the cell closer in (all lanes take part)
+        Tri tw = {__shfl(st.s1t.d, lane_out), 0.f, __shfl(st.s1t.g, lane_out)};
+        const float tm_new = __shfl(n1.tm, lane_out);
+        float a0 = __shfl(st.s1a.d, lane_in), ap = __shfl(st.s1a.g, lane_in), am = __shfl(n1.am, lane_in);
+        if (cx.hd == 1) {                           // closer in = my own edge cell
+            a0 = left ? w1_d3x : w1_d1w; ap = left ? w1_g6x : w1_g5w; am = left ? q1[D::Cn].x : q1[D::Bn].w;
+        }
+#ifdef LB_DIAG
+        if (!(a.diag & 1024))
+#endif
+        if (halo2) {
+            Cell c;
+            halo_cell_next<BC, MASK, DOWN>(a, cx.hx, a.y0 + r2, left, (st.hmask & 2u) != 0, st.s1c, n1.cm, tw, tm_new, a0, ap, am, c);
+            n2 = halo_all<DOWN>(c, left);
+        }
+#ifdef LB_DIAG
+        if (!(a.diag & 2))
+#endif
+        collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(st.mhist, 1), r4, u4, v4);
+        if (NST == 2) {                    // my position 0 after step 2 -> the other wave's window 2
+            lds_publish<DOWN>(cx.P2, lane, 3, q2);
+            if (halo1) {
+                float *hv = &cx.xchg->v[wy ^ 1][1][0][hslot];
+                hv[0] = n2.cm; hv[8] = n2.tm;
+            }
+        }
+    } else {
+        window_push_dir<DOWN>(w1, q1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q2[k] = f4a{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- step 3 of position i-2 (window 2, LDS) ----------------------------------------------------------------
+    f4a q3[9];
+    HaloCell9 n3 = {};                              // stage-3 links of my halo cell at position i-2
+    if (NST >= 3) {
+        int r3, t0_, t1_;
+        (void)step1_rows(a, row_at(i - 2), r3, t0_, t1_);
+        Window w2;
+        lds_window_load(W2, lane, it, w2);
+        stage_gather<DOWN>(w2, q2, st.s2t, n2.tm, lane, q3);
+        const float e0 = left ? w2.d3.x : w2.d1.w, ep = left ? w2.g6.x : w2.g5.w, em = left ? q2[D::Cn].x : q2[D::Bn].w;
+        lds_window_push<DOWN>(W2, lane, it, q2);
+        Tri tw = {__shfl(st.s2t.d, lane_out), 0.f, __shfl(st.s2t.g, lane_out)};
+        const float tm_new = __shfl(n2.tm, lane_out);
+#ifdef LB_DIAG
+        if (!(a.diag & 1024))
+#endif
+        if (halo3) {
+            Cell c;
+            halo_cell_next<BC, MASK, DOWN>(a, cx.hx, a.y0 + r3, left, (st.hmask & 4u) != 0, st.s2c, n2.cm, tw, tm_new, e0, ep, em, c);
+            n3 = halo_all<DOWN>(c, left);
+        }
+#ifdef LB_DIAG
+        if (!(a.diag & 4))
+#endif
+        collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(st.mhist, 2), r4, u4, v4);
+        if (NST == 3) {                    // my position 0 after step 3 -> the other wave's window 3
+            lds_publish<DOWN>(cx.P3, lane, 6, q3);
+            if (halo1) cx.xchg->v[wy ^ 1][2][0][hslot] = n3.tm;
+        }
+    } else {
+        if (i == 1) lds_window_push<DOWN>(W2, lane, it, q2);    // (iteration 0 has nothing to push: slots 3..5 belong to the mailbox)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q3[k] = f4a{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- step 4 of position i-3 (window 3, LDS), stored --------------------------------------------------------
+    if (NST >= 4) {
+        int r4_, t0_, t1_;
+        (void)step1_rows(a, row_at(i - 3), r4_, t0_, t1_);
+        Window w3;
+        lds_window_load(W3, lane, it, w3);
+        f4a t[9];
+        stage_gather<DOWN>(w3, q3, st.s3t, n3.tm, lane, t);
+        lds_window_push<DOWN>(W3, lane, it, q3);
+#ifdef LB_DIAG
+        if (!(a.diag & 2048))
+#endif
+        collide_row<BC, MASK>(a, x4, a.y0 + r4_, t, mask_bits(st.mhist, 3), r4, u4, v4);
+        if (cx.store_lane) {
+            const long long o = (long long)r4_ * a.pitch;   // row start, uniform
+            float *d = a.dst + o;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
+            if (MACRO) {
+                const long long m = (long long)r4_ * a.fpitch;
+                store4<false>(lane_ptr(a.rho + m, x4), r4);
+                store4<false>(lane_ptr(a.u + m, x4), u4);
+                store4<false>(lane_ptr(a.v + m, x4), v4);
+            }
+        }
+    } else if (i == 2) {
+        lds_window_push<DOWN>(W3, lane, it, q3);    // position 0 after step 3: the d slots and ring slot 3 (the other
+    }                                               // wave fills ring slot 6; iterations 0, 1 have nothing to push)
+    // ---- slide the halo cells' delay lines -----------------------------------------------------------------------
+    tri_push(st.s1c, n1.c0, n1.cp); tri_push(st.s1t, n1.t0, n1.tp); tri_push(st.s1a, n1.a0, n1.ap);
+    tri_push(st.s2c, n2.c0, n2.cp); tri_push(st.s2t, n2.t0, n2.tp);
+    tri_push(st.s3t, n3.t0, n3.tp);
+    if (MASK) {
+        st.mhist = ((st.mhist | mask_word(mk)) << 1) & 0x0e0e0e0eu;
+        st.hmask = ((st.hmask | (hsolid ? 1u : 0u)) << 1) & 0x6u;
+    }
+    if (NST < 4) __syncthreads();         // what was published in this iteration is consumed in the next
+}
+
+// Halo lanes.  The three cells beyond each end of the strip are spread over six lanes -- lanes 0,1,2 own
+// the cells at distance 1,2,3 on the left, lanes 63,62,61 those on the right -- so that one scalar-cell
+// call per stage serves all of them at once (six sequential calls by two lanes made the kernel bound by
+// vector-ALU issue).  A halo cell takes the links moving toward the strip from the lane that owns the
+// cell farther out (`lane_out`) and the links moving away from it from the lane that owns the cell
+// closer in (`lane_in`; for distance 1 that is the strip's own edge cell, in the same lane), through
+// ds_bpermute, which does not occupy the vector ALU.
+//
+// One wave's march: strip [x0, x0 + 256), own rows = `len` rows starting at the pair's middle line `ym` and going up
+// (rows ym .. ym+len-1) or down (rows ym-1 .. ym-len).  Position p of the march = row ym + p / ym - 1 - p; iteration i
+// loads position i and runs step 1 on it, step 2 on position i-1, step 3 on i-2, step 4 on i-3 (stored): len + 3
+// iterations.  What the steps of position 0 pull from "position -1" is the other wave's position 0 (see the header).
+// Iterations 0..2 (the pipeline fills, the two waves hand over across the middle line) and len..len+2 (the three rows beyond
+// the far end, which may lie outside a wall; no next row to gather) run the generic body; the iterations in between, two by
+// two, the steady one (march4_iter).
+// (Touching the next row's 90 cache lines a row ahead with two one-lane-per-line loads, instead of the register prefetch
+//  PF below, costs more in the texture addresser than the wait it saves: 243 -> 162 k MLUPS at 8192^2,
+//  profiles/r02_experiments.txt.)
+template <int BC, bool MASK, bool MACRO, bool NTS, bool PF, bool DOWN>
+__device__ __forceinline__ void march4(const StepArgs &a, const int x0, const int ym, const int len, const int wy,
+                                       f4a (*lds_win)[2][9][64], HaloXchg &xchg, const unsigned slot)
+{
+    March4Ctx cx;
+    cx.lane = threadIdx.x;
+    const int xr = x0 + cx.lane * 4;
+    cx.x4 = xr;
+    if (BC == LB_BC_PERIODIC && xr >= a.nx) cx.x4 = xr - a.nx;
+    cx.store_lane = xr < a.nx;
+    cx.left = (cx.lane < 32);
+    cx.hd = cx.left ? cx.lane + 1 : 64 - cx.lane;    // distance of my halo cell from the strip (1..3 in halo lanes)
+    cx.halo1 = (cx.hd <= 3); cx.halo2 = (cx.hd <= 2); cx.halo3 = (cx.hd == 1);   // lanes taking part in halo stages 1, 2, 3
+    cx.hx = cx.left ? x0 - cx.hd : x0 + STRIP_W - 1 + cx.hd;                     // my halo cell
+    cx.lane_out = cx.left ? cx.lane + 1 : cx.lane - 1;          // owner of the cell one farther out
+    cx.lane_in = cx.left ? max(cx.lane - 1, 0) : min(cx.lane + 1, 63);      // owner of the cell one closer in
+    cx.hslot = cx.left ? cx.lane : cx.lane - 56;     // my place in the halo exchange (halo lanes: 0,1,2 | 5,6,7)
+    cx.ym = ym; cx.n_iter = len + 3; cx.wy = wy; cx.slot = slot;
+    cx.W2 = lds_win[wy][0];
+    cx.W3 = lds_win[wy][1];
+    cx.P2 = lds_win[wy ^ 1][0];                      // the other wave's windows
+    cx.P3 = lds_win[wy ^ 1][1];
+    cx.xchg = &xchg;
+    March4State st = {};
+    auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
+
+    // PF: the gather of the next row is issued before the current one is computed, so that a wave does not wait a full
+    // memory latency per row (it spent 25 % of its cycles there: profiles/r02_experiments.txt).  46 more registers: only
+    // the instantiations that stay under 256 without spilling are launched with it (launch_step2_bc).
+    Row1 ra, rb;
+    if (PF) row1_load<BC, MASK>(a, row_at(0), cx.x4, cx.halo1, cx.hx, ra);
+    // the pipeline fills: iterations 0, 1, 2 run one, two, three stages (every launch gives a wave at least 4 rows: n_iter >= 7)
+    march4_iter<BC, MASK, MACRO, NTS, PF, DOWN, 1>(a, cx, 0, st, ra, PF ? rb : ra);
+    if (PF) ra = rb;
+    march4_iter<BC, MASK, MACRO, NTS, PF, DOWN, 2>(a, cx, 1, st, ra, PF ? rb : ra);
+    if (PF) ra = rb;
+    march4_iter<BC, MASK, MACRO, NTS, PF, DOWN, 3>(a, cx, 2, st, ra, PF ? rb : ra);
+    if (PF) ra = rb;
+    // The full pipeline.  (Round 4 also ran these iterations in PAIRS, the two row buffers swapping roles so that "this row =
+    // the row gathered an iteration ago" is a register name instead of 60 v_mov per row: 927 instead of ~990 vector
+    // instructions per wave and row, no scratch at 251-253 registers -- and 1-1.5 % SLOWER at 8192^2 on every box tried
+    // (17 KB of loop body per direction instead of 9; profiles/r04_experiments.txt).  The kernel is not bound by vector-ALU
+    // issue any more; the pairs are not kept.  PAIRS = true restores them.)
+    constexpr bool PAIRS = false;
+    int i = 3;
+    if (PAIRS) {
+        for (; i + 1 < cx.n_iter; i += 2) {
+            march4_iter<BC, MASK, MACRO, NTS, PF, DOWN, 4>(a, cx, i, st, ra, rb);
+            march4_iter<BC, MASK, MACRO, NTS, PF, DOWN, 4>(a, cx, i + 1, st, rb, ra);
+        }
+    }
+    for (; i < cx.n_iter; ++i) {
+        march4_iter<BC, MASK, MACRO, NTS, PF, DOWN, 4>(a, cx, i, st, ra, PF ? rb : ra);
+        if (PF) ra = rb;
+    }
+}
+
+// Which instantiations gather one row ahead (template flag PF): those that stay within 256 registers without scratch
+// (tools/kernel_resources.py k_step4).
+constexpr bool step4_prefetch(int bc, bool mask, bool macro)
+{
+    // (with a mask: it fits since round 4 -- pipe 254 registers, cavity 256, no scratch -- and buys nothing: config 5
+    //  262 k MLUPS with it, 267 k without, one box: profiles/r04_experiments.txt)
+    // (the D2Q9i fork's launch that also stores rho, u, v: 20 B of scratch with the prefetch)
+    return bc != LB_BC_VELOCITY_INLET && !mask && !(bc == LB_BC_PIPE_I && macro);
 }
 
 template <int BC, bool MASK, bool MACRO, bool NTS, bool PF>

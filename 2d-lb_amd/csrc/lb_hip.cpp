@@ -28,6 +28,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <initializer_list>
@@ -160,6 +161,18 @@ struct lb_sim {
     int graph_key = -1;                    // state the capture is valid for (cur, mask, variant)
     hipStream_t graph_stream = nullptr;
     bool graph_failed = false;
+    // peer transport (lb_peer_export / lb_peer_connect): my flag block, the neighbours' flag blocks and lattices as mapped here
+    unsigned long long *peer_flags = nullptr;
+    bool peer_flags_fine = false;
+    bool peer_connected = false;
+    struct PeerNb {
+        unsigned long long *flags = nullptr;
+        float *lat_raw[2] = {nullptr, nullptr};     // base of the neighbour's allocations as mapped into this process
+        bool mapped = false;                        // (opened through IPC: to be closed; false: the same process / shared with the other side)
+        long long plane = 0, rowp = 0;
+        int h = 0;
+    } peer_nb[2];                                   // [0] = south, [1] = north
+    unsigned long long peer_timeout_ticks = 0;
     int diag = 0;
     int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1..4) chosen by lb_autotune
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
@@ -304,21 +317,22 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
 {
     const int waves = (depth == 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4: the two directions of ONE item (a
                                                            // segment pair); the others: four independent items
-    // k_step4 gathers one row ahead where that fits in 256 registers without scratch: the instantiations without an obstacle
-    // mask (+3 % periodic 8192^2, +-0 pipe; with a mask it spills 20-44 B per lane and loses 10 %: profiles/r02_experiments.txt).
-    // Variant bit 10 switches it off (A/B runs).
-    const bool pf = !s->has_mask && !(effective_variant(s) & 1024);
+    // k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
+    // instantiation without an obstacle mask but the D2Q9i fork's, and -- since the stage rows stopped being joined with zero
+    // rows, round 4 -- the pipe / cavity families with a mask, whose waves waited 28 % of their cycles without it:
+    // profiles/r03_sq_counters.txt).  Variant bit 10 switches it off (A/B runs).
+    const bool pf_on = !(effective_variant(s) & 1024);
     const dim3 block(64, waves), grid(depth == 4 ? items : (items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
-        if (depth == 4 && pf) {                                                                                  \
-            if constexpr (!(MASK))    /* (the prefetching form is only built where it does not spill) */         \
-                hipLaunchKernelGGL((k_step4<BC, false, MACRO, NTS, true>), grid, block, 0, st, a, strips,        \
-                                   seg_rows, nsegs, row_end);                                                    \
-        } else if (depth == 4)                                                                                   \
-            hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips, seg_rows,  \
-                               nsegs, row_end);                                                                  \
-        else if (depth == 3)                                                                                     \
+        if (depth == 4) {                                                                                        \
+            if (step4_prefetch(BC, MASK, MACRO) && pf_on)                                                        \
+                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, step4_prefetch(BC, MASK, MACRO)>), grid, block, 0, st, a, \
+                                   strips, seg_rows, nsegs, row_end);                                            \
+            else                                                                                                 \
+                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips, seg_rows,  \
+                                   nsegs, row_end);                                                              \
+        } else if (depth == 3)                                                                                   \
             hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
                                row_end);                                                                         \
         else                                                                                                     \
@@ -812,6 +826,57 @@ int exchange_rccl(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
     return halo_unpack(s, which, q, T, south >= 0 ? recv_s : nullptr, north >= 0 ? recv_n : nullptr);
 }
 
+// The same exchange over the peer transport: announce, store my edge rows straight into the neighbours' ghost rows, publish
+// (kernels_phases.h: k_peer_pre, k_halo_push, k_peer_post), all on stream q.
+int exchange_peer(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
+{
+    PeerArgs pa;
+    pa.mine = s->peer_flags;
+    pa.south = s->peer_nb[0].flags;
+    pa.north = s->peer_nb[1].flags;
+    pa.timeout_ticks = s->peer_timeout_ticks;
+    pa.which = which;
+    hipLaunchKernelGGL(k_peer_pre, dim3(1), dim3(64), 0, q, pa);
+    HIP_TRY(hipGetLastError());
+    PeerDst dst[2];
+    for (int side = 0; side < 2; ++side) {
+        const lb_sim::PeerNb &nb = s->peer_nb[side];
+        for (int w = 0; w < 2; ++w)
+            dst[side].lat[w] = nb.flags ? nb.lat_raw[w] + GUARD + GHOST * nb.rowp : nullptr;
+        dst[side].plane = nb.plane; dst[side].rowp = nb.rowp; dst[side].h = nb.h;
+    }
+    const bool vec = (s->p.nx % 4) == 0;
+    const dim3 grid((s->p.nx + (vec ? 1023 : 255)) / (vec ? 1024 : 256), T.n, 2);
+    if (vec)
+        hipLaunchKernelGGL(k_halo_push<4>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->rowp, s->H,
+                           s->p.nx, (const unsigned long long *)s->peer_flags, dst[1], dst[0], T.device(true), T.device(false));
+    else
+        hipLaunchKernelGGL(k_halo_push<1>, grid, dim3(256), 0, q, (const float *)s->origin(which), s->plane, (int)s->rowp, s->H,
+                           s->p.nx, (const unsigned long long *)s->peer_flags, dst[1], dst[0], T.device(true), T.device(false));
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_peer_post, dim3(1), dim3(64), 0, q, pa);
+    HIP_TRY(hipGetLastError());
+    return LB_OK;
+}
+
+// halo of lattice `which` to the neighbours, by the transport this handle is attached to
+int exchange_halo(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
+{
+    return s->peer_connected ? exchange_peer(s, which, q, T) : exchange_rccl(s, which, q, T);
+}
+
+// a wait of the peer transport gave up (the neighbour never arrived): reported once the device is idle
+int peer_check_error(lb_sim *s)
+{
+    if (!s->peer_connected) return LB_OK;
+    unsigned long long err = 0;
+    HIP_TRY(hipMemcpy(&err, s->peer_flags + PEER_ERR, sizeof(err), hipMemcpyDeviceToHost));
+    if (err)
+        return fail(LB_ERR_COMM, "peer transport: a neighbour did not arrive at halo exchange %llu within the timeout "
+                                 "(LB_PEER_TIMEOUT_S); the state of this handle is not valid", err);
+    return LB_OK;
+}
+
 // adv (1, 2 or 3) time steps of a slab, edge rows first.  Enqueues on the edge stream (the three
 // rows at each end that the halo is cut from) and on the compute stream (the rest), records ev_boundary
 // when the edge rows of the new lattice are complete and ev_interior when the interior is.  The caller
@@ -1282,6 +1347,18 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipStreamSynchronize(s->stream));
 #undef CREATE_TRY
     s->bytes = 2 * lat_bytes + 3 * fld_bytes + (size_t)s->pitch * s->H;
+    // A periodic box whose width is not a multiple of 4 cannot use the marching kernels (their lanes hold four consecutive
+    // cells, and the wrap at x = nx must fall on a lane boundary): above the Infinity Cache that costs a factor of two or
+    // more (LDS tiles / single steps instead of k_step4).  Say so once instead of being silently slow; LB_QUIET=1 mutes it.
+    if (p->bc_mode == LB_BC_PERIODIC && (p->nx % 4) != 0 && (double)p->nx * s->H >= 1950.0 * 1950.0) {
+        static bool warned = false;
+        if (!warned && !(getenv("LB_QUIET") && atoi(getenv("LB_QUIET")) != 0)) {
+            warned = true;
+            fprintf(stderr, "liblbhip: periodic grid %d x %d: nx is not a multiple of 4, so the multi-step marching kernels do "
+                            "not apply and this grid runs on the slower tile / single-step kernels (pad nx to a multiple of 4 "
+                            "for full speed).\n", p->nx, p->ny);
+        }
+    }
     *out = s;
     return LB_OK;
 }
@@ -1294,6 +1371,13 @@ int lb_destroy(lb_sim *s)
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     drop_graph(s);
+    for (lb_sim::PeerNb &nb : s->peer_nb)
+        if (nb.mapped) {
+            (void)hipIpcCloseMemHandle(nb.flags);
+            for (float *l : nb.lat_raw)
+                if (l) (void)hipIpcCloseMemHandle(l);
+        }
+    if (s->peer_flags) (void)hipFree(s->peer_flags);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner, s->stage})
         if (p) (void)hipFree(p);
@@ -1315,7 +1399,7 @@ int lb_sync(lb_sim *s)
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipStreamSynchronize(s->comm_stream));
     HIP_TRY(hipStreamSynchronize(s->edge_stream));
-    return LB_OK;
+    return peer_check_error(s);
 }
 
 int lb_set_stream(lb_sim *s, void *hip_stream)
@@ -1755,8 +1839,8 @@ int lb_run(lb_sim *s, int n_steps)
         return LB_OK;
     }
     if (!s->multi_slab()) return run_whole_grid(s, n_steps);     // (never blocks the host: tuning is lb_autotune*'s job)
-    if (!s->comm)
-        return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init (or drive lb_step_* yourself)");
+    if (!s->comm && !s->peer_connected)
+        return fail(LB_ERR_STATE, "lb_run on a slab handle needs lb_comm_init or lb_peer_connect (or drive lb_step_* yourself)");
     if (n_steps == 0) return LB_OK;
     if (s->H < 6) return fail(LB_ERR_ARG, "a slab needs at least 6 rows (has %d)", s->H);
     // Two queues.  The edge stream carries the dependency chain of the slab as it is:
@@ -1781,7 +1865,7 @@ int lb_run(lb_sim *s, int n_steps)
         // six-step cycle started the second run's first half from 3-deep ghosts: rows 0 and H-1 wrong one step later --
         // found by tools/ring_stress.py)
         if (s->ghost_depth < (left == D ? D : 2 * D)) {
-            if ((rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
+            if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
             s->ghost_depth = 2 * D;
         }
         for (; left >= 2 * D; left -= 2 * D) {
@@ -1789,7 +1873,7 @@ int lb_run(lb_sim *s, int n_steps)
             s->cur ^= 1;
             if ((rc = slab_cycle_second(s, left == 2 * D, D))) return rc;
             s->cur ^= 1;
-            if ((rc = exchange_rccl(s, s->cur, s->edge_stream, T))) return rc;
+            if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
             s->ghost_depth = 2 * D;
         }
@@ -1806,7 +1890,7 @@ int lb_run(lb_sim *s, int n_steps)
     }
     if (left > 0 && s->ghost_depth < 3) {
         // ghost rows of the current lattice: exchange once before the first step
-        if ((rc = exchange_rccl(s, s->cur, s->edge_stream, HALO3))) return rc;
+        if ((rc = exchange_halo(s, s->cur, s->edge_stream, HALO3))) return rc;
     }
     const bool two = (effective_variant(s) & 32) && step2_applicable(s, hmin);
     const bool three = (effective_variant(s) & 64) && step3_applicable(s, hmin);
@@ -1817,7 +1901,7 @@ int lb_run(lb_sim *s, int n_steps)
         if ((rc = slab_step_launch(s, adv, left == adv))) return rc;
         // 2. halo of the lattice just written, behind the edge kernel on its stream (RCCL over xGMI),
         //    while the interior is still being computed
-        if ((rc = exchange_rccl(s, s->cur ^ 1, s->edge_stream, HALO3))) return rc;
+        if ((rc = exchange_halo(s, s->cur ^ 1, s->edge_stream, HALO3))) return rc;
         // 3. the next launches read the new lattice
         HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
         HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
@@ -2132,6 +2216,124 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
         HIP_TRY(hipStreamSynchronize(s->edge_stream));
     }
     s->ghost_depth = 0;
+    return LB_OK;
+}
+
+// ---- peer transport ----------------------------------------------------------------------
+namespace {
+struct PeerDesc {                      // what lb_peer_export hands out (<= LB_PEER_HANDLE_BYTES)
+    uint32_t magic, version;
+    int32_t pid, device;
+    int32_t nx, ny, h, planar;
+    int64_t pitch, rowp, plane, lat_floats;
+    uint64_t self_lat[2], self_flags;  // the exporter's own pointers: meaningful inside the exporting process only
+    hipIpcMemHandle_t lat[2], flags;
+};
+static_assert(sizeof(PeerDesc) <= LB_PEER_HANDLE_BYTES, "LB_PEER_HANDLE_BYTES too small");
+constexpr uint32_t PEER_MAGIC = 0x4c425052u;    // "LBPR"
+}  // namespace
+
+int lb_peer_export(lb_sim *s, void *handle_out)
+{
+    if (!s || !handle_out) return fail(LB_ERR_ARG, "null argument");
+    if (!s->multi_slab()) return fail(LB_ERR_STATE, "lb_peer_export needs a slab handle (LB_FLAG_HALO)");
+    DeviceGuard guard(s->p.device);
+    if (!s->peer_flags) {
+        // fine-grained device memory: the neighbours' system-scope stores must become visible to a kernel that is already
+        // running here (the bulk rows, ordinary coarse-grained memory, only have to be visible at kernel boundaries)
+        void *f = nullptr;
+        const size_t bytes = sizeof(unsigned long long) * PEER_FLAG_WORDS;
+        if (hipExtMallocWithFlags(&f, bytes, hipDeviceMallocFinegrained) == hipSuccess) s->peer_flags_fine = true;
+        else {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&f, bytes));
+        }
+        s->peer_flags = static_cast<unsigned long long *>(f);
+        HIP_TRY(hipMemset(s->peer_flags, 0, bytes));
+    }
+    PeerDesc d;
+    memset(&d, 0, sizeof(d));
+    d.magic = PEER_MAGIC; d.version = LB_ABI_VERSION;
+    d.pid = (int32_t)getpid(); d.device = s->p.device;
+    d.nx = s->p.nx; d.ny = s->p.ny; d.h = s->H; d.planar = (s->p.flags & LB_FLAG_PLANAR) ? 1 : 0;
+    d.pitch = s->pitch; d.rowp = s->rowp; d.plane = s->plane; d.lat_floats = s->lat_floats;
+    d.self_lat[0] = (uint64_t)(uintptr_t)s->lat[0]; d.self_lat[1] = (uint64_t)(uintptr_t)s->lat[1];
+    d.self_flags = (uint64_t)(uintptr_t)s->peer_flags;
+    HIP_TRY(hipIpcGetMemHandle(&d.lat[0], s->lat[0]));
+    HIP_TRY(hipIpcGetMemHandle(&d.lat[1], s->lat[1]));
+    if (hipIpcGetMemHandle(&d.flags, s->peer_flags) != hipSuccess && s->peer_flags_fine) {
+        // (a runtime that cannot export fine-grained memory: fall back to an ordinary allocation -- enough between processes
+        //  that share one GPU, where the flags meet in that GPU's own memory)
+        (void)hipGetLastError();
+        (void)hipFree(s->peer_flags);
+        s->peer_flags = nullptr;
+        s->peer_flags_fine = false;
+        void *f = nullptr;
+        HIP_TRY(hipMalloc(&f, sizeof(unsigned long long) * PEER_FLAG_WORDS));
+        s->peer_flags = static_cast<unsigned long long *>(f);
+        HIP_TRY(hipMemset(s->peer_flags, 0, sizeof(unsigned long long) * PEER_FLAG_WORDS));
+        d.self_flags = (uint64_t)(uintptr_t)s->peer_flags;
+        HIP_TRY(hipIpcGetMemHandle(&d.flags, s->peer_flags));
+    }
+    memset(handle_out, 0, LB_PEER_HANDLE_BYTES);
+    memcpy(handle_out, &d, sizeof(d));
+    return LB_OK;
+}
+
+int lb_peer_connect(lb_sim *s, int rank, int nranks, const void *south_handle, const void *north_handle, int min_h)
+{
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks || min_h < 1) return fail(LB_ERR_ARG, "bad argument");
+    if (!s->peer_flags) return fail(LB_ERR_STATE, "lb_peer_connect before lb_peer_export");
+    if (s->peer_connected || s->comm) return fail(LB_ERR_STATE, "this handle already has a halo transport");
+    DeviceGuard guard(s->p.device);
+    const void *handles[2] = {south_handle, north_handle};
+    PeerDesc d[2];
+    for (int side = 0; side < 2; ++side) {
+        if (!handles[side]) continue;
+        memcpy(&d[side], handles[side], sizeof(PeerDesc));
+        const PeerDesc &e = d[side];
+        if (e.magic != PEER_MAGIC || e.version != LB_ABI_VERSION)
+            return fail(LB_ERR_ARG, "not a peer descriptor of this library version");
+        if (e.nx != s->p.nx || e.ny != s->p.ny || e.pitch != s->pitch || e.planar != ((s->p.flags & LB_FLAG_PLANAR) ? 1 : 0))
+            return fail(LB_ERR_ARG, "the %s neighbour's lattice has another geometry or layout", side ? "north" : "south");
+    }
+    for (int side = 0; side < 2; ++side) {
+        lb_sim::PeerNb &nb = s->peer_nb[side];
+        if (!handles[side]) continue;
+        const PeerDesc &e = d[side];
+        nb.plane = e.plane; nb.rowp = e.rowp; nb.h = e.h;
+        if (e.pid == (int32_t)getpid()) {              // exported by this process (a ring that closes on itself): use it in place
+            nb.flags = reinterpret_cast<unsigned long long *>((uintptr_t)e.self_flags);
+            nb.lat_raw[0] = reinterpret_cast<float *>((uintptr_t)e.self_lat[0]);
+            nb.lat_raw[1] = reinterpret_cast<float *>((uintptr_t)e.self_lat[1]);
+            continue;
+        }
+        if (side == 1 && handles[0] && d[0].pid == e.pid && d[0].self_flags == e.self_flags) {
+            // two ranks in a periodic box: both neighbours are the same peer; one mapping serves both sides
+            nb.flags = s->peer_nb[0].flags; nb.lat_raw[0] = s->peer_nb[0].lat_raw[0]; nb.lat_raw[1] = s->peer_nb[0].lat_raw[1];
+            continue;
+        }
+        void *m = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&m, e.flags, hipIpcMemLazyEnablePeerAccess));
+        nb.flags = static_cast<unsigned long long *>(m);
+        nb.mapped = true;
+        for (int w = 0; w < 2; ++w) {
+            HIP_TRY(hipIpcOpenMemHandle(&m, e.lat[w], hipIpcMemLazyEnablePeerAccess));
+            nb.lat_raw[w] = static_cast<float *>(m);
+        }
+    }
+    if (!s->halo_buf) {       // (lb_check's scratch and the launch-by-launch fallback share it with the RCCL path)
+        HIP_TRY(hipMalloc(&s->halo_buf, sizeof(float) * 4 * HALO_SEGS_DEEP * s->p.nx));
+        s->bytes += sizeof(float) * 4 * HALO_SEGS_DEEP * s->p.nx;
+    }
+    double timeout_s = 20.0;
+    if (const char *t = getenv("LB_PEER_TIMEOUT_S")) timeout_s = atof(t) > 0 ? atof(t) : timeout_s;
+    s->peer_timeout_ticks = (unsigned long long)(timeout_s * 1e8);         // s_memrealtime: 100 MHz
+    s->rank = rank;
+    s->nranks = nranks;
+    s->min_h = min_h;
+    s->ghost_depth = 0;
+    s->peer_connected = true;
     return LB_OK;
 }
 

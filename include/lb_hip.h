@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 5
+#define LB_ABI_VERSION 6
 
 typedef enum {
     LB_OK = 0,
@@ -216,6 +216,29 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps);
 int lb_comm_available(void);               /* 0 when librccl can be loaded in this process (no communicator is made) */
 int lb_comm_unique_id(void *unique_id_128);
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
+
+/* Peer transport: the halo rows are stored DIRECTLY into the neighbours' ghost rows, through device memory mapped from
+ * one rank's process into the other's (hipIpcMemHandle; over xGMI between GPUs, plain device memory between processes that
+ * share a GPU), and the ranks meet at device-side flags (sequence numbers in fine-grained device memory, written with
+ * system-scope release stores by the neighbour's kernels, polled by one lane) -- no packing, no unpacking, no library
+ * call on the data path, nothing the host waits for: the alternative SURVEY.md section 8(e) lists beside RCCL (the
+ * reference itself is single-device: opencl_dim.py:229-240).  lb_run's schedule is the one it runs over RCCL.
+ *   lb_peer_export   fills LB_PEER_HANDLE_BYTES with this handle's descriptor (IPC handles of its two lattices and its
+ *                    flag block, its geometry).  The caller carries it to the two neighbouring ranks by any means
+ *                    (torch.distributed all_gather of bytes, a file, a pipe).
+ *   lb_peer_connect  maps the neighbours (NULL = wall; south = rank-1, north = rank+1, wrapping for PERIODIC; a
+ *                    descriptor exported by THIS process is used in place, so a 1-rank periodic ring talks to itself) and
+ *                    switches lb_run on this handle to the peer transport.  min_h = the smallest slab height over all ranks
+ *                    (decides the kernels and the exchange rhythm; every rank passes the same number).  Not a collective by
+ *                    itself, but every rank must have exported before anyone connects, and all ranks must call lb_run with
+ *                    the same step counts (as over RCCL).
+ * A rank whose neighbour does not arrive within LB_PEER_TIMEOUT_S seconds (environment, default 20) gives up waiting on
+ * the device, and the next lb_sync / lb_check on that handle fails with LB_ERR_COMM.  One handle per process and GPU (a
+ * handle waits on the device for its neighbours' kernels: several such handles in ONE process could share a hardware
+ * queue and wait for each other forever -- lb_run_group is the in-process stand-in). */
+#define LB_PEER_HANDLE_BYTES 384
+int lb_peer_export(lb_sim *s, void *handle_out);
+int lb_peer_connect(lb_sim *s, int rank, int nranks, const void *south_handle, const void *north_handle, int min_h);
 
 /* ---- health check (the reference's forks warn when max |u| exceeds a tenth of the speed of sound,
  *      porous_media/single_component.py:221-225, and print field sums while debugging, check_fields() :753-766; the

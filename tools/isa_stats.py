@@ -60,7 +60,7 @@ def main():
         sys.exit(1)
     for line in r.stderr.splitlines():
         m = re.search(r"remark: (.*?)\s*\[-Rpass", line)
-        if m and re.search(r"VGPRs:|AGPRs|Scratch|Occupancy|LDS Size|SGPRs:", m.group(1)):
+        if m and re.search(r"VGPRs:|AGPRs|Scratch|Occupancy|LDS Size|SGPRs|Spill", m.group(1)):
             print("  ", m.group(1).strip())
     asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
     lines = open(os.path.join(tmp, asm)).read().splitlines()
