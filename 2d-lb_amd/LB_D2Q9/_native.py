@@ -14,6 +14,7 @@ LB_FLAG_PLANAR = 2
 LB_FLAG_EAGER_MACRO = 4
 LB_MASK_HALO_ROWS = 7
 LB_PEER_HANDLE_BYTES = 384
+LB_DEVICE_CPU = -1
 LB_SEM_OPENCL, LB_SEM_CYTHON, LB_SEM_OPENCL_D2Q9I = 0, 1, 2
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
             "velocity_inlet": LB_BC_VELOCITY_INLET}
@@ -30,7 +31,7 @@ EXPORTS = (
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group", "lb_run_batch",
     "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
     "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state", "lb_check", "lb_set_debug_sync",
-    "lb_peer_export", "lb_peer_connect",
+    "lb_peer_export", "lb_peer_connect", "lb_set_params_f64",
 )
 
 
@@ -87,6 +88,7 @@ def lib():
     if not older:
         L.lb_peer_export.argtypes = [h, vp]
         L.lb_peer_connect.argtypes = [h, I, I, vp, vp, I]
+        L.lb_set_params_f64.argtypes = [h, ct.c_double, ct.c_double, ct.c_double]
     L.lb_comm_init.argtypes = [h, vp, I, I]
     L.lb_timer_stop.argtypes = [h, fp]
     L.lb_layout.argtypes = [h, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64)]

@@ -62,6 +62,9 @@ class Simulation(object):
         :param inlet_u, outlet_u: bc='velocity_inlet' (D2Q9.cl:263-374; un-fused kernels): imposed speed at
                x=0 / x=nx-1 (outlet_u defaults to inlet_u, as OLD/opencl.py:283-286 sets u_e = u_w).
         :param obstacle_mask: optional (nx, ny) array, non-zero = solid (bounce-back, D2Q9.cl:398-433).
+        :param device: HIP device ordinal; -1 (LB_DEVICE_CPU) = the product's own CPU backend: semantics='cython', bc='pipe',
+               whole grid, single thread, the reference's mixed float32 / float64 arithmetic (include/lb_hip.h).  Chosen by
+               this value only: a GPU handle never falls back to the host.
         :param y0, local_ny: the row slab this object owns (multi-GPU); default = whole grid.
         :param halo: fill the ghost rows through the halo interface even for a whole-grid handle.
         :param semantics: 'opencl' (D2Q9.cl, fused fast path), 'cython' (cython_dim.pyx: pipe family, whole grid,
@@ -109,6 +112,9 @@ class Simulation(object):
         p.inlet_u, p.outlet_u = np.float32(self.inlet_u), np.float32(self.outlet_u)
         self._h = ct.c_void_p()
         check(self._lib.lb_create(ct.byref(p), ct.byref(self._h)))
+        if self.device == _native.LB_DEVICE_CPU:
+            # the CPU backend keeps the reference's float64 scalars (lb_params carries float32: include/lb_hip.h)
+            check(self._lib.lb_set_params_f64(self._h, float(omega), float(inlet_rho), float(outlet_rho)))
         self._shape2 = (self.nx, self.local_ny)
         self._shape3 = (self.nx, self.local_ny, NUM_JUMPERS)
         self._mask_host = None

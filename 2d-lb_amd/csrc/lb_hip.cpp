@@ -39,6 +39,7 @@
 #include <string.h>
 
 #include "../../include/lb_hip.h"
+#include "cpu_backend.h"
 
 namespace {
 
@@ -132,6 +133,7 @@ int rccl_load()
 // ------------------------------------------------------------------------------------------
 struct lb_sim {
     lb_params p;
+    lbcpu::CpuPipe *cpu = nullptr;   // device = LB_DEVICE_CPU: the host backend (cpu_backend.h); every device member below stays empty
     int H = 0;                  // rows owned
     long long pitch = 0, rowp = 0, plane = 0, lat_floats = 0;   // padded row width; lattice row / plane strides; floats per lattice
     float *lat[2] = {nullptr, nullptr};   // raw allocations (with guards)
@@ -173,6 +175,12 @@ struct lb_sim {
         int h = 0;
     } peer_nb[2];                                   // [0] = south, [1] = north
     unsigned long long peer_timeout_ticks = 0;
+    // CYCLE_GRAPH_CYCLES halo cycles of lb_run captured into one hipGraph (peer transport; LB_CYCLE_GRAPH=1)
+    hipGraph_t cyc_graph = nullptr;
+    hipGraphExec_t cyc_exec = nullptr;
+    int cyc_key = -1;
+    bool cyc_failed = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int diag = 0;
     int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1..4) chosen by lb_autotune
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
@@ -190,6 +198,12 @@ struct DeviceGuard {
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); (void)hipSetDevice(dev); }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// Handles of the CPU backend: an entry point either has a host form or refuses.
+#define CPU_UNSUPPORTED(s, name)                                                                            \
+    do {                                                                                                    \
+        if ((s) && (s)->cpu) return fail(LB_ERR_STATE, "%s is not available on the CPU backend", name);      \
+    } while (0)
 
 // boundary family as the kernels' template argument (the D2Q9i fork is the PIPE family with its own cell routines)
 int kernel_bc(const lb_sim *s) { return s->p.semantics == LB_SEM_OPENCL_D2Q9I ? LB_BC_PIPE_I : s->p.bc_mode; }
@@ -1263,6 +1277,21 @@ int lb_create(const lb_params *p, lb_sim **out)
     if (p->semantics == LB_SEM_CYTHON &&
         (p->bc_mode != LB_BC_PIPE || p->local_ny != p->ny || (p->flags & LB_FLAG_HALO)))
         return fail(LB_ERR_ARG, "Cython-path semantics exist for whole-grid pipe-flow handles only");
+    if (p->device == LB_DEVICE_CPU) {
+        // the CPU backend: asked for by name, never chosen for the caller (include/lb_hip.h, LB_DEVICE_CPU)
+        if (p->semantics != LB_SEM_CYTHON || p->bc_mode != LB_BC_PIPE || p->local_ny != p->ny || p->y0 != 0 || p->flags != 0)
+            return fail(LB_ERR_ARG, "the CPU backend runs whole-grid pipe flow in Cython-path semantics (LB_SEM_CYTHON) only");
+        lb_sim *s = new lb_sim();
+        s->p = *p;
+        s->H = p->ny;
+        s->cpu = new lbcpu::CpuPipe();
+        s->cpu->resize(p->nx, p->ny);
+        s->cpu->omega = (double)p->omega;           // (the ABI carries float32 parameters: the reference's np.float64 values
+        s->cpu->rho_in = (double)p->inlet_rho;      //  rounded once, as on the GPU path)
+        s->cpu->rho_out = (double)p->outlet_rho;
+        *out = s;
+        return LB_OK;
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(LB_ERR_HIP, "no HIP device visible");
@@ -1365,12 +1394,21 @@ int lb_create(const lb_params *p, lb_sim **out)
 
 int lb_destroy(lb_sim *s)
 {
+    if (s && s->cpu) {
+        delete s->cpu;
+        delete s;
+        return LB_OK;
+    }
     if (!s) return LB_OK;
     DeviceGuard guard(s->p.device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->edge_stream) (void)hipStreamSynchronize(s->edge_stream);
     drop_graph(s);
+    if (s->cyc_exec) (void)hipGraphExecDestroy(s->cyc_exec);
+    if (s->cyc_graph) (void)hipGraphDestroy(s->cyc_graph);
+    for (hipEvent_t e : {s->ev_fork, s->ev_join})
+        if (e) (void)hipEventDestroy(e);
     for (lb_sim::PeerNb &nb : s->peer_nb)
         if (nb.mapped) {
             (void)hipIpcCloseMemHandle(nb.flags);
@@ -1392,8 +1430,20 @@ int lb_destroy(lb_sim *s)
     return LB_OK;
 }
 
+int lb_set_params_f64(lb_sim *s, double omega, double inlet_rho, double outlet_rho)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (!s->cpu) return fail(LB_ERR_STATE, "lb_set_params_f64 is for handles of the CPU backend (the device kernels compute in float32)");
+    if (!(omega > 0. && omega < 2.)) return fail(LB_ERR_ARG, "omega must be in (0,2), got %g", omega);
+    s->cpu->omega = omega;
+    s->cpu->rho_in = inlet_rho;
+    s->cpu->rho_out = outlet_rho;
+    return LB_OK;
+}
+
 int lb_sync(lb_sim *s)
 {
+    if (s && s->cpu) return LB_OK;                 // (the host backend is synchronous)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1404,6 +1454,7 @@ int lb_sync(lb_sim *s)
 
 int lb_set_stream(lb_sim *s, void *hip_stream)
 {
+    CPU_UNSUPPORTED(s, "lb_set_stream");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1413,6 +1464,7 @@ int lb_set_stream(lb_sim *s, void *hip_stream)
 
 int lb_set_variant(lb_sim *s, int variant)
 {
+    if (s && s->cpu) return LB_OK;                 // (one code path: nothing to select)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     s->variant = variant;
     return LB_OK;
@@ -1420,6 +1472,12 @@ int lb_set_variant(lb_sim *s, int variant)
 
 int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated)
 {
+    if (s && s->cpu) {
+        if (pitch) *pitch = s->cpu->nx;
+        if (plane_stride) *plane_stride = (int64_t)s->cpu->plane();
+        if (bytes_allocated) *bytes_allocated = (int64_t)s->cpu->plane() * (18 * 4 + 4 + 16 + 1);
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (pitch) *pitch = s->pitch;
     if (plane_stride) *plane_stride = s->plane;
@@ -1430,6 +1488,12 @@ int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_a
 // ---- state transfer ----------------------------------------------------------------------
 int lb_set_macro(lb_sim *s, const float *rho, const float *u, const float *v)
 {
+    if (s && s->cpu) {
+        if (!rho || !u || !v) return fail(LB_ERR_ARG, "null argument");
+        const size_t n = s->cpu->plane();
+        for (size_t c = 0; c < n; ++c) { s->cpu->rho[c] = rho[c]; s->cpu->u[c] = u[c]; s->cpu->v[c] = v[c]; }
+        return LB_OK;
+    }
     if (!s || !rho || !u || !v) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     int rc;
@@ -1443,6 +1507,15 @@ int lb_set_macro(lb_sim *s, const float *rho, const float *u, const float *v)
 
 int lb_get_macro(lb_sim *s, float *rho, float *u, float *v)
 {
+    if (s && s->cpu) {
+        const size_t n = s->cpu->plane();
+        for (size_t c = 0; c < n; ++c) {
+            if (rho) rho[c] = s->cpu->rho[c];
+            if (u) u[c] = (float)s->cpu->u[c];
+            if (v) v[c] = (float)s->cpu->v[c];
+        }
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     int rc;
@@ -1456,6 +1529,11 @@ int lb_get_macro(lb_sim *s, float *rho, float *u, float *v)
 
 int lb_set_f(lb_sim *s, const float *f)
 {
+    if (s && s->cpu) {
+        if (!f) return fail(LB_ERR_ARG, "null argument");
+        memcpy(s->cpu->f.data(), f, sizeof(float) * 9 * s->cpu->plane());
+        return LB_OK;
+    }
     if (!s || !f) return fail(LB_ERR_ARG, "null argument");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_set_f between lb_step_boundary and lb_step_finish");
     DeviceGuard guard(s->p.device);
@@ -1477,6 +1555,11 @@ int lb_set_f(lb_sim *s, const float *f)
 
 int lb_get_f(lb_sim *s, float *f)
 {
+    if (s && s->cpu) {
+        if (!f) return fail(LB_ERR_ARG, "null argument");
+        memcpy(f, s->cpu->f.data(), sizeof(float) * 9 * s->cpu->plane());
+        return LB_OK;
+    }
     if (!s || !f) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipStreamSynchronize(s->comm_stream));
@@ -1491,6 +1574,7 @@ int lb_get_f(lb_sim *s, float *f)
 
 int lb_get_corner_state(lb_sim *s, float *out8)
 {
+    CPU_UNSUPPORTED(s, "lb_get_corner_state");
     if (!s || !out8) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipMemcpyAsync(out8, s->vi_corner, 8 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -1500,6 +1584,7 @@ int lb_get_corner_state(lb_sim *s, float *out8)
 
 int lb_set_corner_state(lb_sim *s, const float *in8)
 {
+    CPU_UNSUPPORTED(s, "lb_set_corner_state");
     if (!s || !in8) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipMemcpyAsync(s->vi_corner, in8, 8 * sizeof(float), hipMemcpyHostToDevice, s->stream));
@@ -1512,6 +1597,11 @@ int lb_steps_per_launch(lb_sim *s);
 
 int lb_get_feq(lb_sim *s, float *feq)
 {
+    if (s && s->cpu) {
+        if (!feq) return fail(LB_ERR_ARG, "null argument");
+        memcpy(feq, s->cpu->feq.data(), sizeof(float) * 9 * s->cpu->plane());     // (as the reference's feq array: whatever update_feq left)
+        return LB_OK;
+    }
     if (!s || !feq) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     int rc;
@@ -1525,6 +1615,12 @@ int lb_get_feq(lb_sim *s, float *feq)
 
 int lb_set_mask(lb_sim *s, const int32_t *mask)
 {
+    if (s && s->cpu) {
+        s->cpu->has_mask = mask != nullptr;
+        s->cpu->mask.assign(s->cpu->plane(), 0);
+        for (size_t c = 0; mask && c < s->cpu->plane(); ++c) s->cpu->mask[c] = mask[c] == 1;
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     if (!mask) {
@@ -1557,6 +1653,7 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
 
 int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_rows)
 {
+    CPU_UNSUPPORTED(s, "lb_set_mask_halo");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     uint8_t *tmp = (uint8_t *)calloc((size_t)s->pitch * MASK_GHOST, 1);
@@ -1594,6 +1691,7 @@ static dim3 cells_grid(const lb_sim *s, int nz) { return dim3((s->p.nx + 255) / 
 
 int lb_move(lb_sim *s)
 {
+    if (s && s->cpu) { s->cpu->move(); return LB_OK; }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int rc = need_single_slab(s, "lb_move");
     if (rc) return rc;
@@ -1622,6 +1720,7 @@ int lb_move(lb_sim *s)
 
 int lb_move_bcs(lb_sim *s)
 {
+    if (s && s->cpu) { s->cpu->move_bcs(); return LB_OK; }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int rc = need_single_slab(s, "lb_move_bcs");
     if (rc) return rc;
@@ -1641,6 +1740,7 @@ int lb_move_bcs(lb_sim *s)
 
 int lb_update_hydro(lb_sim *s)
 {
+    if (s && s->cpu) { s->cpu->update_hydro(); return LB_OK; }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int rc = need_single_slab(s, "lb_update_hydro");
     if (rc) return rc;
@@ -1663,6 +1763,7 @@ int lb_update_hydro(lb_sim *s)
 
 int lb_update_feq(lb_sim *s)
 {
+    if (s && s->cpu) { s->cpu->update_feq(); return LB_OK; }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     int rc = ensure_feq(s);
@@ -1681,6 +1782,7 @@ int lb_update_feq(lb_sim *s)
 
 int lb_collide_particles(lb_sim *s)
 {
+    if (s && s->cpu) { s->cpu->collide(); return LB_OK; }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int rc = need_single_slab(s, "lb_collide_particles");
     if (rc) return rc;
@@ -1694,6 +1796,11 @@ int lb_collide_particles(lb_sim *s)
 
 int lb_zero_velocity_in_obstacle(lb_sim *s)
 {
+    if (s && s->cpu) {
+        for (size_t c = 0; s->cpu->has_mask && c < s->cpu->plane(); ++c)
+            if (s->cpu->mask[c]) { s->cpu->u[c] = 0.; s->cpu->v[c] = 0.; }
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (!s->has_mask) return LB_OK;
     DeviceGuard guard(s->p.device);
@@ -1709,6 +1816,10 @@ int lb_zero_velocity_in_obstacle(lb_sim *s)
 
 int lb_init_pop(lb_sim *s)
 {
+    if (s && s->cpu) {                               // f = feq (cython_dim.pyx:191-197; the perturbation is the host class's)
+        s->cpu->f = s->cpu->feq;
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     int rc;
@@ -1722,6 +1833,7 @@ int lb_init_pop(lb_sim *s)
 // ---- fused stepping ----------------------------------------------------------------------
 int lb_step_boundary(lb_sim *s, int write_macro)
 {
+    CPU_UNSUPPORTED(s, "lb_step_boundary");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_step_boundary called twice");
     if (s->p.bc_mode == LB_BC_VELOCITY_INLET || s->p.semantics == LB_SEM_CYTHON)
@@ -1736,6 +1848,7 @@ int lb_step_boundary(lb_sim *s, int write_macro)
 
 int lb_step_interior(lb_sim *s, int write_macro)
 {
+    CPU_UNSUPPORTED(s, "lb_step_interior");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (!s->stepping) return fail(LB_ERR_STATE, "lb_step_interior before lb_step_boundary");
     DeviceGuard guard(s->p.device);
@@ -1744,6 +1857,7 @@ int lb_step_interior(lb_sim *s, int write_macro)
 
 int lb_step_finish(lb_sim *s)
 {
+    CPU_UNSUPPORTED(s, "lb_step_finish");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (!s->stepping) return fail(LB_ERR_STATE, "lb_step_finish before lb_step_boundary");
     s->cur ^= 1;
@@ -1756,6 +1870,7 @@ int lb_step_finish(lb_sim *s)
 
 int lb_halo_export(lb_sim *s, int side, void *buf)
 {
+    CPU_UNSUPPORTED(s, "lb_halo_export");
     if (!s || !buf || side < 0 || side > 1) return fail(LB_ERR_ARG, "bad argument");
     DeviceGuard guard(s->p.device);
     const int which = s->stepping ? (s->cur ^ 1) : s->cur;
@@ -1768,6 +1883,7 @@ int lb_halo_export(lb_sim *s, int side, void *buf)
 
 int lb_halo_import(lb_sim *s, int side, const void *buf)
 {
+    CPU_UNSUPPORTED(s, "lb_halo_import");
     if (!s || !buf || side < 0 || side > 1) return fail(LB_ERR_ARG, "bad argument");
     DeviceGuard guard(s->p.device);
     const int which = s->stepping ? (s->cur ^ 1) : s->cur;
@@ -1780,12 +1896,93 @@ int lb_halo_import(lb_sim *s, int side, const void *buf)
 
 int lb_halo_floats(lb_sim *s)
 {
+    CPU_UNSUPPORTED(s, "lb_halo_floats");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     return HALO_SEGS * s->p.nx;
 }
 
+namespace {
+constexpr int CYCLE_GRAPH_CYCLES = 4;
+
+// one halo cycle: E1 + C1, E2 + C2, exchange of the 2D edge rows (see slab_cycle_first)
+int slab_cycle_one(lb_sim *s, int D, bool last_of_run, const HaloTables &T)
+{
+    int rc;
+    if ((rc = slab_cycle_first(s, D))) return rc;
+    s->cur ^= 1;
+    if ((rc = slab_cycle_second(s, last_of_run, D))) return rc;
+    s->cur ^= 1;
+    if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+    return LB_OK;
+}
+
+bool cycle_graph_wanted(const lb_sim *s)
+{
+    static const bool on = getenv("LB_CYCLE_GRAPH") && atoi(getenv("LB_CYCLE_GRAPH")) != 0;
+    return on && s->peer_connected && !s->cyc_failed;
+}
+
+// CYCLE_GRAPH_CYCLES halo cycles as ONE graph launch.  Captured once per (lattice parity, depth, mask, variant): both queues
+// of the handle are captured -- the edge stream forks off the compute stream at the top and joins it at the bottom --, so the
+// cross-queue waits inside become graph edges; between two graph launches the two queues are joined (once per
+// 8 D CYCLE_GRAPH_CYCLES / 2 time steps instead of never: the price of replaying).  A capture the runtime refuses is not an
+// error: the caller falls back to eager launches.
+int slab_cycle_graph(lb_sim *s, int D, const HaloTables &T)
+{
+    const int key = (s->cur & 1) | (s->has_mask ? 2 : 0) | (D << 2) | (effective_variant(s) << 5);
+    if (!s->ev_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
+    if (!s->cyc_exec || s->cyc_key != key) {
+        if (s->cyc_exec) (void)hipGraphExecDestroy(s->cyc_exec);
+        if (s->cyc_graph) (void)hipGraphDestroy(s->cyc_graph);
+        s->cyc_exec = nullptr;
+        s->cyc_graph = nullptr;
+        if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            (void)hipGetLastError();
+            s->cyc_failed = true;
+            return LB_OK;
+        }
+        int rc = LB_OK;
+        const int cur0 = s->cur;
+        hipError_t e = hipEventRecord(s->ev_fork, s->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->edge_stream, s->ev_fork, 0);
+        for (int c = 0; c < CYCLE_GRAPH_CYCLES && !rc && e == hipSuccess; ++c) rc = slab_cycle_one(s, D, false, T);
+        if (e == hipSuccess) e = hipEventRecord(s->ev_join, s->edge_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev_join, 0);
+        s->cur = cur0;
+        hipGraph_t g = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(s->stream, &g);
+        if (rc || e != hipSuccess || e2 != hipSuccess || !g || hipGraphInstantiate(&s->cyc_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (g) (void)hipGraphDestroy(g);
+            s->cyc_exec = nullptr;
+            s->cyc_failed = true;
+            return LB_OK;
+        }
+        s->cyc_graph = g;
+        s->cyc_key = key;
+    }
+    // whatever the edge stream still has in flight (the exchange before the first cycle) precedes the graph, and what it is
+    // given afterwards follows it
+    HIP_TRY(hipEventRecord(s->ev_join, s->edge_stream));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    HIP_TRY(hipGraphLaunch(s->cyc_exec, s->stream));
+    HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_fork, 0));
+    return LB_OK;                                       // (an even number of launches: cur is unchanged)
+}
+}  // namespace
+
 int lb_run(lb_sim *s, int n_steps)
 {
+    if (s && s->cpu) {
+        if (n_steps < 0) return fail(LB_ERR_ARG, "negative step count");
+        s->cpu->run(n_steps);
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (n_steps < 0) return fail(LB_ERR_ARG, "negative step count");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_run between lb_step_boundary and lb_step_finish");
@@ -1868,13 +2065,16 @@ int lb_run(lb_sim *s, int n_steps)
             if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
             s->ghost_depth = 2 * D;
         }
+        // (peer transport, LB_CYCLE_GRAPH=1: CYCLE_GRAPH_CYCLES cycles at a time replayed from a captured hipGraph -- the cycle's
+        //  kernel arguments never change, the exchange counters live on the device: slab_cycle_graph)
+        while (left >= 2 * D * CYCLE_GRAPH_CYCLES + 2 * D && cycle_graph_wanted(s)) {
+            if ((rc = slab_cycle_graph(s, D, T))) return rc;
+            if (!s->cyc_exec) break;                    // (capture refused: eager launches below)
+            left -= 2 * D * CYCLE_GRAPH_CYCLES;
+            s->ghost_depth = 2 * D;
+        }
         for (; left >= 2 * D; left -= 2 * D) {
-            if ((rc = slab_cycle_first(s, D))) return rc;
-            s->cur ^= 1;
-            if ((rc = slab_cycle_second(s, left == 2 * D, D))) return rc;
-            s->cur ^= 1;
-            if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
-            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
+            if ((rc = slab_cycle_one(s, D, left == 2 * D, T))) return rc;
             s->ghost_depth = 2 * D;
         }
         if (left >= D) {
@@ -1947,6 +2147,7 @@ int lb_set_debug_sync(int bits)
 
 int lb_run_group(lb_sim **sims, int count, int n_steps)
 {
+    for (int i = 0; sims && i < count; ++i) CPU_UNSUPPORTED(sims[i], "lb_run_group");
     if (!sims || count < 1 || n_steps < 0) return fail(LB_ERR_ARG, "bad argument");
     for (int i = 0; i < count; ++i) {
         if (!sims[i]) return fail(LB_ERR_ARG, "null handle in group");
@@ -2126,6 +2327,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
 // model, each with its own omega / mask content) advanced in lock step, ONE launch per time step for all of them.
 int lb_run_batch(lb_sim **sims, int count, int n_steps)
 {
+    for (int i = 0; sims && i < count; ++i) CPU_UNSUPPORTED(sims[i], "lb_run_batch");
     if (!sims || count < 1 || count > BATCH_MAX || n_steps < 0)
         return fail(LB_ERR_ARG, "lb_run_batch takes 1..%d handles and a non-negative step count", BATCH_MAX);
     for (int i = 0; i < count; ++i) {
@@ -2193,6 +2395,7 @@ int lb_comm_unique_id(void *unique_id_128)
 
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
 {
+    CPU_UNSUPPORTED(s, "lb_comm_init");
     if (!s || !unique_id_128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(LB_ERR_ARG, "bad argument");
     int rc = rccl_load();
     if (rc) return rc;
@@ -2235,6 +2438,7 @@ constexpr uint32_t PEER_MAGIC = 0x4c425052u;    // "LBPR"
 
 int lb_peer_export(lb_sim *s, void *handle_out)
 {
+    CPU_UNSUPPORTED(s, "lb_peer_export");
     if (!s || !handle_out) return fail(LB_ERR_ARG, "null argument");
     if (!s->multi_slab()) return fail(LB_ERR_STATE, "lb_peer_export needs a slab handle (LB_FLAG_HALO)");
     DeviceGuard guard(s->p.device);
@@ -2282,6 +2486,7 @@ int lb_peer_export(lb_sim *s, void *handle_out)
 
 int lb_peer_connect(lb_sim *s, int rank, int nranks, const void *south_handle, const void *north_handle, int min_h)
 {
+    CPU_UNSUPPORTED(s, "lb_peer_connect");
     if (!s || nranks < 1 || rank < 0 || rank >= nranks || min_h < 1) return fail(LB_ERR_ARG, "bad argument");
     if (!s->peer_flags) return fail(LB_ERR_STATE, "lb_peer_connect before lb_peer_export");
     if (s->peer_connected || s->comm) return fail(LB_ERR_STATE, "this handle already has a halo transport");
@@ -2340,6 +2545,28 @@ int lb_peer_connect(lb_sim *s, int rank, int nranks, const void *south_handle, c
 // ---- health check ------------------------------------------------------------------------
 int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach, double *sum_rho)
 {
+    if (s && s->cpu) {
+        if (across_ranks) return fail(LB_ERR_STATE, "lb_check across ranks is not available on the CPU backend");
+        const size_t n = s->cpu->plane();
+        const float *f = s->cpu->f.data();
+        int64_t bad = 0;
+        double sum = 0.;
+        float mx = 0.f;
+        for (size_t c = 0; c < n; ++c) {                // the moments of the populations, as the device pass computes them
+            float r = f[c];
+            for (int k = 1; k < 9; ++k) r += f[k * n + c];
+            const float inv = 1.f / r;
+            const float ux = (f[n + c] - f[3 * n + c] + f[5 * n + c] - f[6 * n + c] - f[7 * n + c] + f[8 * n + c]) * inv;
+            const float uy = (f[5 * n + c] + f[2 * n + c] + f[6 * n + c] - f[7 * n + c] - f[4 * n + c] - f[8 * n + c]) * inv;
+            const float usq = ux * ux + uy * uy;
+            if (fabsf(r) <= 3.0e38f && fabsf(usq) <= 3.0e38f) { sum += (double)r; mx = fmaxf(mx, usq); }
+            else ++bad;
+        }
+        if (n_nonfinite) *n_nonfinite = bad;
+        if (max_mach) *max_mach = sqrtf(3.f * mx);
+        if (sum_rho) *sum_rho = sum;
+        return LB_OK;
+    }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_check inside a split step");
     if (across_ranks && !s->comm) return fail(LB_ERR_STATE, "lb_check across ranks needs lb_comm_init");
@@ -2377,6 +2604,7 @@ int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach,
 // ---- measurement -------------------------------------------------------------------------
 int lb_steps_per_launch(lb_sim *s)
 {
+    if (s && s->cpu) return 1;
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int n = 1;
     if (s->p.semantics == LB_SEM_CYTHON) return cython_tiles(s) ? TILE_T : 1;
@@ -2396,6 +2624,7 @@ int lb_steps_per_launch(lb_sim *s)
 
 int lb_autotune(lb_sim *s)
 {
+    if (s && s->cpu) return 0;                     // (one code path on the host: nothing to choose between)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune inside a split step");
     if (!autotune_applies(s)) return 0;                // nothing to choose between
@@ -2405,6 +2634,7 @@ int lb_autotune(lb_sim *s)
 
 int lb_autotune_quick(lb_sim *s, int max_steps)
 {
+    if (s && s->cpu) return 0;
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune_quick inside a split step");
     if (!autotune_applies(s) || s->variant >= 0 || s->tuned_steps || max_steps < autotune_quick_cost(s)) return 0;
@@ -2414,6 +2644,11 @@ int lb_autotune_quick(lb_sim *s, int max_steps)
 
 int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
 {
+    if (s && s->cpu) {
+        if (!buf || buflen < 1) return fail(LB_ERR_ARG, "bad argument");
+        snprintf(buf, (size_t)buflen, "cpu backend (cython_dim.pyx Pipe_Flow.run restated for the host, 1 thread)");
+        return LB_OK;
+    }
     if (!s || !buf || buflen < 1) return fail(LB_ERR_ARG, "bad argument");
     static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET", "PIPE, D2Q9i"};
     const char *kernel = "k_step";
@@ -2435,6 +2670,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
 
 int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)
 {
+    CPU_UNSUPPORTED(s, "lb_copy_calibration");
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_copy_calibration inside a split step");
     DeviceGuard guard(s->p.device);
@@ -2451,6 +2687,7 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved)
 
 int lb_timer_start(lb_sim *s)
 {
+    if (s && s->cpu) { s->cpu->t0 = std::chrono::steady_clock::now(); return LB_OK; }
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipEventRecord(s->ev_t0, s->stream));
@@ -2459,6 +2696,11 @@ int lb_timer_start(lb_sim *s)
 
 int lb_timer_stop(lb_sim *s, float *elapsed_ms)
 {
+    if (s && s->cpu) {
+        if (!elapsed_ms) return fail(LB_ERR_ARG, "null argument");
+        *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - s->cpu->t0).count();
+        return LB_OK;
+    }
     if (!s || !elapsed_ms) return fail(LB_ERR_ARG, "null argument");
     DeviceGuard guard(s->p.device);
     HIP_TRY(hipEventRecord(s->ev_t1, s->stream));

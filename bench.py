@@ -115,6 +115,25 @@ def cpu_baseline(budgets=((256, 3.0), (1024, 4.0), (4096, 10.0)), all_cores_budg
                      "imported reference), %dx%d grid, %d steps, %.1f s, 1 thread of %d available"
                      % (big["grid"][0], big["grid"][1], big["steps"], big["seconds"], ncores),
            "sizes": sizes}
+    # the product's own CPU backend (lb_create with device = -1: 2d-lb_amd/csrc/cpu_backend.h, the same reference path restated
+    # behind the C ABI, 1 thread) on the largest size -- BASELINE.md section 4's "build's own C++ restatement"
+    try:
+        from LB_D2Q9.dimensionless import cython_dim
+        n = budgets[-1][0]
+        own = cython_dim.Pipe_Flow(device=-1, verbose=False, diameter=1., rho=1., viscosity=0.05, pressure_grad=-1.,
+                                   pipe_length=1., N=n - 1, time_prefactor=(n - 1) / 10.)
+        own.run(1)
+        steps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(4.0, budgets[-1][1]):
+            own.run(1)
+            steps += 1
+        el = time.perf_counter() - t0
+        out["product_cpu_backend"] = {"value": round(own.nx * own.ny * steps / el / 1e6, 3), "unit": "MLUPS", "cores": 1,
+                                      "kind": "own", "sample": "cython_dim.Pipe_Flow(device=-1) = lb_create(device = LB_DEVICE_CPU), "
+                                                               "%dx%d, %d steps, %.1f s" % (own.nx, own.ny, steps, el)}
+        own._sim.close()
+    except Exception as exc:                             # noqa: BLE001 - the baseline leg must not take the line down
+        out["product_cpu_backend"] = {"error": str(exc)}
     if all_cores_budget_s > 0:
         # "honest best CPU" line: the same port with OpenMP over the independent
         # cell loops (the in-place streaming only splits four ways), all host cores

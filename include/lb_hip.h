@@ -78,7 +78,7 @@ typedef struct {
     int32_t nx, ny;           /* global grid (reference: self.nx, self.ny, opencl_dim.py:191-201) */
     int32_t y0, local_ny;     /* row slab [y0, y0+local_ny) owned by this handle; 0, ny for one GPU */
     int32_t bc_mode;          /* lb_bc_mode */
-    int32_t device;           /* HIP device ordinal */
+    int32_t device;           /* HIP device ordinal, or LB_DEVICE_CPU */
     float omega;              /* np.float32(self.omega), opencl_dim.py:369 */
     float inlet_rho;          /* np.float32(self.inlet_rho), :336 */
     float outlet_rho;
@@ -89,6 +89,19 @@ typedef struct {
     float inlet_u, outlet_u;  /* VELOCITY_INLET only: u_w, u_e of OLD/opencl.py:283-286 */
     int32_t reserved[1];      /* must be zero */
 } lb_params;
+
+/* lb_params.device = LB_DEVICE_CPU: the product's own CPU backend (2d-lb_amd/csrc/cpu_backend.h): the reference's CPU class
+ * LB_D2Q9/dimensionless/cython_dim.pyx Pipe_Flow.run (:346-359) restated for the host, single-threaded like the reference, in
+ * the reference's mixed float32 / float64 arithmetic.  Needs semantics = LB_SEM_CYTHON, bc_mode = LB_BC_PIPE, a whole-grid
+ * handle and no flags.  BASELINE.json's first configuration ("256 x 256 Poiseuille, CPU path, no GPU") runs on it without a
+ * GPU in the box, and bench.py times it next to the GPU numbers.  It is selected by this value and by nothing else: a handle
+ * with a device ordinal >= 0 never falls back to the host.  Entry points that only make sense on a device (lb_set_stream,
+ * the slab / halo / comm / peer calls, lb_run_group, lb_run_batch, lb_autotune*, lb_copy_calibration, the corner state) return
+ * LB_ERR_STATE on such a handle; u, v are float64 inside, float32 across the ABI like everywhere else. */
+#define LB_DEVICE_CPU (-1)
+
+/* (declared below: lb_set_params_f64 hands a CPU-backend handle the reference's float64 omega / inlet_rho / outlet_rho, which
+ *  lb_params carries as float32) */
 
 /* Treat the handle as a row slab with ghost rows even when it owns the whole grid: its halo
  * is then filled by lb_halo_import / the RCCL exchange (a 1-rank periodic ring sends to
@@ -120,6 +133,11 @@ int lb_device_count(void);                     /* <0 on error */
 const char *lb_last_error(void);
 int lb_create(const lb_params *p, lb_sim **out);
 int lb_destroy(lb_sim *s);
+/* CPU backend only (LB_DEVICE_CPU): the reference keeps omega, inlet_rho and outlet_rho as np.float64 and its mixed-precision
+ * expressions see them as such (cython_dim.pyx:86-95, 139-141); lb_params rounds them to float32.  This call restores the
+ * float64 values, which makes the backend reproduce the reference's populations bit for bit.  LB_ERR_STATE on a GPU handle
+ * (the device kernels compute in float32 throughout). */
+int lb_set_params_f64(lb_sim *s, double omega, double inlet_rho, double outlet_rho);
 int lb_sync(lb_sim *s);
 /* Run everything on an externally owned hipStream_t (e.g. torch's current
  * stream) instead of the handle's own; pass NULL to go back. */

@@ -25,7 +25,9 @@ def test_shear_layer_shape_and_slab_consistency():
 def test_cpu_baseline_leg_reports_the_contract_keys():
     import bench
     r = bench.cpu_baseline(budgets=((64, 0.2), (128, 0.4)), all_cores_budget_s=0.3)
-    assert set(r) == {"value", "unit", "cores", "kind", "sample", "sizes", "all_cores"}
+    assert set(r) == {"value", "unit", "cores", "kind", "sample", "sizes", "all_cores", "product_cpu_backend"}
+    own = r["product_cpu_backend"]                                     # the product's own CPU backend, timed beside the oracle's port
+    assert own["kind"] == "own" and own["cores"] == 1 and own["value"] > 0.1 and "LB_DEVICE_CPU" in own["sample"]
     assert r["all_cores"]["cores"] >= 1 and r["all_cores"]["value"] > 0
     assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "MLUPS" and r["value"] > 0.1
     assert "numpy2=True" in r["sample"]                                # the mode pinned bit-exact to the imported reference

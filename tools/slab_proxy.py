@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--parts", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--variants", default="-1,9")
+    ap.add_argument("--transports", default="rccl", help="comma list of rccl, peer (the slab path as a 1-rank ring over that transport)")
     args = ap.parse_args()
     from LB_D2Q9.simulation import Simulation, comm_unique_id
     from bench import shear_layer
@@ -26,12 +27,16 @@ def main():
         ny = args.nx // parts
         for variant in [int(v) for v in args.variants.split(",")]:
             res = {}
-            for mode in ("plain", "slab+rccl-self"):
+            modes = ["plain"] + ["slab+%s-self" % t for t in args.transports.split(",")]
+            for mode in modes:
                 sim = Simulation(args.nx, ny, 1.7, bc="periodic", halo=(mode != "plain"))
                 if variant >= 0:
                     sim.set_variant(variant)
-                if mode != "plain":
+                if mode == "slab+rccl-self":
                     sim.comm_init(comm_unique_id(), 0, 1)
+                elif mode == "slab+peer-self":
+                    d = sim.peer_export()
+                    sim.peer_connect(0, 1, d, d, ny)
                 sim.init_equilibrium(*shear_layer(args.nx, ny, 0, ny))
                 sim.run(10)
                 best = 0.0
@@ -48,11 +53,11 @@ def main():
                 res[mode] = best
                 res[mode + "_host_us"] = host
                 sim.close()
-            print("grid %5d x %5d (1/%d of %d^2) variant %3d: plain %9.1f MLUPS, slab path %9.1f MLUPS "
-                  "(%.0f us/step GPU, %.0f us/step host enqueue) -> x%d = %9.1f"
-                  % (args.nx, ny, parts, args.nx, variant, res["plain"], res["slab+rccl-self"],
-                     args.nx * ny / res["slab+rccl-self"], res["slab+rccl-self_host_us"], parts,
-                     parts * res["slab+rccl-self"]), flush=True)
+            for mode in modes[1:]:
+                print("grid %5d x %5d (1/%d of %d^2) variant %3d: plain %9.1f MLUPS, slab path (%s) %9.1f MLUPS "
+                      "(%.1f us/step GPU, %.0f us/step host enqueue) -> x%d = %9.1f"
+                      % (args.nx, ny, parts, args.nx, variant, res["plain"], mode[5:], res[mode],
+                         args.nx * ny / res[mode], res[mode + "_host_us"], parts, parts * res[mode]), flush=True)
 
 
 if __name__ == "__main__":
