@@ -198,7 +198,7 @@ __device__ __forceinline__ void row1_load(const StepArgs &a, int r, int x4, bool
     o.mk = uc4{0, 0, 0, 0};
     o.hsolid = false;
     o.hxc = -1;
-    o.hc = Cell{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (o.hc is only read by the halo lanes of a row that was loaded: no zero fill for everybody else -- nine v_mov per row)
     if (o.have) {
         gather_issue<BC, MASK, false>(a, x4, o.rr, ym, yp, o.q, o.mk, o.wp);
 #ifdef LB_DIAG
@@ -308,7 +308,7 @@ __device__ __forceinline__ void march4_iter(const StepArgs &a, const March4Ctx &
     const bool hsolid = cur.hsolid;
     HaloCell9 n1 = {};                              // stage-1 links of my halo cell at position i
     if (cur.have) {
-        gather_merge<BC>(a, x4, q1, cur.wp);          // (periodic wrap elements: merged here, not behind the loads)
+        gather_merge<BC, true>(a, x4, q1, cur.wp);    // (periodic wrap elements: merged here, not behind the loads; nx % 4 == 0: step4_applicable)
 #ifdef LB_DIAG
         if (!(a.diag & 1024))
 #endif
@@ -529,13 +529,22 @@ constexpr bool step4_prefetch(int bc, bool mask, bool macro)
     return bc != LB_BC_VELOCITY_INLET && !mask && !(bc == LB_BC_PIPE_I && macro);
 }
 
-template <int BC, bool MASK, bool MACRO, bool NTS, bool PF>
-__global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a, int strips, int seg_rows, int nsegs,
-                                                               int row_end)
+// XW = strips per workgroup.  1 (what is launched): a workgroup is the two waves of one segment pair.  2 was an experiment of
+// round 4: the pairs of two x-ADJACENT strips share a workgroup -- they start together on one CU, so the cache lines a strip's
+// halo cells and displaced loads take from its neighbour's strip (the read traffic beyond the compulsory bytes: +12.7 % at
+// 8192^2) would be lines the neighbour's waves fetch at about the same time on the same L2.  Bitwise equal, 74.9 KB of LDS per
+// workgroup, and no faster: 8192^2 314.7 / 316.3 / 314.3 k MLUPS against 318.7 / 316.2 / 319.1 k, 4096^2 287-292 k against
+// 285-299 k (one box, alternating: profiles/r04_experiments.txt).  The template parameter stays; nothing instantiates 2.
+template <int BC, bool MASK, bool MACRO, bool NTS, bool PF, int XW = 1>
+__global__ __launch_bounds__(64 * STEP4_WAVES * XW, 2) void k_step4(const StepArgs a, int strips, int seg_rows, int nsegs,
+                                                                    int row_end)
 {
-    __shared__ f4a lds_win[STEP4_WAVES][2][9][64];
-    __shared__ HaloXchg xchg;
-    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    __shared__ f4a lds_win_all[STEP4_WAVES * XW][2][9][64];
+    __shared__ HaloXchg xchg_all[XW];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wy = w & 1, wx = w >> 1;
+    f4a (*lds_win)[2][9][64] = lds_win_all + STEP4_WAVES * wx;
+    HaloXchg &xchg = xchg_all[wx];
     // one workgroup = one pair of segments of one strip (XCD-transposed order, as k_step3: eight x-adjacent strips share an L2)
     int item = xcd_item(blockIdx.x, gridDim.x);
 #ifdef LB_DIAG
@@ -546,16 +555,24 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step4(const StepArgs a,
     // left and right end (a.edge_seg_rows > 0): further pairs of the first and the last strip only.  Those two strips run
     // the inlet / outlet / wall rule for one cell per row and stage, which makes their rows ~18 % dearer; with equal segments
     // their waves were the last to finish by that margin in every launch (tools/wave_timeline.py), so they get shorter ones.
+    // (XW = 2: an item is a pair of strips -- 2 i and 2 i + 1 --; behind them, items that hold one further pair of BOTH edge strips)
     int sx, sy;
     const unsigned slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u;       // HW_REG_HW_ID wave_id bit 0: my slot on the SIMD
-    if (item < strips * nsegs) {
-        sx = item % strips;
-        sy = item / strips;
+    const int sgroups = (strips + XW - 1) / XW;
+    if (item < sgroups * nsegs) {
+        sx = (item % sgroups) * XW + wx;
+        sy = item / sgroups;
+        if (sx >= strips) return;                       // (an odd number of strips: the last group holds one)
     } else {
         if (!a.edge_seg_rows) return;
-        const int j = item - strips * nsegs;
-        sx = (j & 1) ? strips - 1 : 0;
-        sy = nsegs + (j >> 1);
+        const int j = item - sgroups * nsegs;
+        if (XW == 1) {
+            sx = (j & 1) ? strips - 1 : 0;
+            sy = nsegs + (j >> 1);
+        } else {
+            sx = wx ? strips - 1 : 0;
+            sy = nsegs + j;
+        }
     }
     int stride = a.seg_stride, rows = seg_rows;
     if (a.edge_seg_rows && (sx == 0 || sx == strips - 1)) stride = rows = a.edge_seg_rows;

@@ -299,7 +299,9 @@ def main():
                          "flow through the porous-medium image.  2, 3, 5 are single-GPU cases")
     ap.add_argument("--size", type=int, default=None, help="grid side (default: the configuration's own: 1024 / 4096 / 8192 / 4096)")
     ap.add_argument("--omega", type=float, default=None, help="BGK relaxation rate (default: the configuration's own; 1.7 for config 4)")
-    ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "torch"])
+    ap.add_argument("--transport", default=os.environ.get("LB_HALO_TRANSPORT", "rccl"), choices=["rccl", "peer", "torch"],
+                    help="halo transport of the multi-rank run: rccl (default), peer (direct stores into the neighbours' ghost rows "
+                         "through IPC-mapped memory), torch (python-driven); one that cannot be set up falls back to the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="do not time BASELINE configurations 2, 3 and 5 behind the headline (N = 1, default configuration)")
@@ -369,25 +371,30 @@ def main():
         sim = Simulation(n, n, args.omega, bc="periodic", device=local_rank, eager_macro=args.eager_macro)
         eng, y0, h = sim, 0, n
     else:
-        # RCCL halo exchange inside the engine; if any rank cannot set it up, every rank falls back to the
-        # torch.distributed-driven exchange (same halo format, single-step kernel, not overlapped)
-        slab, failed = None, 0
-        try:
-            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=args.transport, device=local_rank,
-                                   eager_macro=args.eager_macro)
-        except Exception as exc:                                   # noqa: BLE001 - reported below
-            failed = 1
-            print("rank %d: %s halo transport unavailable (%s)" % (rank, args.transport, exc), file=sys.stderr, flush=True)
-        flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag[0]):
-            if args.transport == "torch":
-                raise SystemExit("bench: no usable halo transport")
-            args.transport = "torch"
+        # RCCL halo exchange inside the engine; if any rank cannot set it up, every rank falls back -- first to the peer
+        # transport (the same schedule inside lb_run, halo rows stored straight into the neighbours' ghost rows through
+        # IPC-mapped device memory), then to the torch.distributed-driven exchange (same halo format, single-step kernel,
+        # not overlapped)
+        chain = {"rccl": ["rccl", "peer", "torch"], "peer": ["peer", "torch"], "torch": ["torch"]}[args.transport]
+        slab = None
+        for transport in chain:
+            failed = 0
+            try:
+                slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=transport, device=local_rank,
+                                       eager_macro=args.eager_macro)
+            except Exception as exc:                                   # noqa: BLE001 - reported below
+                failed = 1
+                print("rank %d: %s halo transport unavailable (%s)" % (rank, transport, exc), file=sys.stderr, flush=True)
+            flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if not int(flag[0]):
+                args.transport = transport
+                break
             if slab is not None:
                 slab.engine.close()
-            slab = DistributedSlab(n, n, args.omega, bc="periodic", transport="torch", device=local_rank,
-                                   eager_macro=args.eager_macro)
+                slab = None
+        if slab is None:
+            raise SystemExit("bench: no usable halo transport")
         sim, eng, y0, h = slab, slab.engine, slab.y0, slab.h
     if args.variant is not None:
         eng.set_variant(args.variant)

@@ -128,3 +128,18 @@ def test_committed_bench_line_has_the_contract_fields():
             t = d["timing"]
             assert t["blocks"] >= 5 and t["timed_s"] >= 0.5 and t["statistic"] == "median"
             assert t["min_ms_per_step"] <= d["ms_per_step"] <= t["max_ms_per_step"]
+        if rnd >= 4:
+            # the other single-GPU configurations of BASELINE.json ride behind the headline, on the same clock
+            assert d["methodology"] == "r3-block-avg"
+            oc = {o["config"]: o for o in d["other_configs"]}
+            assert sorted(oc) == [2, 3, 5]
+            for c, o in oc.items():
+                for k in ("workload", "value", "unit", "ms_per_step", "launch_ms", "roofline_frac", "kernel", "steps_per_launch", "health"):
+                    assert k in o, (path, c, k)
+                assert o["unit"] == "MLUPS" and o["value"] > 0 and 0 < o["roofline_frac"] <= 1 and o["health"]["n_nonfinite"] == 0
+                n = {2: 1024, 3: 4096, 5: 4096}[c]
+                assert o["value"] == pytest.approx(n * n / (o["ms_per_step"] * 1e-3) / 1e6, rel=2e-3)
+                assert o["roofline_frac"] == pytest.approx(o["bytes_per_cell_per_launch"] * n * n / (o["launch_ms"] * 1e-3) / 1e9 / 8000.0, abs=2e-3)
+            assert "cavity" in oc[2]["workload"] and "Kelvin-Helmholtz" in oc[3]["workload"] and "porous" in oc[5]["workload"]
+            own = d["cpu_baseline"]["product_cpu_backend"]
+            assert own["kind"] == "own" and own["cores"] == 1 and own["value"] > 0
