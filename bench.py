@@ -527,7 +527,12 @@ def main():
             # the other single-GPU configurations, on the driver's clock too: after the headline's timed region, the
             # headline's lattice released first (same code path as `--config N`; about a second each)
             eng.close()
-            line["other_configs"] = [measure_config(c, local_rank, 20, 8, args.min_blocks, args.min_timed_s) for c in (2, 3, 5)]
+            line["other_configs"] = []
+            for c in (2, 3, 5):
+                try:
+                    line["other_configs"].append(measure_config(c, local_rank, 20, 8, args.min_blocks, args.min_timed_s))
+                except (Exception, SystemExit) as exc:             # noqa: BLE001 - a side line must not take the headline down
+                    line["other_configs"].append({"config": c, "error": str(exc)})
         if world == 1 and not args.no_cpu_baseline and args.config == 4:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=result_out, flush=True)
