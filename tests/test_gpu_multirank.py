@@ -46,6 +46,21 @@ def test_slabs_over_rccl_equal_the_undivided_run_bitwise(lbhip):
     assert "= False" not in p.stdout
 
 
+@pytest.mark.timeout(2400, method="thread")
+def test_slabs_over_the_peer_transport_across_gpus_equal_the_undivided_run_bitwise(lbhip):
+    """tools/peer_ranks_check.py with one rank process per GPU: the same schedules over the peer transport (halo rows stored into
+    the neighbour GPU's ghost rows over xGMI through IPC-mapped memory, flags in fine-grained memory).  On one GPU the same tool
+    runs in tests/test_gpu_peer_ranks.py; this is its multi-GPU form."""
+    n = _gpus(lbhip)
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (%d visible)" % n)
+    n = min(n, 8)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_ranks_check.py"), "--ranks", str(n), "--gpus", str(n)],
+                       capture_output=True, text=True, timeout=1800, env=_env())
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "all cases bitwise equal" in p.stdout and "= False" not in p.stdout
+
+
 @pytest.mark.timeout(1800, method="thread")
 def test_bench_spawns_its_own_ranks(lbhip):
     """`python bench.py --gpus N` as the driver calls it (no launcher): one JSON line, n_gpus = N, RCCL transport."""
