@@ -227,8 +227,8 @@ def measure_config(config, local_rank, steps, warmup, min_blocks, min_timed_s, s
         launch_s = ev_ms / 1e3 / steps * spl
         achieved = bytes_per_cell * n * n / launch_s / 1e9
         return {"config": config, "workload": what, "value": round(n * float(n) * steps / wall / 1e6, 1), "unit": "MLUPS",
-                "ms_per_step": round(wall * 1e3 / steps, 4), "steps": steps, "warmup": warmup, "blocks": len(walls),
-                "timed_s": round(total, 3), "launch_ms": round(launch_s * 1e3, 4), "steps_per_launch": spl,
+                "ms_per_step": round(wall * 1e3 / steps, 6), "steps": steps, "warmup": warmup, "blocks": len(walls),
+                "timed_s": round(total, 3), "launch_ms": round(launch_s * 1e3, 6), "steps_per_launch": spl,
                 "roofline_frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_GBps": round(achieved, 1),
                 "bytes_per_cell_per_launch": bytes_per_cell, "kernel": sim.hot_kernel(), "health": health}
     finally:

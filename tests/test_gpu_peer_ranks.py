@@ -82,3 +82,24 @@ def test_peer_connect_refuses_what_does_not_fit(lbhip):
     with pytest.raises(_native.LbError):
         a.peer_connect(0, 1, da, da, 64)                           # already attached
     a.run(8)
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+@pytest.mark.timeout(600, method="thread")
+def test_bench_through_the_slab_path_on_one_gpu(lbhip, transport):
+    """`bench.py --force-slab-path`: the code path `bench.py --gpus N` takes (DistributedSlab inside a torch.distributed group, the
+    halo cycle inside lb_run, the collective health check) with ONE rank whose neighbours are itself, over either transport: one
+    JSON line that names the transport."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-slab-path", "--transport", transport, "--size", "2048",
+                        "--steps", "24", "--warmup", "8", "--min-timed-s", "0.1", "--no-cpu-baseline", "--calibrate", "0"],
+                       capture_output=True, text=True, timeout=500, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and ("halo via " + transport) in line["config"]["workload"]
+    assert line["health"]["n_nonfinite"] == 0 and 0 < line["roofline"]["frac"] <= 1.0

@@ -26,6 +26,7 @@ namespace { constexpr int GHOST = 8; constexpr int MASK_GHOST = LB_MASK_HALO_ROW
 #include "%(csrc)s/kernels_fused.h"
 #include "%(csrc)s/kernels_step4.h"
 #include "%(csrc)s/kernels_tile.h"
+#include "%(csrc)s/kernels_phases.h"
 void isa_stats_force(hipStream_t st) { void *p = (void *)(&%(kernel)s); hipLaunchKernel(p, dim3(1), dim3(1), nullptr, 0, st); }
 """
 
