@@ -396,6 +396,27 @@ __device__ __forceinline__ void march4_iter(const StepArgs &a, const March4Ctx &
         if (!(a.diag & 4))
 #endif
         collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(st.mhist, 2), r4, u4, v4);
+#ifdef LB_DIAG
+        if (a.diag & 1048576) {
+            // timing only (wrong results): a FIFTH stage's worth of work -- a window load and push on W2 again, the gather with its
+            // six cross-lane moves, a halo-cell stage, a collide -- to price five steps per pass before building them
+            // (tools/r04_fifth_stage.sh, profiles/r04_experiments.txt section 9)
+            Window w2b;
+            lds_window_load(W2, lane, it, w2b);
+            f4a q3b[9];
+            stage_gather<DOWN>(w2b, q3, st.s2t, n3.tm, lane, q3b);
+            lds_window_push<DOWN>(W2, lane, it, q3);
+            if (halo3) {
+                Cell c;
+                Tri tw5 = {__shfl(st.s2t.d, lane_out), 0.f, __shfl(st.s2t.g, lane_out)};
+                halo_cell_next<BC, MASK, DOWN>(a, cx.hx, a.y0 + r3, left, false, st.s2c, n3.cm, tw5, n3.tm, n3.a0, n3.ap, n3.am, c);
+                n3 = halo_all<DOWN>(c, left);
+            }
+            collide_row<BC, MASK>(a, x4, a.y0 + r3, q3b, mask_bits(st.mhist, 2), r4, u4, v4);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q3[k] = q3b[k];
+        }
+#endif
         if (NST == 3) {                    // my position 0 after step 3 -> the other wave's window 3
             lds_publish<DOWN>(cx.P3, lane, 6, q3);
             if (halo1) cx.xchg->v[wy ^ 1][2][0][hslot] = n3.tm;
