@@ -25,6 +25,8 @@ struct StepArgs {
     int edge_seg_rows;     // k_step4: > 0: the first and the last strip march segments of this many rows (see the kernel)
     int diag;              // ablation switches, read only by the LB_DIAG build (tools/ablate.py)
     int prio_turns;        // k_step4: the two waves of a SIMD alternate their issue priority (bit of the 100 MHz clock)
+    int nts;               // marching kernels: non-temporal stores (a run-time flag there: halves their instantiations and takes a
+                           // minute off the library's build)
     int tile_launch_order; // k_tile4: 1 = tile = blockIdx (A/B switch; default: one band of tile rows per XCD)
     float omega, rho_in, rho_out, lid_u, rho0;
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
@@ -184,6 +186,24 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
     WrapPatch wp;
     gather_issue<BC, MASK, NTL>(a, x4, yl, ym, yp, q, mk, wp);
     gather_merge<BC>(a, x4, q, wp);
+}
+
+// The nine 16-byte stores of a row of the marching kernels, non-temporal or plain by a RUN-TIME, wave-uniform flag (as a template
+// argument the choice doubled those kernels' instantiations: a minute and a half of the library's build).  The empty asm keeps
+// the two branches from being merged: merged, the stores lose the non-temporal hint (the compiler keeps only what both carry)
+// -- measured: 8192^2 277 k instead of 309 k MLUPS.
+template <bool NTS>
+__device__ __forceinline__ void store_row9(bool nts, float *d, long long S, int x4, const f4a (&t)[9])
+{
+    if (NTS || nts) {
+        asm volatile("" ::: "memory");                  // (in front as well: common code is hoisted out of branches, too)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) store4<true>(lane_ptr(d + k * S, x4), t[k]);
+        asm volatile("" ::: "memory");
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) store4<false>(lane_ptr(d + k * S, x4), t[k]);
+    }
 }
 
 // Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.
@@ -582,8 +602,7 @@ __global__ __launch_bounds__(256, 2) void k_step2(const StepArgs a, int strips, 
 #endif
             if (store_lane) {
                 float *d = a.dst + o;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
+                store_row9<NTS>(a.nts != 0, d, S, x4, t);
                 if (MACRO) {
                     const long long m = (long long)y * a.fpitch;
                     store4<false>(lane_ptr(a.rho + m, x4), r4);
@@ -791,8 +810,7 @@ __global__ __launch_bounds__(256, 2) void k_step3(const StepArgs a, int strips, 
             collide_row<BC, MASK>(a, x4, a.y0 + r3, t, mask_bits(mhist, 2), r4, u4, v4);
             if (store_lane) {
                 float *d = a.dst + o;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
+                store_row9<NTS>(a.nts != 0, d, S, x4, t);
                 if (MACRO) {
                     const long long m = (long long)r3 * a.fpitch;
                     store4<false>(lane_ptr(a.rho + m, x4), r4);

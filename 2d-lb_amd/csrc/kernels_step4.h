@@ -442,8 +442,7 @@ __device__ __forceinline__ void march4_iter(const StepArgs &a, const March4Ctx &
         if (cx.store_lane) {
             const long long o = (long long)r4_ * a.pitch;   // row start, uniform
             float *d = a.dst + o;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) store4<NTS>(lane_ptr(d + k * S, x4), t[k]);
+            store_row9<NTS>(a.nts != 0, d, S, x4, t);
             if (MACRO) {
                 const long long m = (long long)r4_ * a.fpitch;
                 store4<false>(lane_ptr(a.rho + m, x4), r4);

@@ -237,6 +237,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.tile_launch_order = (s->variant >= 0 && (s->variant & 8192)) ? 1 : 0;    // (A/B switch: explicit variants only)
     a.diag = s->diag;
     a.prio_turns = 0;      // (set by launch_step2 from the variant)
+    a.nts = 0;
     a.omega = s->p.omega; a.rho_in = s->p.inlet_rho; a.rho_out = s->p.outlet_rho;
     a.lid_u = s->p.lid_u; a.rho0 = s->p.rho0;
     return a;
@@ -341,16 +342,16 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
     do {                                                                                                         \
         if (depth == 4) {                                                                                        \
             if (step4_prefetch(BC, MASK, MACRO) && pf_on)                                                        \
-                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, step4_prefetch(BC, MASK, MACRO)>), grid, block, 0, st, a, \
+                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, false, step4_prefetch(BC, MASK, MACRO)>), grid, block, 0, st, a, \
                                    strips, seg_rows, nsegs, row_end);                                            \
             else                                                                                                 \
-                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips, seg_rows,  \
+                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, false, false>), grid, block, 0, st, a, strips, seg_rows,  \
                                    nsegs, row_end);                                                              \
         } else if (depth == 3)                                                                                   \
-            hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
+            hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs,\
                                row_end);                                                                         \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows, nsegs,  \
+            hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs,\
                                row_end);                                                                         \
     } while (0)
     if (s->has_mask) {
@@ -374,13 +375,13 @@ void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int it
 #define LB_LAUNCHV(MASK, MACRO, NTS)                                                                                      \
     do {                                                                                                                  \
         if (depth == 4)                                                                                                   \
-            hipLaunchKernelGGL((k_step4<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS, false>), grid, block, 0, st, a, strips,   \
+            hipLaunchKernelGGL((k_step4<LB_BC_VELOCITY_INLET, MASK, MACRO, false, false>), grid, block, 0, st, a, strips,   \
                                seg_rows, nsegs, row_end);                                                                 \
         else if (depth == 3)                                                                                              \
-            hipLaunchKernelGGL((k_step3<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows,\
+            hipLaunchKernelGGL((k_step3<LB_BC_VELOCITY_INLET, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows,\
                                nsegs, row_end);                                                                           \
         else                                                                                                              \
-            hipLaunchKernelGGL((k_step2<LB_BC_VELOCITY_INLET, MASK, MACRO, NTS>), grid, block, 0, st, a, strips, seg_rows,\
+            hipLaunchKernelGGL((k_step2<LB_BC_VELOCITY_INLET, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows,\
                                nsegs, row_end);                                                                           \
     } while (0)
     if (s->has_mask) {
@@ -487,6 +488,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     // k_step4: the two waves of a SIMD take turns at the higher issue priority (see the kernel); variant bit 11 = off
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
+    a.nts = nts ? 1 : 0;                       // (the marching kernels take it at run time)
     switch (kernel_bc(s)) {
     case LB_BC_PIPE_I: launch_step2_bc<LB_BC_PIPE_I>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
