@@ -73,6 +73,7 @@ int fail(int code, const char *fmt, ...)
 #include "d2q9_cell.h"
 #include "kernels_fused.h"
 #include "kernels_step4.h"
+#include "kernels_step5.h"
 #include "kernels_tile.h"
 #include "kernels_phases.h"
 
@@ -330,17 +331,19 @@ template <int BC>
 void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows,
                      int nsegs, int row_end, bool macro, bool nts, int depth)
 {
-    const int waves = (depth == 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4: the two directions of ONE item (a
-                                                           // segment pair); the others: four independent items
+    const int waves = (depth >= 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4 / k_step5: the two directions of ONE item
+                                                           // (a segment pair); the others: four independent items
     // k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
     // instantiation without an obstacle mask but the D2Q9i fork's, and -- since the stage rows stopped being joined with zero
     // rows, round 4 -- the pipe / cavity families with a mask, whose waves waited 28 % of their cycles without it:
     // profiles/r03_sq_counters.txt).  Variant bit 10 switches it off (A/B runs).
     const bool pf_on = !(effective_variant(s) & 1024);
-    const dim3 block(64, waves), grid(depth == 4 ? items : (items + waves - 1) / waves);
+    const dim3 block(64, waves), grid(depth >= 4 ? items : (items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
-        if (depth == 4) {                                                                                        \
+        if (depth == 5)                                                                                          \
+            hipLaunchKernelGGL((k_step5<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end); \
+        else if (depth == 4) {                                                                                      \
             if (step4_prefetch(BC, MASK, MACRO) && pf_on)                                                        \
                 hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, false, step4_prefetch(BC, MASK, MACRO)>), grid, block, 0, st, a, \
                                    strips, seg_rows, nsegs, row_end);                                            \
@@ -411,6 +414,10 @@ bool step4_applicable(const lb_sim *s)
     return true;
 }
 
+// five steps per pass (k_step5; asked for by variant bit 12 only): whole-grid handles; not the velocity-inlet family, whose
+// wall-row bands (k_vel_band) are built for three and four steps
+bool step5_applicable(const lb_sim *s) { return step4_applicable(s) && s->p.bc_mode != LB_BC_VELOCITY_INLET; }
+
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
 {
@@ -437,7 +444,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     macro = macro && !lazy_macro(s);
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
-    const int strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
+    // (k_step5: overlapping strips, 248 cells apart)
+    const int strips = depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W;
     int segs, seg_rows, extra_items = 0;
     if (nsegs_fixed > 0) {
         segs = nsegs_fixed;
@@ -451,7 +459,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         if (wpc_env > 0) waves_per_cu = wpc_env;
         // (k_step4: an item is a PAIR of segments, marched by the two waves of a workgroup from its middle line: two
         //  wave slots each; `capacity`, `segs`, `seg_rows` then count pairs)
-        const int per_item = (depth == 4) ? STEP4_WAVES : 1;
+        const int per_item = (depth >= 4) ? STEP4_WAVES : 1;
         const int capacity = (s->cu_count * waves_per_cu - reserve) / per_item;
         const int rows = row_end - row_begin;
         segs = capacity / strips;
@@ -931,14 +939,17 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
 int next_advance(int allowed, int left)
 {
     int D = 1;
-    for (int d = 2; d <= 4; ++d)
+    for (int d = 2; d <= 5; ++d)
         if (allowed & (1 << d)) D = d;
     const int rem = left % D;
     for (int d = std::min(rem == 0 ? D : rem, left); d > 1; --d)
         if (allowed & (1 << d)) return d;
     return 1;
 }
-int depth_mask(bool two, bool three, bool four = false) { return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0); }
+int depth_mask(bool two, bool three, bool four = false, bool five = false)
+{
+    return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0) | (five ? 32 : 0);
+}
 
 // Both compute streams wait for the other one's kernel and for the halo of the lattice just written.
 int slab_step_join(lb_sim *s)
@@ -1041,7 +1052,8 @@ int whole_grid_depths(const lb_sim *s)
         return depth_mask(step2_applicable(s) && s->tuned_steps >= 2, step3_applicable(s) && s->tuned_steps >= 3,
                           step4_applicable(s) && s->tuned_steps >= 4);
     const int v = effective_variant(s);
-    return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s));
+    return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s),
+                      s->variant >= 0 && (v & 4096) && step5_applicable(s));
 }
 
 // A d-step pass (d = 3, 4) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
@@ -2612,7 +2624,7 @@ int lb_steps_per_launch(lb_sim *s)
     if (s->p.semantics == LB_SEM_CYTHON) return cython_tiles(s) ? TILE_T : 1;
     if (!s->multi_slab()) {
         const int depths = whole_grid_depths(s);
-        for (int d = 2; d <= 4; ++d)
+        for (int d = 2; d <= 5; ++d)
             if (depths & (1 << d)) n = d;
     } else {
         const int v = effective_variant(s);
@@ -2659,6 +2671,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";
+        else if (spl == 5) kernel = "k_step5 (marching strips, five steps per pass: two stage windows in registers, two in wave-private LDS)";
         else if (spl == 4) kernel = "k_step4 (marching strips, stage windows in registers + wave-private LDS)";
         else if (spl == 3) kernel = "k_step3 (marching strips, register windows)";
         else if (spl == 2) kernel = "k_step2 (marching strips, register window)";

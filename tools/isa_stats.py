@@ -25,6 +25,7 @@ namespace { constexpr int GHOST = 8; constexpr int MASK_GHOST = LB_MASK_HALO_ROW
 #include "%(csrc)s/d2q9_cell.h"
 #include "%(csrc)s/kernels_fused.h"
 #include "%(csrc)s/kernels_step4.h"
+#include "%(csrc)s/kernels_step5.h"
 #include "%(csrc)s/kernels_tile.h"
 #include "%(csrc)s/kernels_phases.h"
 void isa_stats_force(hipStream_t st) { void *p = (void *)(&%(kernel)s); hipLaunchKernel(p, dim3(1), dim3(1), nullptr, 0, st); }
@@ -40,7 +41,9 @@ def classify(op):
         return "salu"
     if op.startswith("ds_"):
         return "lds"
-    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+    if op.startswith("scratch_"):
+        return "scratch"
+    if op.startswith(("global_", "buffer_", "flat_")):
         return "vmem"
     return "other"
 
@@ -100,9 +103,9 @@ def main():
         dpp = sum(1 for op, s in valu if "dpp" in op or "row_" in s or "wave_" in s or "quad_perm" in s)
         cnd = sum(1 for op, s in valu if op.startswith("v_cndmask"))
         acc = sum(1 for op, s in valu if op.startswith("v_accvgpr"))
-        print("loop %-12s %5d insts: VALU %4d (pk %d, mov %d, cndmask %d, dpp %d, accvgpr %d, other %d)  SALU %d  LDS %d  VMEM %d  SMEM %d" % (
+        print("loop %-12s %5d insts: VALU %4d (pk %d, mov %d, cndmask %d, dpp %d, accvgpr %d, other %d)  SALU %d  LDS %d  VMEM %d  SMEM %d  scratch %d" % (
             tgt, len(body), len(valu), pk, mov, cnd, dpp, acc, len(valu) - pk - mov - cnd - dpp - acc, c.get("salu", 0), c.get("lds", 0),
-            c.get("vmem", 0), c.get("smem", 0)))
+            c.get("vmem", 0), c.get("smem", 0), c.get("scratch", 0)))
         if dump:
             hist = {}
             for op, s in valu:
