@@ -195,14 +195,21 @@ __device__ __forceinline__ void gather_row(const StepArgs &a, int x4, int yl, in
 template <bool NTS>
 __device__ __forceinline__ void store_row9(bool nts, float *d, long long S, int x4, const f4a (&t)[9])
 {
+    // Addressing: ONE scalar base (the row) and a 32-bit per-lane offset that carries the plane as well -- (x + k S) * 4 bytes
+    // stays below 4 GB for every lattice the marching kernels are launched on (marching_planes_fit, lb_hip.cpp).  With nine
+    // bases d + k S the compiler, once the two branches below share them, computes nine 64-bit per-lane addresses in front of the
+    // branch (instruction selection works block by block and then sees nine opaque pointers): 18 registers and 36 vector adds
+    // per row.  The lane offset passes through an empty asm in either branch so that the sums are not shared either.
+    const int kS = (int)S;
     if (NTS || nts) {
-        asm volatile("" ::: "memory");                  // (in front as well: common code is hoisted out of branches, too)
+        asm volatile("" : "+v"(x4) : : "memory");       // (in front as well: common code is hoisted out of branches, too)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) store4<true>(lane_ptr(d + k * S, x4), t[k]);
+        for (int k = 0; k < 9; ++k) store4<true>(lane_ptr(d, x4 + k * kS), t[k]);
         asm volatile("" ::: "memory");
     } else {
+        asm volatile("" : "+v"(x4));
 #pragma unroll
-        for (int k = 0; k < 9; ++k) store4<false>(lane_ptr(d + k * S, x4), t[k]);
+        for (int k = 0; k < 9; ++k) store4<false>(lane_ptr(d, x4 + k * kS), t[k]);
     }
 }
 

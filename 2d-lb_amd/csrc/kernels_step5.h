@@ -59,11 +59,15 @@ __device__ __forceinline__ void skirt_gather(const Window &w, const f4a (&q)[9],
 
 // One iteration: position i is loaded and takes step 1, position i-1 step 2 (window 1), i-2 step 3 (window 2), i-3 step 4 (LDS
 // window 3), i-4 step 5 (LDS window 4; stored).  NST = number of stages that have a row: 1..4 in iterations 0..3 (code of their
-// own, i a constant: the pipeline fills, the two waves of the pair hand over), 5 in the loop.  PF: position i was gathered an
-// iteration ago (`cur`), position i + 1 is gathered into `nxt` (see march4_iter).
+// own, i a constant: the pipeline fills, the two waves of the pair hand over), 5 in the loop.
+// PF: `cur` holds position i on entry, gathered during the previous iteration, and is gathered anew -- position i + 1 -- as soon
+// as step 2 has taken what it needs from it: the loads fly while steps 3, 4, 5 compute, in the registers the row just consumed
+// occupied (k_step4's one-row-ahead gather keeps two row buffers and copies one into the other every row: 46 more registers).
+// NOT launched: wherever the gather is placed the compiler ends up with ~21 scratch accesses per row for it (the 42 registers of
+// the row in flight do not fit beside two register windows), and the kernel runs at 277-295 k instead of 327 k MLUPS at 8192^2
+// (profiles/r04_experiments.txt section 10).
 template <int BC, bool MASK, bool MACRO, bool PF, bool DOWN, int NST>
-__device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &cx, const int i_, March5State &st, Row1 &cur,
-                                            Row1 &nxt)
+__device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &cx, const int i_, March5State &st, Row1 &cur)
 {
     const int lane = cx.lane, x4 = cx.x4;
     const long long S = a.plane;
@@ -85,8 +89,7 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
     if (NST == 2) { w1.g2 = W4[6][lane]; w1.g5 = W4[7][lane]; w1.g6 = W4[8][lane]; }
     if (NST == 3) { w2.g2 = W4[3][lane]; w2.g5 = W4[4][lane]; w2.g6 = W4[5][lane]; }
     // ---- step 1 of position i (from memory) --------------------------------------------------------------------
-    if (PF) row1_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, false, 0, nxt);
-    else row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
+    if (!PF) row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
     f4a (&q1)[9] = cur.q;
     f4a r4, u4, v4;
     const uc4 mk = cur.mk;
@@ -94,6 +97,8 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
         gather_merge<BC, true>(a, x4, q1, cur.wp);
         collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
     }
+    // (behind the last position the last row is gathered once more -- a cache hit that nobody consumes: no condition on i)
+    const int r_next = row_at(min(i + 1, cx.n_iter - 1));
     if (NST == 1) lds_publish<DOWN>(cx.P4, lane, 6, q1);        // my position 0 after step 1 -> the other wave's window 1 (mailbox)
     // ---- step 2 of position i-1 (window 1, registers) ----------------------------------------------------------
     f4a q2[9];
@@ -102,10 +107,12 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
         (void)step1_rows(a, row_at(i - 1), r2, t0_, t1_);
         skirt_gather<DOWN>(w1, q1, q2);
         window_push_dir<DOWN>(w1, q1);              // (every window takes its new row as soon as its old one has been gathered from)
+        if (PF) row1_load<BC, MASK>(a, r_next, x4, false, 0, cur);
         collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(st.mhist, 1), r4, u4, v4);
         if (NST == 2) lds_publish<DOWN>(cx.P4, lane, 3, q2);    // my position 0 after step 2 -> the other wave's window 2 (mailbox)
     } else {
         window_push_dir<DOWN>(w1, q1);
+        if (PF) row1_load<BC, MASK>(a, r_next, x4, false, 0, cur);
     }
     // ---- step 3 of position i-2 (window 2, registers) ----------------------------------------------------------
     f4a q3[9];
@@ -182,26 +189,20 @@ __device__ __forceinline__ void march5(const StepArgs &a, const int x0, const in
     cx.P4 = lds_win[wy ^ 1][1];
     March5State st = {};
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
-    Row1 ra, rb;
-    if (PF) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
-    march5_iter<BC, MASK, MACRO, PF, DOWN, 1>(a, cx, 0, st, ra, PF ? rb : ra);
-    if (PF) ra = rb;
-    march5_iter<BC, MASK, MACRO, PF, DOWN, 2>(a, cx, 1, st, ra, PF ? rb : ra);
-    if (PF) ra = rb;
-    march5_iter<BC, MASK, MACRO, PF, DOWN, 3>(a, cx, 2, st, ra, PF ? rb : ra);
-    if (PF) ra = rb;
-    march5_iter<BC, MASK, MACRO, PF, DOWN, 4>(a, cx, 3, st, ra, PF ? rb : ra);
-    if (PF) ra = rb;
-    for (int i = 4; i < cx.n_iter; ++i) {
-        march5_iter<BC, MASK, MACRO, PF, DOWN, 5>(a, cx, i, st, ra, PF ? rb : ra);
-        if (PF) ra = rb;
-    }
+    Row1 cur;
+    if (PF) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, cur);
+    march5_iter<BC, MASK, MACRO, PF, DOWN, 1>(a, cx, 0, st, cur);
+    march5_iter<BC, MASK, MACRO, PF, DOWN, 2>(a, cx, 1, st, cur);
+    march5_iter<BC, MASK, MACRO, PF, DOWN, 3>(a, cx, 2, st, cur);
+    march5_iter<BC, MASK, MACRO, PF, DOWN, 4>(a, cx, 3, st, cur);
+    for (int i = 4; i < cx.n_iter; ++i) march5_iter<BC, MASK, MACRO, PF, DOWN, 5>(a, cx, i, st, cur);
 }
 
 // strips a grid of nx columns is cut into
 constexpr int step5_strips(int nx) { return (nx + STEP5_VALID - 1) / STEP5_VALID; }
 
-// Launch geometry as k_step4: one workgroup = one segment pair of one strip (two waves), XCD-transposed order.
+// Launch geometry as k_step4: one workgroup = one segment pair of one strip (two waves), XCD-transposed order, shorter segments
+// for the two wall-column strips.
 template <int BC, bool MASK, bool MACRO, bool PF>
 __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step5(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
@@ -209,9 +210,21 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step5(const StepArgs a,
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int item = xcd_item(blockIdx.x, gridDim.x);
     const unsigned slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u;
-    if (item >= strips * nsegs) return;
-    const int sx = item % strips, sy = item / strips;
-    const int ya = a.row_begin + sy * a.seg_stride;
+    // items [0, strips * nsegs): pair item / strips of strip item % strips; behind them, in a box with walls at its left and right
+    // end (a.edge_seg_rows > 0): further pairs of the first and the last strip, which get shorter segments (k_step4)
+    int sx, sy;
+    if (item < strips * nsegs) {
+        sx = item % strips;
+        sy = item / strips;
+    } else {
+        if (!a.edge_seg_rows) return;
+        const int j = item - strips * nsegs;
+        sx = (j & 1) ? strips - 1 : 0;
+        sy = nsegs + (j >> 1);
+    }
+    int stride = a.seg_stride;
+    if (a.edge_seg_rows && (sx == 0 || sx == strips - 1)) stride = seg_rows = a.edge_seg_rows;
+    const int ya = a.row_begin + sy * stride;
     if (ya >= row_end) return;                          // (both waves of the workgroup: the barriers stay matched)
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up

@@ -299,6 +299,10 @@ int effective_variant(const lb_sim *s)
     // profiles/r01_slab_proxy_1gpu.txt).  Smaller grids: single step, replayed through a hipGraph.
     if (cells >= 1024.0 * 1024.0) v = (v & ~16) | 32 | 64;
     if (cells >= 1280.0 * 1280.0) v |= 256;
+    // ... and five wherever four are (k_step5, overlapping strips: periodic 2048^2 298 against 250 k MLUPS, 4096^2 315 against 289 k,
+    // 8192^2 327-346 against 306-319 k; pipe 8192^2 346 against 309 k: profiles/r04_experiments.txt section 10); the velocity-inlet
+    // family and slabs stay on four (step5_applicable)
+    if (cells >= 1280.0 * 1280.0) v |= 4096;
     return v;
 }
 
@@ -397,10 +401,16 @@ void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int it
 #undef LB_LAUNCHV
 }
 
+// The marching kernels address the nine planes of a row through ONE scalar base and a 32-bit byte offset per lane that carries the
+// plane (store_row9): (x + 8 plane) * 4 must stay below 4 GB.  Always true for the default layout (plane = the padded row);
+// LB_FLAG_PLANAR lattices of more than ~11000^2 cells take the single-step kernel and the tiles instead.
+bool marching_planes_fit(const lb_sim *s) { return (8.0 * (double)s->plane + (double)s->rowp) * 4.0 < 4294967296.0; }
+
 // (h: the height the decision is taken on -- a slab's own, or the smallest of the slabs that must agree)
 bool step3_applicable(const lb_sim *s, int h = -1)
 {
     if (h < 0) h = s->H;
+    if (!marching_planes_fit(s)) return false;
     if (s->p.nx < 512 || h < (s->multi_slab() ? 32 : 128)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
@@ -409,7 +419,7 @@ bool step3_applicable(const lb_sim *s, int h = -1)
 // four steps per pass on a whole-grid handle (slabs use it inside the eight-step halo cycle only: cycle_depth)
 bool step4_applicable(const lb_sim *s)
 {
-    if (s->multi_slab() || s->p.nx < 512 || s->H < 128) return false;
+    if (s->multi_slab() || s->p.nx < 512 || s->H < 128 || !marching_planes_fit(s)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
 }
@@ -428,7 +438,7 @@ bool tile_applicable(const lb_sim *s)
 bool step2_applicable(const lb_sim *s, int h = -1)
 {
     if (h < 0) h = s->H;
-    if (s->p.nx < 512) return false;
+    if (s->p.nx < 512 || !marching_planes_fit(s)) return false;
     if (h < (s->multi_slab() ? 16 : 64)) return false;
     if (s->p.bc_mode == LB_BC_PERIODIC && (s->p.nx % 4) != 0) return false;
     return true;
@@ -477,7 +487,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         // within the same number of wave slots: pipe / cavity +5..8 %, velocity inlet +19..30 % (profiles/r02_experiments.txt)
         static const double edge_env = getenv("LB_EDGE_COST") ? atof(getenv("LB_EDGE_COST")) : 0.0;          // tuning knob
         const double edge_cost = edge_env > 0.0 ? edge_env : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? 1.6 : 1.2);
-        if (depth == 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
+        if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
             const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
             const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
             const int rows_i = (rows + segs_i - 1) / segs_i, rows_e = (rows + segs_e - 1) / segs_e;
@@ -1041,7 +1051,11 @@ bool use_tile_kernel(const lb_sim *s)
     //  periodic 1792^2 220 / 235 k, 1920^2 229 / 239 k, 2048^2 243 / 207 k; cavity 1920^2 200 / 228 k, 2048^2 214 / 201 k; pipe
     //  1920^2 193 / 231 k, 2048^2 208 / 204 k, 2176^2 218 / 197 k: the tiles hold while the lattice pair fits the 256 MB
     //  Infinity Cache -- 1920^2 is 265 MB, 2048^2 302 MB -- in every family)
-    const double side = 1950.0;
+    // (round 4: five steps per pass on overlapping strips, k_step5 / tiles: periodic 1024^2 166 / 198 k, 1280^2 233 / 218 k, 1536^2
+    //  261 / 240 k, 1792^2 294 / 249 k, 2048^2 305 / 209 k; cavity 1280^2 173 / 202 k, 1536^2 200 / 220 k, 1792^2 225 / 231 k,
+    //  2048^2 259 / 194 k: profiles/r04_step5_sweep.txt.  Where k_step5 does not apply -- the velocity-inlet family has no tiles
+    //  anyway -- the change-over to k_step4 stays at 1950^2.)
+    const double side = !step5_applicable(s) ? 1950.0 : (s->p.bc_mode == LB_BC_PERIODIC ? 1200.0 : 1850.0);
     return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 
@@ -1050,10 +1064,10 @@ int whole_grid_depths(const lb_sim *s)
     if (use_tile_kernel(s)) return depth_mask(false, false, true);      // k_tile4 + single steps for the remainder
     if (s->variant < 0 && s->tuned_steps)
         return depth_mask(step2_applicable(s) && s->tuned_steps >= 2, step3_applicable(s) && s->tuned_steps >= 3,
-                          step4_applicable(s) && s->tuned_steps >= 4);
+                          step4_applicable(s) && s->tuned_steps >= 4, step5_applicable(s) && s->tuned_steps >= 5);
     const int v = effective_variant(s);
     return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s),
-                      s->variant >= 0 && (v & 4096) && step5_applicable(s));
+                      (v & 4096) && step5_applicable(s));
 }
 
 // A d-step pass (d = 3, 4) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
@@ -1136,10 +1150,11 @@ int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
     // (k_step4 at 8192^2 on one box: 4 waves per CU 189 k MLUPS, 6: 243 k, 8: 232 k, 12: 210 k -- profiles/r02_experiments.txt)
-    const Cand cands[] = {{4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
-    // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1; small grids: 36, so that the single-step candidate
-    // runs the way it would (hipGraph replay of 16 launches)
-    const int per = small_grid(s) ? 36 : 12;
+    const Cand cands[] = {{5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
+    // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1 (the five-step candidates: 2 x 5; compared by time per step);
+    // small grids: 36, so that the single-step candidate runs the way it would (hipGraph replay of 16 launches)
+    const int per12 = small_grid(s) ? 36 : 12;
+    auto per_of = [&](const Cand &c) { return c.steps == 5 ? 10 : per12; };
     const int keep_steps = s->tuned_steps, keep_wpc = s->tuned_wpc;
     int used = 0, best = -1;
     float best_ms = 0.f;
@@ -1170,7 +1185,8 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     bool usable[NC];
     for (int c = 0; c < NC; ++c) {
         ms_min[c] = 0.f;
-        usable[c] = !(cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) && !(cands[c].wpc < 0 && !tile_applicable(s)) &&
+        usable[c] = !(cands[c].steps == 5 && !step5_applicable(s)) &&
+                    !(cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) && !(cands[c].wpc < 0 && !tile_applicable(s)) &&
                     !(cands[c].steps == 3 && !step3_applicable(s)) && !(cands[c].steps == 2 && !step2_applicable(s));
     }
     for (int r = 0; r <= rounds; ++r) {
@@ -1179,12 +1195,14 @@ int autotune_whole_grid(lb_sim *s, int rounds)
             s->tuned_steps = cands[c].steps;
             s->tuned_wpc = cands[c].wpc;
             TUNE_TRY(hipEventRecord(e0, s->stream));
+            const int per = per_of(cands[c]);
             int rc = run_whole_grid(s, per, false);     // no rho,u,v epilogue: it would weigh on the short samples
             if (rc) return bail(rc);
             TUNE_TRY(hipEventRecord(e1, s->stream));
             TUNE_TRY(hipEventSynchronize(e1));
             float ms = 0.f;
             TUNE_TRY(hipEventElapsedTime(&ms, e0, e1));
+            ms /= (float)per;                           // time per step
             used += per;
             if (r >= 1 && (r == 1 || ms < ms_min[c])) ms_min[c] = ms;
         }
@@ -1237,8 +1255,8 @@ int corners_patch(lb_sim *s, int which)
     return LB_OK;
 }
 
-// steps a quick (one-round) tuning pass consumes at most: 10 candidates x 2 samples x 12 (36) steps + 1
-int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 : 12) + 1; }
+// steps a quick (one-round) tuning pass consumes at most: 10 candidates x 2 samples x 12 (36) steps, 2 x 2 x 10, + 1
+int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 1; }
 
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)

@@ -291,8 +291,8 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5],
                     help="BASELINE.json configuration, 1-based: 4 (default) = 8192^2 periodic shear layer, the one the metric "
                          "is quoted on; 2 = 1024^2 lid-driven cavity Re=1000; 3 = 4096^2 Kelvin-Helmholtz; 5 = 4096^2 pipe "

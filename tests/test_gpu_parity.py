@@ -185,7 +185,8 @@ def test_periodic_mass_drift_tracks_reference(lbhip, oracle):
                                       ("cavity", 777, 201), ("pipe", 2048, 300)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, masked):
-    """variant bit 5 selects k_step2 (two time steps per pass, register window + lane shuffles).  Same
+    """variant bit 5 selects k_step2 (two time steps per pass, register window + lane shuffles), bits 6 / 8 / 12 the three-,
+    four- and five-step kernels, bit 9 the LDS tiles.  Same
     per-cell arithmetic as k_step and the library is built with -ffp-contract=on, so the fields must
     be bitwise equal to the single-step kernel's, and match the oracle."""
     from LB_D2Q9.simulation import Simulation
@@ -199,13 +200,13 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
     kw = dict(inlet_rho=1.004, lid_u=0.06)
     sims = []
     # single step / two-step / + NT stores / three-step (+ two-step remainder) / four-step (+ remainders) /
-    # four steps through LDS tiles (+ single-step remainders)
-    for variant in (0, 32, 33, 97, 97 | 256, 512):
+    # four steps through LDS tiles (+ single-step remainders) / five-step on overlapping strips (+ remainders)
+    for variant in (0, 32, 33, 97, 97 | 256, 512, 97 | 256 | 4096):
         s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
-        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4}[variant]
+        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4, 4449: 5}[variant]
         s.set_f(f0)
-        s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step)
+        s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step) = 2+5 (five-step)
         s.run(4)                      # 4 = 2+2 = 1+3 = 4
         sims.append(s.get_fields(("f", "rho", "u", "v")))
     for k in ("f", "rho", "u", "v"):
@@ -214,6 +215,7 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
         assert np.array_equal(sims[0][k], sims[3][k]), k          # three steps per pass: still bitwise
         assert np.array_equal(sims[0][k], sims[4][k]), k          # four steps per pass (LDS windows): still bitwise
         assert np.array_equal(sims[0][k], sims[5][k]), k          # four steps per pass (LDS tiles): still bitwise
+        assert np.array_equal(sims[0][k], sims[6][k]), k          # five steps per pass (overlapping strips): still bitwise
     code = {"pipe": oracle.BC_PIPE, "periodic": oracle.BC_PERIODIC, "cavity": oracle.BC_CAVITY}[bc]
     o = oracle.O2Sim(nx, ny, 1.6, code, 1.004, 1., 0.06, 1., mask=mask)
     o.set_f(f0)

@@ -50,7 +50,12 @@ def classify(op):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
-    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    flags = []
+    for a in sys.argv[1:]:
+        if a.startswith("-D"):
+            flags.append(a)
+        elif a.startswith("-mllvm="):                    # -mllvm=<option>  ->  -mllvm <option>
+            flags += ["-mllvm", a[len("-mllvm="):]]
     dump = "--dump" in sys.argv
     kernel = args[0]
     tmp = tempfile.mkdtemp(prefix="isa_")
