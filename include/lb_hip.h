@@ -309,9 +309,11 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * time steps per pass, bit 7 slabs exchange their halo after every launch instead of every two (no
  * halo cycle), bit 8 four time steps per pass (nx >= 512; whole-grid handles of >= 128 rows, slabs of >= 64), bit 9
  * four time steps per pass through 32 x 16 LDS tiles (whole-grid handles of >= 64 x 64 cells; for small grids), bit 10
- * k_step4 without its one-row-ahead gather, bit 11 k_step4 without the priority turns of the two waves of a SIMD, bit 13
- * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (all three on by
- * default; A/B switches).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
+ * k_step4 without its one-row-ahead gather, bit 11 k_step4 / k_step5 without the priority turns of the two waves of a SIMD,
+ * bit 12 five time steps per pass on overlapping strips (k_step5: whole-grid handles where bit 8 applies, not the
+ * velocity-inlet family; what the automatic choice takes from 1200^2 periodic / 1850^2 walled cells), bit 13
+ * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
+ * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);
 
 #ifdef __cplusplus
