@@ -14,7 +14,7 @@
 // is `pitch` floats (nx rounded up to 64 floats = 256 B); the nine plane-rows of one lattice row are stored together
 // ([row][plane][pitch]: the marching kernels then stream 2 regions per segment instead of 18 -- +12 % at 8192^2,
 // profiles/r02_experiments.txt; LB_FLAG_PLANAR keeps each plane contiguous, [plane][row][pitch]).  Rows -GHOST..-1 and
-// H..H+GHOST-1 are ghost rows (GHOST = 8: slab halo, deep enough for two four-step launches per exchange / don't-care
+// H..H+GHOST-1 are ghost rows (GHOST = 10: slab halo, deep enough for two five-step launches per exchange / don't-care
 // at walls), so element (k, x, y) of a slab of H rows lives at
 //   lattice + GUARD + (y+GHOST)*rowp + k*plane + x,      rowp = 9*pitch, plane = pitch   (planar: rowp = pitch,
 //                                                         plane = (H+2*GHOST)*pitch);
@@ -43,9 +43,9 @@
 
 namespace {
 
-constexpr int GHOST = 8;   // ghost rows below row 0 and above row H-1 of every plane: a slab runs two four-step
-                           // launches per halo exchange, the first one recomputing 4 of the neighbour's rows
-constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -7)
+constexpr int GHOST = 10;  // ghost rows below row 0 and above row H-1 of every plane: a slab runs two five-step
+                           // launches per halo exchange, the first one recomputing 5 of the neighbour's rows
+constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -9)
 constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (the marching kernels' last
                            // strip reads up to 257 cells past a row's end, every kernel 1 cell before its start)
 
@@ -156,7 +156,7 @@ struct lb_sim {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int min_h = 0;              // smallest slab height over the ranks (every rank must pick the same schedule)
-    float *halo_buf = nullptr;  // 4 x HALO_SEGS_DEEP (63) x nx floats: send north, send south, recv south, recv north
+    float *halo_buf = nullptr;  // 4 x HALO_SEGS_DEEP (81) x nx floats: send north, send south, recv south, recv north
     int ghost_depth = 0;        // ghost rows of lat[cur] hold this many of the neighbours' edge rows (0, 3, 6 or 8)
     int variant = -1;           // < 0: automatic (effective_variant)
     hipGraph_t graph = nullptr;            // GRAPH_STEPS single-step launches, captured for small grids
@@ -761,7 +761,7 @@ int lattice_plane_d2h(lb_sim *s, float *host, const float *origin, int k)
 // Entry i of an OUT table of one slab pairs with entry i of the IN table of its neighbour.
 struct HaloSeg { int k, row; };
 constexpr int HALO_SEGS = 18;          // D = 3
-constexpr int HALO_SEGS_DEEP = 63;     // D = 8 (45 for D = 6)
+constexpr int HALO_SEGS_DEEP = 81;     // D = 10 (63 for D = 8, 45 for D = 6)
 
 struct HaloTables {
     HaloSeg neg[HALO_SEGS_DEEP], pos[HALO_SEGS_DEEP];
@@ -795,7 +795,7 @@ struct HaloTables {
         return t;
     }
 };
-const HaloTables HALO3(3), HALO6(6), HALO8(8);
+const HaloTables HALO3(3), HALO6(6), HALO8(8), HALO10(10);
 const HaloSeg *const NORTH_OUT = HALO3.neg;   // + H
 const HaloSeg *const SOUTH_IN = HALO3.neg;    // + 0
 const HaloSeg *const SOUTH_OUT = HALO3.pos;   // + 0
@@ -988,9 +988,11 @@ int cycle_depth(const lb_sim *s, int h)
 {
     const int v = effective_variant(s);
     if (!(v & 64) || (v & 128) || !step3_applicable(s, h) || h < 32) return 0;
+    // (k_step5 on slabs: the ten-step cycle, ghost zone ten rows deep; not the velocity-inlet family -- step5_applicable)
+    if ((v & 4096) && (v & 256) && h >= 80 && s->p.bc_mode != LB_BC_VELOCITY_INLET) return 5;
     return ((v & 256) && h >= 64) ? 4 : 3;
 }
-const HaloTables &cycle_halo(int depth) { return depth == 4 ? HALO8 : HALO6; }
+const HaloTables &cycle_halo(int depth) { return depth == 5 ? HALO10 : (depth == 4 ? HALO8 : HALO6); }
 
 // bands of output rows [lo_s, hi_s) and [lo_n, hi_n): one wave per strip and band
 int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi_n, bool macro, int depth)
@@ -1007,14 +1009,14 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
 // outside the slab to write to).
 int slab_cycle_first(lb_sim *s, int D, bool last = false)
 {
-    const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
+    const int H = s->H, strips = D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W;
     const StepArgs probe = step_args(s, 0, 1, 1);
     const bool macro = last && !lazy_macro(s);
     int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D, H - D, (probe.ghost_n && !last) ? H + D : H,
                           macro, D);
     if (rc) return rc;
     // (wave slots left to the band launch running beside it: two bands x strips items, two waves each under k_step4)
-    if ((rc = launch_step2(s, s->stream, D, H - D, macro, 0, 0, 0, 2 * strips * (D == 4 ? STEP4_WAVES : 1), D))) return rc;
+    if ((rc = launch_step2(s, s->stream, D, H - D, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
@@ -1022,13 +1024,13 @@ int slab_cycle_first(lb_sim *s, int D, bool last = false)
 // E2 + C2 (the caller flips cur afterwards); ev_boundary = the 2D edge rows of the new lattice are complete
 int slab_cycle_second(lb_sim *s, bool macro, int D)
 {
-    const int H = s->H, strips = (s->p.nx + STRIP_W - 1) / STRIP_W;
+    const int H = s->H, strips = D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W;
     macro = macro && !lazy_macro(s);
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     int rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-    return launch_step2(s, s->stream, 2 * D, H - 2 * D, macro, 0, 0, 0, 2 * strips * (D == 4 ? STEP4_WAVES : 1), D);
+    return launch_step2(s, s->stream, 2 * D, H - 2 * D, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D);
 }
 
 // Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
@@ -2235,7 +2237,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
     int hmin = sims[0]->H;
     for (int i = 1; i < count; ++i) hmin = std::min(hmin, sims[i]->H);
     bool two = true, three = true;
-    int D = 4;
+    int D = 5;
     for (int i = 0; i < count; ++i) {
         two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i], hmin);
         three = three && (effective_variant(sims[i]) & 64) && step3_applicable(sims[i], hmin);

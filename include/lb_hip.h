@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 6
+#define LB_ABI_VERSION 7
 
 typedef enum {
     LB_OK = 0,
@@ -120,9 +120,9 @@ typedef struct {
  * semantics always store: their fields are not plain moments (imposed inlet speeds, wall overrides, momentum). */
 #define LB_FLAG_EAGER_MACRO 4
 
-/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the eight-step halo cycle
- * recomputes four of the neighbour's rows and reads the mask three rows beyond them. */
-#define LB_MASK_HALO_ROWS 7
+/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the ten-step halo cycle
+ * recomputes five of the neighbour's rows and reads the mask four rows beyond them. */
+#define LB_MASK_HALO_ROWS 9
 
 typedef struct lb_sim lb_sim; /* opaque: device buffers, streams, events, RCCL communicator */
 
@@ -228,9 +228,9 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps);
  * lb_comm_init is collective (every rank of the communicator calls it: the ranks agree on the smallest
  * slab height there, which decides the kernels and the exchange rhythm).  lb_check(across_ranks = 1) is the only
  * other collective (two all-reduces of three scalars, outside the data path).  Afterwards lb_run on a slab
- * handle exchanges halos itself: two four-step (slabs of >= 64 rows) or three-step (>= 32 rows) launches per
- * exchange with ghost zones eight / six rows deep when nx >= 512, otherwise one exchange of the 3-deep halo
- * per launch. */
+ * handle exchanges halos itself: two five-step (slabs of >= 80 rows), four-step (>= 64 rows; the velocity-inlet family)
+ * or three-step (>= 32 rows) launches per exchange with ghost zones ten / eight / six rows deep when nx >= 512,
+ * otherwise one exchange of the 3-deep halo per launch. */
 int lb_comm_available(void);               /* 0 when librccl can be loaded in this process (no communicator is made) */
 int lb_comm_unique_id(void *unique_id_128);
 int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks);
@@ -310,8 +310,9 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * halo cycle), bit 8 four time steps per pass (nx >= 512; whole-grid handles of >= 128 rows, slabs of >= 64), bit 9
  * four time steps per pass through 32 x 16 LDS tiles (whole-grid handles of >= 64 x 64 cells; for small grids), bit 10
  * k_step4 without its one-row-ahead gather, bit 11 k_step4 / k_step5 without the priority turns of the two waves of a SIMD,
- * bit 12 five time steps per pass on overlapping strips (k_step5: whole-grid handles where bit 8 applies, not the
- * velocity-inlet family; what the automatic choice takes from 1200^2 periodic / 1850^2 walled cells), bit 13
+ * bit 12 five time steps per pass on overlapping strips (k_step5: whole-grid handles where bit 8 applies and slabs of >= 80
+ * rows -- the ten-step halo cycle --, not the velocity-inlet family; what the automatic choice takes from 1200^2 periodic /
+ * 1850^2 walled cells of a whole grid, 1280^2 cells of a slab), bit 13
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);

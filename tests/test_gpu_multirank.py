@@ -30,8 +30,8 @@ def _env():
 #  subprocess.run -- which kills its child -- before pytest's thread-method timeout ends the whole session)
 @pytest.mark.timeout(2400, method="thread")
 def test_slabs_over_rccl_equal_the_undivided_run_bitwise(lbhip):
-    """tools/multi_gpu_check.py under torch.distributed.run: automatic kernel choice (eight-step halo cycle on
-    k_step4) and every explicit schedule x three boundary families x obstacle mask, each rank against the
+    """tools/multi_gpu_check.py under torch.distributed.run: automatic kernel choice (ten-step halo cycle on
+    k_step5) and every explicit schedule x three boundary families x obstacle mask, each rank against the
     undivided single-step run, bit for bit."""
     n = _gpus(lbhip)
     if n < 2:

@@ -24,7 +24,7 @@ def _env():
 @pytest.mark.parametrize("ranks", [2, 4])
 @pytest.mark.timeout(900, method="thread")
 def test_rank_processes_on_one_gpu_equal_the_undivided_run_bitwise(lbhip, ranks):
-    """2 and 4 rank processes on GPU 0: eight-step and six-step halo cycles, launch-by-launch schedules (three-, two-, single-step
+    """2 and 4 rank processes on GPU 0: ten-, eight- and six-step halo cycles, launch-by-launch schedules (three-, two-, single-step
     kernels), lone first halves and remainders (runs of 20 + 7 + 4 steps), three boundary families, obstacle masks, slabs of
     unequal height; the halo rows travel through memory mapped across the processes, the ranks meet at device-side flags."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_ranks_check.py"), "--ranks", str(ranks)],
@@ -45,12 +45,13 @@ def test_peer_transport_self_ring_equals_plain_run(lbhip):
     w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
     f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)
     mask = rng.random((nx, ny)) < 0.02
-    for variant in (97 | 256, 97, 33, 1):
+    for variant in (97 | 256 | 4096, 97 | 256, 97, 33, 1):
         one = Simulation(nx, ny, 1.6, bc="periodic", obstacle_mask=mask)
         one.set_variant(0)
         ring = Simulation(nx, ny, 1.6, bc="periodic", obstacle_mask=mask, halo=True)
         ring.set_variant(variant)
-        ring.set_obstacle_mask_halo(mask[:, -7:].T.copy(), mask[:, :7].T.copy())
+        d_ = ring.MASK_HALO_ROWS
+        ring.set_obstacle_mask_halo(mask[:, -d_:].T.copy(), mask[:, :d_].T.copy())
         d = ring.peer_export()
         ring.peer_connect(0, 1, d, d, ny)
         one.set_f(f0)

@@ -11,7 +11,7 @@ from test_gpu_parity import assert_fields_close, _random_state
 pytestmark = pytest.mark.gpu
 
 # NT / tile shapes / XCD order / two-, three-, four-step marching kernels / LDS-tile kernel / the automatic choice
-VARIANTS = (1, 9, 16, 24, 33, 41, 97, 105, 97 | 256, 105 | 256, 512, 512 | 1, -1)
+VARIANTS = (1, 9, 16, 24, 33, 41, 97, 105, 97 | 256, 105 | 256, 97 | 256 | 4096, 105 | 256 | 4096, 512, 512 | 1, -1)
 WIDTHS = (2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 600, 768, 1021, 1024, 1028, 1280)
 
 
@@ -60,7 +60,7 @@ def test_random_configuration(lbhip, oracle, seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LB_RANDOM_SLAB_SEEDS", "12"))))
 def test_random_slab_partition(lbhip, seed, sync_bits):
     """Random row-slab partitions run through the in-library multi-GPU schedule (lb_run_group: halo cycles of two
-    four- or three-step launches, launch-by-launch remainders, walls with bands of unequal height, masks) must
+    five-, four- or three-step launches, launch-by-launch remainders, walls with bands of unequal height, masks) must
     equal the undivided run bit for bit -- with the members' streams ordered by events alone (sync_bits 0: what lb_run
     relies on with RCCL) and with a device join after every exchange (2)."""
     from LB_D2Q9.simulation import Simulation
@@ -80,7 +80,7 @@ def _random_slab_partition_case(seed):
     nx = int(rng.choice((512, 516, 768, 1000, 1024, 1284)))
     nslabs = int(rng.integers(2, 6))
     ny = int(rng.integers(nslabs * 7, 700))                  # slab heights from 7 rows (no fused kernel) to 350
-    variant = int(rng.choice((-1, 97 | 256, 97, 97 | 128, 33, 1)))
+    variant = int(rng.choice((-1, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1)))
     mask = None
     if rng.integers(0, 2):
         mask = rng.random((nx, ny)) < 0.03
@@ -108,14 +108,14 @@ def _random_slab_partition_case(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LB_RANDOM_RING_SEEDS", "16"))))
 def test_random_self_ring(lbhip, seed):
     """The production slab path (lb_run with the RCCL exchange) as a one-rank periodic ring that sends its halo to itself:
-    random shapes, variants (eight- / six-step cycle, no cycle, two- and single-step launches), masks and sequences of run
+    random shapes, variants (ten- / eight- / six-step cycle, no cycle, two- and single-step launches), masks and sequences of run
     lengths (every transition between cycles, lone first halves and launch-by-launch steps, with whatever ghost depth the
     previous run left) against the plain whole-grid handle, bit for bit.  (tools/ring_stress.py is the same in a loop.)"""
     from LB_D2Q9.simulation import Simulation, comm_unique_id
     rng = np.random.default_rng(9000 + (71 if seed == 0 else seed))      # 9071: the case that found the ghost-depth bug
     nx = int(rng.choice((512, 516, 768, 1000, 1024, 1284, 2048)))
     ny = int(rng.integers(8, 700))
-    variant = int(rng.choice((-1, 97 | 256, 97, 97 | 128, 33, 1)))
+    variant = int(rng.choice((-1, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1)))
     mask = None
     if rng.integers(0, 2):
         mask = rng.random((nx, ny)) < 0.03

@@ -21,7 +21,7 @@ TU = r"""
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "%(root)s/include/lb_hip.h"
-namespace { constexpr int GHOST = 8; constexpr int MASK_GHOST = LB_MASK_HALO_ROWS; constexpr int GUARD = 512; }
+namespace { constexpr int GHOST = 10; constexpr int MASK_GHOST = LB_MASK_HALO_ROWS; constexpr int GUARD = 512; }
 #include "%(csrc)s/d2q9_cell.h"
 #include "%(csrc)s/kernels_fused.h"
 #include "%(csrc)s/kernels_step4.h"

@@ -8,7 +8,7 @@ Every child joins a gloo process group (CPU tensors: the bootstrap only carries 
 DistributedSlab(transport='peer') -- the halo rows are stored straight into the neighbours' ghost rows through device memory
 mapped across the processes, the ranks meet at device-side flags (include/lb_hip.h, lb_peer_connect) -- runs the cases of
 tools/multi_gpu_check.py and compares its rows with the UNDIVIDED grid, which it computes itself with the single-step kernel,
-bit for bit.  RCCL refuses several ranks on one device; this transport does not, so the eight-step / six-step halo cycles, the
+bit for bit.  RCCL refuses several ranks on one device; this transport does not, so the ten- / eight- / six-step halo cycles, the
 lone first half, the launch-by-launch remainder and the initial exchange of lb_run all execute with nranks > 1 on a 1-GPU box.
 Prints one line per case (rank 0) and exits non-zero on a mismatch."""
 import os
@@ -33,9 +33,11 @@ def child():
     from LB_D2Q9.slabs import DistributedSlab
     w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
     bad = 0
-    cases = [(2048, 1024 * world, -1, (19, 8, 5), ("periodic",))] if not quick else []       # automatic: eight-step cycle on k_step4
-    # explicit schedules on small slabs: eight-step cycle, six-step cycle, three-step launches without the cycle, two-step, single-step
-    cases += [(1024, 128 * world + 5, v, (20, 7, 4), ("periodic", "pipe", "cavity")) for v in ((97 | 256, 97, 97 | 128, 33, 1) if not quick else (97 | 256, 1))]
+    cases = [(2048, 1024 * world, -1, (23, 10, 5), ("periodic",))] if not quick else []       # automatic: ten-step cycle on k_step5
+    # explicit schedules on small slabs: ten-step cycle, eight-step cycle, six-step cycle, three-step launches without the cycle,
+    # two-step, single-step
+    cases += [(1024, 128 * world + 5, v, (20, 7, 4), ("periodic", "pipe", "cavity"))
+              for v in ((97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1) if not quick else (97 | 256 | 4096, 97 | 256, 1))]
     for nx, ny, variant, runs, families in cases:
         rng = np.random.default_rng(3)
         f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)

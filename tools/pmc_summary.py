@@ -89,7 +89,7 @@ def main():
         pass
 
     # calibration on the copy kernel (bytes known: lattice allocation read once, written once)
-    copy_bytes = (9 * (side + 16) * ((side + 63) // 64 * 64) + 1024) * 4      # 8 ghost rows per side, 2 x 512 guard floats
+    copy_bytes = (9 * (side + 20) * ((side + 63) // 64 * 64) + 1024) * 4      # 10 ghost rows per side, 2 x 512 guard floats
     copy_fetch = st.mean(pmc[("k_copy4<false>", "FETCH_SIZE")]) * 1024
     copy_write = st.mean(pmc[("k_copy4<false>", "WRITE_SIZE")]) * 1024
     fetch_corr = copy_bytes / copy_fetch
