@@ -177,9 +177,11 @@ __device__ __forceinline__ void march5(const StepArgs &a, const int x0, const in
     March5Ctx cx;
     cx.lane = threadIdx.x;
     const int xr = x0 + cx.lane * 4;                 // true column of my first cell: -4 .. ; may lie beyond either end of the box
-    // lanes beyond an end of the box: the periodic images (nx % 4 == 0), or -- walls -- copies of the lane at that end (their
+    // lanes beyond an end of the box: the periodic image (nx % 4 == 0), or -- walls -- copies of the lane at that end (their
     // values are never within reach of a stored cell: the wall column's rule rebuilds what it pulled from them)
-    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? xr - a.nx : xr);
+    // (periodic: only the first lane beyond the last column is anybody's skirt; the lanes behind it -- the last strip of 8192
+    //  columns stores 8 cells -- read what that lane reads, i.e. the same cache lines, instead of 240 more columns)
+    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? 0 : xr);
     else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
     cx.store_lane = cx.lane >= 1 && cx.lane <= 62 && xr < a.nx;
     cx.ym = ym; cx.n_iter = len + 4; cx.wy = wy; cx.slot = slot;
