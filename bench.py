@@ -66,6 +66,8 @@ MIN_BLOCKS, MIN_TIMED_S, MAX_BLOCKS = 5, 0.5, 2000
 #   behaviour); roofline.frac prices the K-step block average launch (frac_plain_launch: a launch inside a long run).
 #   Rounds 1-2 ("r2"): wall time included the closing barrier, the last launch of every block stored rho, u, v, and frac
 #   priced the plain launch.
+#   (The default block is 60 steps since the default kernel fuses five steps -- 48 until then, with four: a block should be whole
+#   launches of the deepest kernel, 60 = lcm(1..5); K is on the line.  Not a change of method.)
 METHODOLOGY = "r3-block-avg"
 
 
