@@ -223,6 +223,39 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
     assert_fields_close(sims[1], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
 
 
+@pytest.mark.parametrize("nx", [512, 740, 744, 748, 992, 996, 1000, 1236, 1241, 1488])
+@pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
+def test_five_step_kernel_strip_boundaries(lbhip, bc, nx):
+    """k_step5 marches overlapping strips laid 248 cells apart, each starting 4 cells early: widths around the multiples of
+    248 (the last strip stores 4, 0 + 248 or 244 cells; odd widths in the walled families), heights around the segment sizes,
+    with an obstacle mask whose solid cells sit on the strip seams, against the single-step kernel, bit for bit."""
+    from LB_D2Q9.simulation import Simulation
+    if bc == "periodic" and nx % 4:
+        nx += 4 - nx % 4
+    ny = 128 + (nx % 7) * 9
+    rng = np.random.default_rng(nx)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.02
+    for seam in range(244, nx - 1, 248):                  # the last stored cells of a strip and the first of the next one
+        mask[seam:seam + 8, ::3] = True
+    if bc != "periodic":
+        mask[0, :] = mask[-1, :] = False
+        mask[:, 0] = mask[:, -1] = False
+    out = []
+    for variant in (0, 97 | 256 | 4096):
+        s = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, inlet_rho=1.003, lid_u=0.05)
+        s.set_variant(variant)
+        if variant:
+            assert s.steps_per_launch() == 5 and "k_step5" in s.hot_kernel()
+        s.set_f(f0)
+        s.run(10)
+        s.run(7)
+        out.append(s.get_fields(("f", "rho", "u", "v")))
+        s.close()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
 @pytest.mark.parametrize("bc,nx,ny", [("pipe", 96, 64), ("periodic", 64, 96), ("cavity", 130, 70), ("periodic", 256, 256),
                                       ("pipe", 301, 101)])
 @pytest.mark.parametrize("masked", [False, True])
