@@ -622,7 +622,7 @@ __global__ void k_check_spread(const CheckPartial *res, double *d, float *m)
     m[0] = res->max_usq;
 }
 
-// Halo pack / unpack: the halo of one edge is 18 (3 rows deep), 45 (6 deep) or 63 (8 deep) row segments scattered
+// Halo pack / unpack: the halo of one edge is 18 (3 rows deep), 45 (6 deep), 63 (8 deep) or 81 (10 deep) row segments scattered
 // over the planes (HaloTables on the host side).  One tiny kernel gathers both edges into two contiguous
 // buffers (so that an exchange is one send + one receive per neighbour), one scatters the received
 // buffers into the ghost rows.  `neg` lists rows -D..-1 (leaves north, counted from row H / arrives

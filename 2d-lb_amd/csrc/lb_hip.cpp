@@ -756,6 +756,7 @@ int lattice_plane_d2h(lb_sim *s, float *host, const float *origin, int k)
 //   D = 3 (18 segments): one three-step launch per exchange; also the format of lb_halo_export/import.
 //   D = 6 (45 segments): two three-step launches per exchange (lb_run's six-step cycle);
 //   D = 8 (63 segments): two four-step launches per exchange (eight-step cycle).
+//   D = 10 (81 segments): two five-step launches per exchange (ten-step cycle, k_step5).
 // "neg" tables hold rows -D..-1 (what leaves through a north edge, counted from row H; what a south
 // ghost zone receives, counted from row 0), "pos" tables rows 0..D-1 (leaves south / received north).
 // Entry i of an OUT table of one slab pairs with entry i of the IN table of its neighbour.
@@ -2613,7 +2614,7 @@ int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach,
     CheckPartial h;
     if (across_ranks) {
         // sum_rho and the count travel as two doubles (exact up to 2^53 cells), the maximum on its own
-        double *d = reinterpret_cast<double *>(s->halo_buf);             // (>= 4 x 63 x nx floats, free between runs)
+        double *d = reinterpret_cast<double *>(s->halo_buf);             // (>= 4 x 81 x nx floats, free between runs)
         float *m = reinterpret_cast<float *>(d + 4);
         hipLaunchKernelGGL(k_check_spread, dim3(1), dim3(1), 0, s->stream, (const CheckPartial *)res, d, m);
         HIP_TRY(hipGetLastError());
