@@ -288,7 +288,7 @@ __global__ __launch_bounds__((TileShape<TW, TH, CPT>::THREADS), (CPT == 2 ? 8 : 
 }
 
 // ---- the velocity-inlet family's wall-row bands, D time steps in one launch ---------------------------------------
-// A three- or four-step marching pass of that family covers rows [D, ny-D); the 2D rows next to each wall, stacked, are a
+// A three-, four- or five-step marching pass of that family covers rows [D, ny-D); the 2D rows next to each wall, stacked, are a
 // velocity-inlet lattice of 4D rows of their own (lb_hip.cpp vel_band_pass: the north row's pull reaches "row ny-2" = band
 // row 4D-2, the south row's "row 1" = band row 1; the seam in the middle spreads one row of garbage per step and reaches
 // exactly the rows that are not kept).  Round 2 copied them into a second handle, ran D single steps there and copied

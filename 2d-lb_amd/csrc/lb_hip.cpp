@@ -300,8 +300,8 @@ int effective_variant(const lb_sim *s)
     if (cells >= 1024.0 * 1024.0) v = (v & ~16) | 32 | 64;
     if (cells >= 1280.0 * 1280.0) v |= 256;
     // ... and five wherever four are (k_step5, overlapping strips: periodic 2048^2 298 against 250 k MLUPS, 4096^2 315 against 289 k,
-    // 8192^2 327-346 against 306-319 k; pipe 8192^2 346 against 309 k: profiles/r04_experiments.txt section 10); the velocity-inlet
-    // family and slabs stay on four (step5_applicable)
+    // 8192^2 327-346 against 306-319 k; pipe 8192^2 346 against 309 k: profiles/r04_experiments.txt section 10), in every family,
+    // whole grids and slabs (cycle_depth) alike
     if (cells >= 1280.0 * 1280.0) v |= 4096;
     return v;
 }
@@ -377,11 +377,14 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
 void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs,
                       int row_end, bool macro, bool nts, int depth)
 {
-    const int waves = (depth == 4) ? STEP4_WAVES : 4;
-    const dim3 block(64, waves), grid(depth == 4 ? items : (items + waves - 1) / waves);
+    const int waves = (depth >= 4) ? STEP4_WAVES : 4;
+    const dim3 block(64, waves), grid(depth >= 4 ? items : (items + waves - 1) / waves);
 #define LB_LAUNCHV(MASK, MACRO, NTS)                                                                                      \
     do {                                                                                                                  \
-        if (depth == 4)                                                                                                   \
+        if (depth == 5)                                                                                                   \
+            hipLaunchKernelGGL((k_step5<LB_BC_VELOCITY_INLET, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, \
+                               nsegs, row_end);                                                                           \
+        else if (depth == 4)                                                                                              \
             hipLaunchKernelGGL((k_step4<LB_BC_VELOCITY_INLET, MASK, MACRO, false, false>), grid, block, 0, st, a, strips,   \
                                seg_rows, nsegs, row_end);                                                                 \
         else if (depth == 3)                                                                                              \
@@ -424,9 +427,8 @@ bool step4_applicable(const lb_sim *s)
     return true;
 }
 
-// five steps per pass (k_step5; asked for by variant bit 12 only): whole-grid handles; not the velocity-inlet family, whose
-// wall-row bands (k_vel_band) are built for three and four steps
-bool step5_applicable(const lb_sim *s) { return step4_applicable(s) && s->p.bc_mode != LB_BC_VELOCITY_INLET; }
+// five steps per pass (k_step5) on a whole-grid handle (slabs: inside the ten-step halo cycle, cycle_depth)
+bool step5_applicable(const lb_sim *s) { return step4_applicable(s); }
 
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
@@ -486,7 +488,11 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         // wave, tools/wave_timeline.py: +18 % pipe, +10..16 % cavity; the velocity-inlet columns also read the stored u, v),
         // within the same number of wave slots: pipe / cavity +5..8 %, velocity inlet +19..30 % (profiles/r02_experiments.txt)
         static const double edge_env = getenv("LB_EDGE_COST") ? atof(getenv("LB_EDGE_COST")) : 0.0;          // tuning knob
-        const double edge_cost = edge_env > 0.0 ? edge_env : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? 1.6 : 1.2);
+        // (k_step5 has no halo-lane work, so the wall column's rule weighs more in its rows: velocity inlet, 8192^2, edge cost 1.2:
+        //  301-305 k MLUPS, 1.6: 306-310 k, 2.0: 322-339 k, 2.5: 329-348 k, 3.0: 321-328 k; 4096^2: 252 / 274 / 290 / 298 / 276 k;
+        //  pipe and cavity stay at 1.2: profiles/r04_experiments.txt section 10)
+        const double edge_cost = edge_env > 0.0 ? edge_env
+                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : 1.2);
         if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
             const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
             const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
@@ -989,8 +995,8 @@ int cycle_depth(const lb_sim *s, int h)
 {
     const int v = effective_variant(s);
     if (!(v & 64) || (v & 128) || !step3_applicable(s, h) || h < 32) return 0;
-    // (k_step5 on slabs: the ten-step cycle, ghost zone ten rows deep; not the velocity-inlet family -- step5_applicable)
-    if ((v & 4096) && (v & 256) && h >= 80 && s->p.bc_mode != LB_BC_VELOCITY_INLET) return 5;
+    // (k_step5 on slabs: the ten-step cycle, ghost zone ten rows deep)
+    if ((v & 4096) && (v & 256) && h >= 80) return 5;
     return ((v & 256) && h >= 64) ? 4 : 3;
 }
 const HaloTables &cycle_halo(int depth) { return depth == 5 ? HALO10 : (depth == 4 ? HALO8 : HALO6); }
@@ -1056,9 +1062,8 @@ bool use_tile_kernel(const lb_sim *s)
     //  Infinity Cache -- 1920^2 is 265 MB, 2048^2 302 MB -- in every family)
     // (round 4: five steps per pass on overlapping strips, k_step5 / tiles: periodic 1024^2 166 / 198 k, 1280^2 233 / 218 k, 1536^2
     //  261 / 240 k, 1792^2 294 / 249 k, 2048^2 305 / 209 k; cavity 1280^2 173 / 202 k, 1536^2 200 / 220 k, 1792^2 225 / 231 k,
-    //  2048^2 259 / 194 k: profiles/r04_step5_sweep.txt.  Where k_step5 does not apply -- the velocity-inlet family has no tiles
-    //  anyway -- the change-over to k_step4 stays at 1950^2.)
-    const double side = !step5_applicable(s) ? 1950.0 : (s->p.bc_mode == LB_BC_PERIODIC ? 1200.0 : 1850.0);
+    //  2048^2 259 / 194 k: profiles/r04_step5_sweep.txt; until then the change-over to k_step4 was at 1950^2)
+    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1200.0 : 1850.0;
     return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 
@@ -1073,7 +1078,7 @@ int whole_grid_depths(const lb_sim *s)
                       (v & 4096) && step5_applicable(s));
 }
 
-// A d-step pass (d = 3, 4) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
+// A d-step pass (d = 3, 4, 5) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
 // the marching kernel takes them, treating the wall rows as don't-care like any wall.  The 2d wall-side rows are advanced
 // as a lattice of their own: the 2d rows next to each wall, stacked, ARE a velocity-inlet lattice of 4d rows -- row 0's pull
 // reaches "row ny-2" = band row 4d-2, row ny-1's "row 1" = band row 1 -- except at the seam in the middle, whose garbage
@@ -1092,7 +1097,8 @@ int vel_band_pass(lb_sim *s, int d, bool macro)
     const dim3 grid((unsigned)((s->p.nx + (64 - 2 * d) - 1) / (64 - 2 * d))), blk(256);
 #define LB_LAUNCHB(MASK, MACRO)                                                                          \
     do {                                                                                                 \
-        if (d == 4) hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 4>), grid, blk, 0, q, a);                \
+        if (d == 5) hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 5>), grid, blk, 0, q, a);                \
+        else if (d == 4) hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 4>), grid, blk, 0, q, a);           \
         else hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 3>), grid, blk, 0, q, a);                       \
     } while (0)
     if (s->has_mask) { if (macro) LB_LAUNCHB(true, true); else LB_LAUNCHB(true, false); }

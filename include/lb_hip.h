@@ -228,7 +228,7 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps);
  * lb_comm_init is collective (every rank of the communicator calls it: the ranks agree on the smallest
  * slab height there, which decides the kernels and the exchange rhythm).  lb_check(across_ranks = 1) is the only
  * other collective (two all-reduces of three scalars, outside the data path).  Afterwards lb_run on a slab
- * handle exchanges halos itself: two five-step (slabs of >= 80 rows), four-step (>= 64 rows; the velocity-inlet family)
+ * handle exchanges halos itself: two five-step (slabs of >= 80 rows), four-step (>= 64 rows)
  * or three-step (>= 32 rows) launches per exchange with ghost zones ten / eight / six rows deep when nx >= 512,
  * otherwise one exchange of the 3-deep halo per launch. */
 int lb_comm_available(void);               /* 0 when librccl can be loaded in this process (no communicator is made) */
@@ -311,8 +311,8 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * four time steps per pass through 32 x 16 LDS tiles (whole-grid handles of >= 64 x 64 cells; for small grids), bit 10
  * k_step4 without its one-row-ahead gather, bit 11 k_step4 / k_step5 without the priority turns of the two waves of a SIMD,
  * bit 12 five time steps per pass on overlapping strips (k_step5: whole-grid handles where bit 8 applies and slabs of >= 80
- * rows -- the ten-step halo cycle --, not the velocity-inlet family; what the automatic choice takes from 1200^2 periodic /
- * 1850^2 walled cells of a whole grid, 1280^2 cells of a slab), bit 13
+ * rows -- the ten-step halo cycle; what the automatic choice takes from 1200^2 periodic / 1850^2 walled cells of a whole
+ * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 13
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);

@@ -201,7 +201,7 @@ def test_full_size_families_default_and_four_step_kernel_equal_single_step_kerne
 def test_wall_column_strips_with_shorter_segments_bitwise(lbhip, bc, nx, ny, masked):
     """In the wall families k_step4 and k_step5 give the first and the last strip (the wall columns) shorter segments than the
     others (lb_hip.cpp launch_step2: `edge_seg_rows`); grids of many shapes -- few / many strips, short / tall, odd widths, with a
-    mask, the velocity-inlet family's interior pass (four steps only) -- against the single-step kernel, bit for bit, 11 steps."""
+    mask, the velocity-inlet family's interior pass -- against the single-step kernel, bit for bit, 11 steps."""
     from LB_D2Q9.simulation import Simulation
     rng = np.random.default_rng(nx + ny)
     mask = None
@@ -217,7 +217,7 @@ def test_wall_column_strips_with_shorter_segments_bitwise(lbhip, bc, nx, ny, mas
         sim = Simulation(nx, ny, 1.5, bc=bc, inlet_rho=1.0005, lid_u=0.05, inlet_u=0.02, obstacle_mask=mask)
         sim.set_variant(variant)
         if variant & 4096:
-            assert sim.steps_per_launch() == (4 if bc == "velocity_inlet" else 5)
+            assert sim.steps_per_launch() == 5
         sim.init_equilibrium(rho, u, v)
         sim.run(8)
         sim.run(3)

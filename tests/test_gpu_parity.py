@@ -627,7 +627,7 @@ def test_velocity_inlet_family_vs_reference_kernels(lbhip, oracle):
                                           (1536, 300, True)])
 def test_velocity_inlet_fused_kernels_vs_oracle_and_unfused(lbhip, oracle, nx, ny, masked):
     """lb_run on the velocity-inlet family = fused kernels (k_step; k_step2 from nx >= 512, >= 64 rows; from 128 rows also
-    k_step3 / k_step4 on the rows no wall-row link reaches + the wall-row bands advanced as a small lattice of their own): against the
+    k_step3 / k_step4 / k_step5 on the rows no wall-row link reaches + the wall-row bands advanced as a small lattice of their own): against the
     oracle's restatement of D2Q9.cl:263-374 driven as OLD/opencl.py:281-327 drives it (pinned bit-exact to the executed
     kernels by o2_velocity_inlet_45x23), against the engine's own un-fused phase sequence, and the two fused kernels
     against each other bit for bit.  Random initial populations, so that the four corner cells' never-written links
@@ -649,14 +649,14 @@ def test_velocity_inlet_fused_kernels_vs_oracle_and_unfused(lbhip, oracle, nx, n
     outs = {}
     variants = [("single", 0), ("two", 33), ("auto", -1)]
     if nx >= 512 and ny >= 128:
-        variants += [("three", 97), ("four", 353)]
+        variants += [("three", 97), ("four", 353), ("five", 353 | 4096)]
     for name, variant in variants:
         s = Simulation(nx, ny, omega, bc="velocity_inlet", inlet_u=uw, outlet_u=ue, obstacle_mask=mask)
         s.set_variant(variant)
         if variant == 33 and nx >= 512 and ny >= 64:
             assert s.steps_per_launch() == 2 and "k_step2" in s.hot_kernel()
-        if variant in (97, 353):
-            assert s.steps_per_launch() == (3 if variant == 97 else 4)
+        if variant in (97, 353, 353 | 4096):
+            assert s.steps_per_launch() == {97: 3, 353: 4, 4449: 5}[variant]
         s.set_fields(np.ones((nx, ny)), u0, v0)
         s.set_f(f0)
         s.run(1)
