@@ -448,24 +448,18 @@ __device__ __forceinline__ f4a from_right(f4a v, float halo, int lane)
 // un-overwritten).
 __device__ __forceinline__ bool step1_rows(const StepArgs &a, int r, int &rr, int &ym, int &yp)
 {
-    rr = r; ym = r - 1; yp = r + 1;
-    if (a.wrap_y == 2) {
-        // VELOCITY_INLET: rows 0 and h-1 share their vertical links, i.e. the rows beyond a wall row are the rows on
-        // the far side of the OTHER wall row: row -1 is row h-2, row h is row 1 (period h-1)
-        rr = r < 0 ? r + a.h - 1 : (r >= a.h ? r - a.h + 1 : r);
-        ym = rr - 1 < 0 ? a.h - 2 : rr - 1;
-        yp = rr + 1 >= a.h ? 1 : rr + 1;
-        return true;
-    }
-    if (a.wrap_y) {
-        rr = r < 0 ? r + a.h : (r >= a.h ? r - a.h : r);
-        ym = rr - 1 < 0 ? a.h - 1 : rr - 1;
-        yp = rr + 1 >= a.h ? 0 : rr + 1;
-        return true;
-    }
-    if (r < 0) return a.ghost_s != 0;
-    if (r >= a.h) return a.ghost_n != 0;
-    return true;
+    // (selects, no branches: everything here is wave-uniform, and as early returns it cut the marching kernels' loop bodies into
+    //  two dozen basic blocks -- instruction selection then no longer saw a row's base and its lane offset in one block)
+    // wrap_y: 1 = the grid is periodic in y on this GPU (period h); 2 = VELOCITY_INLET: rows 0 and h-1 share their vertical links,
+    // i.e. the rows beyond a wall row are the rows on the far side of the OTHER wall row: row -1 is row h-2, row h is row 1
+    // (period h-1); 0 = rows beyond the slab are ghost rows or lie outside a wall
+    const int h = a.h, w = a.wrap_y, per = h - (w == 2 ? 1 : 0);
+    const int wr = r < 0 ? r + per : (r >= h ? r - per : r);
+    rr = w ? wr : r;
+    const int m = rr - 1, p = rr + 1;
+    ym = (w && m < 0) ? h - w : m;              // (w = 1: row h-1; w = 2: row h-2)
+    yp = (w && p >= h) ? w - 1 : p;             // (w = 1: row 0; w = 2: row 1)
+    return w || (r < 0 ? a.ghost_s != 0 : (r >= h ? a.ghost_n != 0 : true));
 }
 
 // Step 1 of the single cell (hx, row rr): the strip's halo cell, executed by one edge lane.  Same
