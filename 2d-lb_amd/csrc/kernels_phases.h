@@ -233,7 +233,8 @@ __global__ void k_hydro_vel(const PhaseArgs a)
 
 // cython_dim.pyx:204-269 `move_bcs` (+ :468-513 obstacle swap) of one cell; u_here = the stored u of this cell (inlet /
 // outlet columns: the value the previous update_hydro left there)
-__device__ __forceinline__ void c1_bcs_cell(const PhaseArgs &a, int x, int y, float u_here, bool solid, Cell &c)
+template <typename A>      // (PhaseArgs, or the marching kernels' StepArgs: nx, ny, rho_in, rho_out)
+__device__ __forceinline__ void c1_bcs_cell(const A &a, int x, int y, float u_here, bool solid, Cell &c)
 {
     const int lx = a.nx - 1, ly = a.ny - 1;
     if (x == 0 && y >= 1 && y < ly) {                         // inlet, stored u of the previous update_hydro
@@ -305,7 +306,8 @@ __global__ void k1_move(const PhaseArgs a)
 }
 
 // cython_dim.pyx:302-333 `update_hydro` (+ :459-466 obstacle zeroing) of one cell
-__device__ __forceinline__ void c1_moments(const PhaseArgs &a, int x, int y, bool solid, float f0, float f1, float f2,
+template <typename A>
+__device__ __forceinline__ void c1_moments(const A &a, int x, int y, bool solid, float f0, float f1, float f2,
                                            float f3, float f4, float f5, float f6, float f7, float f8, float &rho,
                                            float &ux, float &uy)
 {

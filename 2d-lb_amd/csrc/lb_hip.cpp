@@ -76,6 +76,7 @@ int fail(int code, const char *fmt, ...)
 #include "kernels_step5.h"
 #include "kernels_tile.h"
 #include "kernels_phases.h"
+#include "kernels_step5c.h"
 
 namespace {
 
@@ -236,6 +237,7 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.seg_stride = 0;
     a.edge_seg_rows = 0;
     a.tile_launch_order = (s->variant >= 0 && (s->variant & 8192)) ? 1 : 0;    // (A/B switch: explicit variants only)
+    a.rule_last = 0;
     a.diag = s->diag;
     a.prio_turns = 0;      // (set by launch_step2 from the variant)
     a.nts = 0;
@@ -513,6 +515,21 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
     a.nts = nts ? 1 : 0;                       // (the marching kernels take it at run time)
+    if (s->p.semantics == LB_SEM_CYTHON) {
+        // the Cython path's five-step march (k1_step5): `macro` = this is the run's last launch -- it stores rho, u, v and is not
+        // followed by the next step's boundary rule
+        a.rule_last = macro ? 0 : 1;
+        const dim3 block(64, STEP4_WAVES), grid(items);
+        if (s->has_mask) {
+            if (macro) hipLaunchKernelGGL((k1_step5<true, true>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
+            else hipLaunchKernelGGL((k1_step5<true, false>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
+        } else {
+            if (macro) hipLaunchKernelGGL((k1_step5<false, true>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
+            else hipLaunchKernelGGL((k1_step5<false, false>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
+        }
+        HIP_TRY(hipGetLastError());
+        return LB_OK;
+    }
     switch (kernel_bc(s)) {
     case LB_BC_PIPE_I: launch_step2_bc<LB_BC_PIPE_I>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
     case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
@@ -1270,6 +1287,14 @@ int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 :
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)
 bool cython_tiles(const lb_sim *s) { return s->p.nx >= 64 && s->H >= 64 && (s->variant < 0 || (s->variant & 512)); }
+// ... and five through the marching kernel on overlapping strips (k1_step5) when an explicit variant with bit 12 asks for it: the
+// kernel is bitwise right and, with the path's scalar cell functions and its rule at twenty sites of the loop body, half as fast
+// as the tiles (3751 x 1251 with the cylinder: 80 k against 168 k MLUPS; profiles/r04_experiments.txt section 11) -- never the default
+bool cython_march(const lb_sim *s)
+{
+    if (s->p.nx < 512 || s->H < 128 || !marching_planes_fit(s)) return false;
+    return s->variant >= 0 && (s->variant & 4096) != 0;
+}
 
 bool autotune_applies(const lb_sim *s)
 {
@@ -2043,11 +2068,15 @@ int lb_run(lb_sim *s, int n_steps)
         // ceiling of a pass that moves 72 B per cell), then a launches of four steps each through LDS tiles (k1_tile4);
         // grids too small for tiles, or LB_VARIANT / lb_set_variant bit 9 clear with an explicit variant: single steps only
         const dim3 blk(64, 4), grd((unsigned)((s->pitch / 4 + 63) / 64), (unsigned)((s->H + 3) / 4));
-        const bool tiles = cython_tiles(s);
+        // (k1_step5, where it applies: n = 5a + rem, the remainder first -- four steps through the tiles, or step by step)
+        const bool tiles = cython_tiles(s), march = cython_march(s);
         int left = n_steps;
         while (left > 0) {
             const PhaseArgs a = phase_args(s);
-            if (tiles && left % TILE_T == 0) {
+            if (march && left % 5 == 0) {
+                if ((rc = launch_step2(s, s->stream, 0, s->H, left == 5, 0, 0, 0, 0, 5))) return rc;
+                left -= 5;
+            } else if (tiles && (march ? left % 5 == TILE_T : left % TILE_T == 0)) {
                 const int tiles_x = (s->p.nx + 31) / 32, tiles_y = (s->H + 15) / 16, n_tiles = tiles_x * tiles_y;
                 const dim3 tg((n_tiles + 7) / 8 * 8), tb(TileShape<32, 16, 2>::THREADS);    // (eight equal shares: xcd_band_tile)
                 const bool lastp = (left == TILE_T);
@@ -2648,7 +2677,7 @@ int lb_steps_per_launch(lb_sim *s)
     if (s && s->cpu) return 1;
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int n = 1;
-    if (s->p.semantics == LB_SEM_CYTHON) return cython_tiles(s) ? TILE_T : 1;
+    if (s->p.semantics == LB_SEM_CYTHON) return cython_march(s) ? 5 : (cython_tiles(s) ? TILE_T : 1);
     if (!s->multi_slab()) {
         const int depths = whole_grid_depths(s);
         for (int d = 2; d <= 5; ++d)
@@ -2694,7 +2723,8 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET", "PIPE, D2Q9i"};
     const char *kernel = "k_step";
     if (s->p.semantics == LB_SEM_CYTHON)
-        kernel = cython_tiles(s) ? "k1_tile4 (Cython path, LDS tiles)" : "k1_fstep (Cython path)";
+        kernel = cython_march(s) ? "k1_step5 (Cython path, marching strips, five steps per pass)"
+                                 : (cython_tiles(s) ? "k1_tile4 (Cython path, LDS tiles)" : "k1_fstep (Cython path)");
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";

@@ -28,6 +28,7 @@ namespace { constexpr int GHOST = 10; constexpr int MASK_GHOST = LB_MASK_HALO_RO
 #include "%(csrc)s/kernels_step5.h"
 #include "%(csrc)s/kernels_tile.h"
 #include "%(csrc)s/kernels_phases.h"
+#include "%(csrc)s/kernels_step5c.h"
 void isa_stats_force(hipStream_t st) { void *p = (void *)(&%(kernel)s); hipLaunchKernel(p, dim3(1), dim3(1), nullptr, 0, st); }
 """
 
