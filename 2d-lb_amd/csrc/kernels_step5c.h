@@ -75,30 +75,115 @@ __device__ __forceinline__ void c1_row1_load(const StepArgs &a, int y, int x4, b
     }
 }
 
-// moments with their overrides, equilibrium, relaxation and -- RULE -- the next step's rule of my four cells of row y, in place;
-// k1_fstep's loop body
+// cell j (run-time index) of my four: select chains -- these run in the rare branches only
+__device__ __forceinline__ float c1_pick(const f4a &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void c1_put(f4a &v, int j, float x)
+{
+    v.x = j == 0 ? x : v.x; v.y = j == 1 ? x : v.y; v.z = j == 2 ? x : v.z; v.w = j == 3 ? x : v.w;
+}
+
+// Moments with their overrides, equilibrium, relaxation and -- `rule` -- the next step's rule of my four cells of row y, in place:
+// k1_fstep's loop body (kernels_phases.h), arranged as collide_row arranges the OpenCL path's.
+//   Straight-line, all four cells as two packed pairs: c1_moments' sums in ITS order (rho = f0 + ... + f8 left to right, the
+//   velocity sums as written there), the wall rows' and the solid cells' zero velocity as selects, then equilibrate_t -- the
+//   same operations as feq_cell + "f (1 - omega) + omega feq" (held bitwise by the tests).
+//   Rare, one copy each: the cell in column 0 / nx-1 again as a scalar cell from its ORIGINAL links (its moments are overridden by
+//   the pinned density: c1_moments in full), and the rule -- cell by cell in a wall row, else that one cell -- through c1_bcs_cell.
+//   The rule's obstacle swap for solid cells anywhere else: selects on the pairs.
 template <bool MASK>
-__device__ __forceinline__ void c1_collide_row(const StepArgs &a, int x4, int y, f4a (&q)[9], uc4 mk, bool rule, f4a &r4, f4a &u4,
-                                               f4a &v4)
+__device__ __forceinline__ void c1_collide_row(const StepArgs &a, int x4, int y, f4a (&q)[9], uc4 mk, bool rule, bool first,
+                                               bool last, int jl, f4a &r4, f4a &u4, f4a &v4)
 {
     const int lx = a.nx - 1, ly = a.ny - 1;
     const bool wall_row = (y == 0 || y == ly);
+    const int jc = first ? 0 : jl;                  // my wall-column cell, if I hold one
+    Cell own = {};
+    if (first || last)
+        own = Cell{c1_pick(q[0], jc), c1_pick(q[1], jc), c1_pick(q[2], jc), c1_pick(q[3], jc), c1_pick(q[4], jc),
+                   c1_pick(q[5], jc), c1_pick(q[6], jc), c1_pick(q[7], jc), c1_pick(q[8], jc)};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = x4 + j;
-        const bool solid = MASK && mk[j] != 0;
+    for (int h = 0; h < 2; ++h) {
+        f2a f[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = h ? q[k].zw : q[k].xy;
+        f2a rho = f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + f[8];
+        const f2a inv = lb_rcp(rho);
+        f2a ux = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8]) * inv;
+        f2a uy = (f[5] + f[2] + f[6] - f[7] - f[4] - f[8]) * inv;
+        if (wall_row) { ux = f2a{0.f, 0.f}; uy = f2a{0.f, 0.f}; }
+        if (MASK) {
+            const bool s0 = mk[2 * h] != 0, s1 = mk[2 * h + 1] != 0;
+            ux = f2a{s0 ? 0.f : ux.x, s1 ? 0.f : ux.y};
+            uy = f2a{s0 ? 0.f : uy.x, s1 ? 0.f : uy.y};
+        }
+        {   // feq_cell + "f (1 - omega) + omega feq" on a pair
+            const f2a one = lb_splat<f2a>(1.f);
+            const f2a usq = lb_fma(ux, ux, uy * uy);
+            const f2a base = lb_fma(lb_splat<f2a>(-1.5f), usq, one);
+            const f2a keep = lb_splat<f2a>(1.f - a.omega), om = lb_splat<f2a>(a.omega);
+            const f2a r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
+            const f2a r13 = 3.f * r1, r23 = 3.f * r2;
+            f2a e[9];
+            e[0] = r0 * base;
+            feq_pair<f2a>(r1, r13, ux, base, e[1], e[3]);
+            feq_pair<f2a>(r1, r13, uy, base, e[2], e[4]);
+            feq_pair<f2a>(r2, r23, ux + uy, base, e[5], e[7]);
+            feq_pair<f2a>(r2, r23, ux - uy, base, e[8], e[6]);
+            // (two roundings, no fma: what the compiler makes of k1_fstep's "f (1 - omega) + omega feq" -- held by the bitwise tests)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const f2a a_ = f[k] * keep; const f2a b_ = om * e[k]; f[k] = a_ + b_; }
+        }
+        if (h) { r4.zw = rho; u4.zw = ux; v4.zw = uy; }
+        else   { r4.xy = rho; u4.xy = ux; v4.xy = uy; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (h) q[k].zw = f[k];
+            else q[k].xy = f[k];
+        }
+    }
+    if (first || last) {                            // the inlet / outlet column's cell: pinned density, its own velocity
+        const int x = x4 + jc;
+        const bool solid = MASK && (jc == 0 ? mk.x : (jc == 1 ? mk.y : (jc == 2 ? mk.z : mk.w))) != 0;
         float rho, ux, uy;
-        c1_moments(a, x, y, solid, q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j], rho, ux, uy);
-        r4[j] = rho; u4[j] = ux; v4[j] = uy;
+        c1_moments(a, x, y, solid, own.f0, own.f1, own.f2, own.f3, own.f4, own.f5, own.f6, own.f7, own.f8, rho, ux, uy);
         float fe[9];
         feq_cell(rho, ux, uy, fe);
+        const float o[9] = {own.f0, own.f1, own.f2, own.f3, own.f4, own.f5, own.f6, own.f7, own.f8};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) q[k][j] = q[k][j] * (1.f - a.omega) + a.omega * fe[k];
-        if (rule && x <= lx && (wall_row || x == 0 || x == lx || solid)) {
-            Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
-            c1_bcs_cell(a, x, y, ux, solid, c);
-            q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
-            q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
+        for (int k = 0; k < 9; ++k) c1_put(q[k], jc, o[k] * (1.f - a.omega) + a.omega * fe[k]);
+        c1_put(r4, jc, rho); c1_put(u4, jc, ux); c1_put(v4, jc, uy);
+    }
+    if (!rule) return;
+    if (wall_row || first || last) {
+        const int j0 = wall_row ? 0 : jc, j1 = wall_row ? 3 : jc;
+#pragma unroll 1
+        for (int j = j0; j <= j1; ++j) {
+            const int x = x4 + j;
+            if (x > lx) break;
+            const bool solid = MASK && (j == 0 ? mk.x : (j == 1 ? mk.y : (j == 2 ? mk.z : mk.w))) != 0;
+            Cell c = {c1_pick(q[0], j), c1_pick(q[1], j), c1_pick(q[2], j), c1_pick(q[3], j), c1_pick(q[4], j),
+                      c1_pick(q[5], j), c1_pick(q[6], j), c1_pick(q[7], j), c1_pick(q[8], j)};
+            c1_bcs_cell(a, x, y, c1_pick(u4, j), solid, c);
+            c1_put(q[1], j, c.f1); c1_put(q[2], j, c.f2); c1_put(q[3], j, c.f3); c1_put(q[4], j, c.f4);
+            c1_put(q[5], j, c.f5); c1_put(q[6], j, c.f6); c1_put(q[7], j, c.f7); c1_put(q[8], j, c.f8);
+        }
+    }
+    if (MASK) {                                     // solid cells that the branch above has not been through: the rule = the swap
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bool s0 = mk[2 * h] != 0, s1 = mk[2 * h + 1] != 0;
+            if (wall_row) s0 = s1 = false;
+            if (first || last) {
+                if (jc == 2 * h) s0 = false;
+                if (jc == 2 * h + 1) s1 = false;
+            }
+            auto swap2 = [&](f4a &p, f4a &o) {
+                const f2a pp = h ? p.zw : p.xy, oo = h ? o.zw : o.xy;
+                const f2a pn = f2a{s0 ? oo.x : pp.x, s1 ? oo.y : pp.y}, on = f2a{s0 ? pp.x : oo.x, s1 ? pp.y : oo.y};
+                if (h) { p.zw = pn; o.zw = on; }
+                else { p.xy = pn; o.xy = on; }
+            };
+            swap2(q[1], q[3]); swap2(q[2], q[4]); swap2(q[5], q[7]); swap2(q[6], q[8]);
         }
     }
 }
@@ -204,7 +289,7 @@ __device__ __forceinline__ void march5c_iter(const StepArgs &a, const March5cCtx
     f4a (&q1)[9] = cur.q;
     f4a r4, u4, v4;
     const uc4 mk = cur.mk;
-    if (cur.have) c1_collide_row<MASK>(a, x4, y1, q1, mk, true, r4, u4, v4);
+    if (cur.have) c1_collide_row<MASK>(a, x4, y1, q1, mk, true, first, last, jl, r4, u4, v4);
     if (NST == 1) lds_publish<DOWN>(cx.P4, lane, 6, q1);
     const Col3 c1n = c1_col_of(q1, first, last, jl);
     // ---- step 2 of position i-1 (window 1, registers) ----------------------------------------------------------
@@ -214,7 +299,7 @@ __device__ __forceinline__ void march5c_iter(const StepArgs &a, const March5cCtx
         const int y2 = row_at(i - 1);
         c1_gather<DOWN>(a, w1, w1.e2, w1.e5, w1.e6, q1, st.col[0], y2, first, last, jl, q2);
         c1_window_push<DOWN>(w1, q1, far_wall(y1));
-        c1_collide_row<MASK>(a, x4, y2, q2, mask_bits(st.mhist, 1), true, r4, u4, v4);
+        c1_collide_row<MASK>(a, x4, y2, q2, mask_bits(st.mhist, 1), true, first, last, jl, r4, u4, v4);
         if (NST == 2) lds_publish<DOWN>(cx.P4, lane, 3, q2);
         c2n = c1_col_of(q2, first, last, jl);
     } else {
@@ -228,7 +313,7 @@ __device__ __forceinline__ void march5c_iter(const StepArgs &a, const March5cCtx
         const int y3 = row_at(i - 2);
         c1_gather<DOWN>(a, w2, w2.e2, w2.e5, w2.e6, q2, st.col[1], y3, first, last, jl, q3);
         c1_window_push<DOWN>(w2, q2, far_wall(row_at(i - 1)));
-        c1_collide_row<MASK>(a, x4, y3, q3, mask_bits(st.mhist, 2), true, r4, u4, v4);
+        c1_collide_row<MASK>(a, x4, y3, q3, mask_bits(st.mhist, 2), true, first, last, jl, r4, u4, v4);
         if (NST == 3) lds_publish<DOWN>(cx.P3, lane, 6, q3);
         c3n = c1_col_of(q3, first, last, jl);
     } else if (NST == 2) {
@@ -249,7 +334,7 @@ __device__ __forceinline__ void march5c_iter(const StepArgs &a, const March5cCtx
         }
         c1_gather<DOWN>(a, w3, eA, eB, eC, q3, st.col[2], y4, first, last, jl, q4);
         c1_lds_window_push<DOWN>(W3, lane, it, q3, far_wall(row_at(i - 2)));
-        c1_collide_row<MASK>(a, x4, y4, q4, mask_bits(st.mhist, 3), true, r4, u4, v4);
+        c1_collide_row<MASK>(a, x4, y4, q4, mask_bits(st.mhist, 3), true, first, last, jl, r4, u4, v4);
         if (NST == 4) lds_publish<DOWN>(cx.P4, lane, 3, q4);
         c4n = c1_col_of(q4, first, last, jl);
     } else if (NST == 3) {
@@ -270,7 +355,7 @@ __device__ __forceinline__ void march5c_iter(const StepArgs &a, const March5cCtx
         c1_gather<DOWN>(a, w4, eA, eB, eC, q4, st.col[3], y5, first, last, jl, t);
         c1_lds_window_push<DOWN>(W4, lane, it, q4, far_wall(row_at(i - 3)));
         const bool in_grid = (y5 >= 0 && y5 <= ly);
-        if (in_grid) c1_collide_row<MASK>(a, x4, y5, t, mask_bits(st.mhist, 4), a.rule_last != 0, r4, u4, v4);
+        if (in_grid) c1_collide_row<MASK>(a, x4, y5, t, mask_bits(st.mhist, 4), a.rule_last != 0, first, last, jl, r4, u4, v4);
         if (cx.store_lane && in_grid) {
             float *d = a.dst + (long long)y5 * a.pitch;
             store_row9<false>(a.nts != 0, d, S, x4, t);

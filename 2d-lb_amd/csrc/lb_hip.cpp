@@ -1288,8 +1288,8 @@ int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 :
 // explicit variant without bit 9 asks for single steps (k1_fstep)
 bool cython_tiles(const lb_sim *s) { return s->p.nx >= 64 && s->H >= 64 && (s->variant < 0 || (s->variant & 512)); }
 // ... and five through the marching kernel on overlapping strips (k1_step5) when an explicit variant with bit 12 asks for it: the
-// kernel is bitwise right and, with the path's scalar cell functions and its rule at twenty sites of the loop body, half as fast
-// as the tiles (3751 x 1251 with the cylinder: 80 k against 168 k MLUPS; profiles/r04_experiments.txt section 11) -- never the default
+// kernel is bitwise right and faster than the tiles from ~6000^2 cells only (3751 x 1251 with the cylinder: 136 k against 174 k
+// MLUPS, 8192^2: 205 against 193 k; profiles/r04_experiments.txt section 11) -- not the default
 bool cython_march(const lb_sim *s)
 {
     if (s->p.nx < 512 || s->H < 128 || !marching_planes_fit(s)) return false;

@@ -53,15 +53,23 @@ def main():
     print("bitwise mismatches:", bad)
     if "--no-time" not in sys.argv:
         for nx, ny in ((3751, 1251), (4096, 4096), (8192, 8192)):
+            yy, xx = np.meshgrid(np.arange(ny), np.arange(nx))
+            mask = (xx - nx // 4) ** 2 + (yy - ny // 2) ** 2 < (ny // 10) ** 2          # a cylinder, as in the reference's case
             for name, variant in (("k1_tile4", 512), ("k1_step5", 4096 | 512), ("k1_tile4", 512), ("k1_step5", 4096 | 512)):
-                s = Simulation(nx, ny, 1.3, bc="pipe", semantics="cython", inlet_rho=1.004, outlet_rho=1.0)
+                s = Simulation(nx, ny, 1.3, bc="pipe", semantics="cython", inlet_rho=1.004, outlet_rho=1.0, obstacle_mask=mask)
                 s.set_variant(variant)
                 spl = s.steps_per_launch()
-                n = 20 * spl
+                n = 200
                 s.run(n)
                 s.sync()
-                best = min(s.timed_run(n) for _ in range(3))
-                print("%5d x %5d %-9s steps/launch %d  %7.1f k MLUPS" % (nx, ny, name, spl, nx * ny * n / best / 1e6), flush=True)
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    s.run(n)
+                    s.sync()
+                    best = min(best, time.perf_counter() - t0)
+                print("%5d x %5d %-9s steps/launch %d  %7.1f k MLUPS (wall clock around run(200))" % (
+                    nx, ny, name, spl, nx * ny * n / best / 1e9), flush=True)
                 s.close()
     sys.exit(1 if bad else 0)
 
