@@ -500,7 +500,10 @@ def main():
                                 if not getattr(eng, "eager_macro", False) else "stored by the last launch of every run()",
                 "note": "achieved = %g B x cells of one launch (compulsory: each plane read once, written once%s) / "
                         "launch time; effective_GBps = 72 B x lattice updates / time is NOT an HBM rate when "
-                        "steps_per_launch > 1" % (bytes_per_cell, "" if bytes_per_cell == B_ALG else ", + 1 B obstacle mask")}
+                        "steps_per_launch > 1 (effective_x_roofline = value against the single-pass roofline 8 TB/s / 72 B per "
+                        "update); frac prices ONE launch, whatever number of time steps it fuses: five since round 4 (k_step5), "
+                        "four before (k_step4: launch 0.85 ms, frac 0.71, 314 k MLUPS)"
+                        % (bytes_per_cell, "" if bytes_per_cell == B_ALG else ", + 1 B obstacle mask")}
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",
