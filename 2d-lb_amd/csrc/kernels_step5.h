@@ -36,6 +36,7 @@ struct March5Ctx {
     bool store_lane;
     unsigned slot;
     f4a (*W3)[64], (*W4)[64], (*P3)[64], (*P4)[64];     // my two LDS windows (steps 3/4, 4/5), the other wave's
+    f4a (*R2)[64], (*Q2)[64];                           // PF: the ring of window 2 (six slots), the other wave's
 };
 
 // gather of the next stage for my 4 cells from a window {d0,d1,d3,g2,g5,g6} and the newest row q; what lanes 0 / 63 take
@@ -60,12 +61,13 @@ __device__ __forceinline__ void skirt_gather(const Window &w, const f4a (&q)[9],
 // One iteration: position i is loaded and takes step 1, position i-1 step 2 (window 1), i-2 step 3 (window 2), i-3 step 4 (LDS
 // window 3), i-4 step 5 (LDS window 4; stored).  NST = number of stages that have a row: 1..4 in iterations 0..3 (code of their
 // own, i a constant: the pipeline fills, the two waves of the pair hand over), 5 in the loop.
-// PF: `cur` holds position i on entry, gathered during the previous iteration, and is gathered anew -- position i + 1 -- as soon
-// as step 2 has taken what it needs from it: the loads fly while steps 3, 4, 5 compute, in the registers the row just consumed
-// occupied (k_step4's one-row-ahead gather keeps two row buffers and copies one into the other every row: 46 more registers).
-// NOT launched: wherever the gather is placed the compiler ends up with ~21 scratch accesses per row for it (the 42 registers of
-// the row in flight do not fit beside two register windows), and the kernel runs at 277-295 k instead of 327 k MLUPS at 8192^2
-// (profiles/r04_experiments.txt section 10).
+// PF (not launched): `cur` holds position i on entry, gathered during the previous iteration, and is gathered anew -- position
+// i + 1 -- as soon as step 2 has taken what it needs from it: the loads fly while steps 3, 4, 5 compute, in the registers the row
+// just consumed occupied.  Beside two register windows the compiler spills the row in flight wherever the gather sits (~21 scratch
+// accesses per row: 277-295 k instead of 327 k MLUPS at 8192^2), so PF also moves window 2's ring into LDS (its links 0,1,3 stay in
+// registers): 227 registers, no scratch, 48 KB of LDS per workgroup, i.e. SIX waves per CU -- and the same speed as eight waves
+// without the gather (8192^2: 335.4-336.7 k against 330.0-335.8 k MLUPS, 4096^2 307-310 k against 313-336 k: not a matter of
+// loads in flight any more; profiles/r04_experiments.txt section 10).
 template <int BC, bool MASK, bool MACRO, bool PF, bool DOWN, int NST>
 __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &cx, const int i_, March5State &st, Row1 &cur)
 {
@@ -87,7 +89,7 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
     // (steps 1 and 2 of its position 0 come through my still idle window 4 -- slots 6..8, then 3..5 -- into my register windows;
     //  steps 3 and 4 went straight into the ring slots of my LDS windows)
     if (NST == 2) { w1.g2 = W4[6][lane]; w1.g5 = W4[7][lane]; w1.g6 = W4[8][lane]; }
-    if (NST == 3) { w2.g2 = W4[3][lane]; w2.g5 = W4[4][lane]; w2.g6 = W4[5][lane]; }
+    if (NST == 3 && !PF) { w2.g2 = W4[3][lane]; w2.g5 = W4[4][lane]; w2.g6 = W4[5][lane]; }
     // ---- step 1 of position i (from memory) --------------------------------------------------------------------
     if (!PF) row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
     f4a (&q1)[9] = cur.q;
@@ -109,7 +111,10 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
         window_push_dir<DOWN>(w1, q1);              // (every window takes its new row as soon as its old one has been gathered from)
         if (PF) row1_load<BC, MASK>(a, r_next, x4, false, 0, cur);
         collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(st.mhist, 1), r4, u4, v4);
-        if (NST == 2) lds_publish<DOWN>(cx.P4, lane, 3, q2);    // my position 0 after step 2 -> the other wave's window 2 (mailbox)
+        if (NST == 2) {                             // my position 0 after step 2 -> the other wave's window 2
+            if (PF) lds_publish<DOWN>(cx.Q2, lane, 0, q2);      // (its ring, the slot it reads in iteration 2)
+            else lds_publish<DOWN>(cx.P4, lane, 3, q2);         // (registers there: through its idle window 4)
+        }
     } else {
         window_push_dir<DOWN>(w1, q1);
         if (PF) row1_load<BC, MASK>(a, r_next, x4, false, 0, cur);
@@ -119,12 +124,27 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
     if (NST >= 3) {
         int r3, t0_, t1_;
         (void)step1_rows(a, row_at(i - 2), r3, t0_, t1_);
-        skirt_gather<DOWN>(w2, q2, q3);
-        window_push_dir<DOWN>(w2, q2);
+        if (PF) {                                   // window 2: links 0,1,3 in registers, the ring in LDS
+            typedef Dir<DOWN> D;
+            const int gs = 3 * (it & 1);
+            w2.g2 = cx.R2[gs][lane]; w2.g5 = cx.R2[gs + 1][lane]; w2.g6 = cx.R2[gs + 2][lane];
+            skirt_gather<DOWN>(w2, q2, q3);
+            cx.R2[gs][lane] = q2[D::A]; cx.R2[gs + 1][lane] = q2[D::B]; cx.R2[gs + 2][lane] = q2[D::C];
+            w2.d0 = q2[0]; w2.d1 = q2[1]; w2.d3 = q2[3];
+        } else {
+            skirt_gather<DOWN>(w2, q2, q3);
+            window_push_dir<DOWN>(w2, q2);
+        }
         collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(st.mhist, 2), r4, u4, v4);
         if (NST == 3) lds_publish<DOWN>(cx.P3, lane, 6, q3);    // my position 0 after step 3 -> the other wave's window 3
     } else if (NST == 2) {
-        window_push_dir<DOWN>(w2, q2);              // (position 0 after step 2 enters window 2)
+        if (PF) {                                   // (position 0 after step 2 enters window 2: ring slot of odd iterations)
+            typedef Dir<DOWN> D;
+            cx.R2[3][lane] = q2[D::A]; cx.R2[4][lane] = q2[D::B]; cx.R2[5][lane] = q2[D::C];
+            w2.d0 = q2[0]; w2.d1 = q2[1]; w2.d3 = q2[3];
+        } else {
+            window_push_dir<DOWN>(w2, q2);
+        }
     }
     // ---- step 4 of position i-3 (window 3, LDS) ----------------------------------------------------------------
     f4a q4[9];
@@ -172,7 +192,7 @@ __device__ __forceinline__ void march5_iter(const StepArgs &a, const March5Ctx &
 // upward or downward; len + 4 iterations.
 template <int BC, bool MASK, bool MACRO, bool PF, bool DOWN>
 __device__ __forceinline__ void march5(const StepArgs &a, const int x0, const int ym, const int len, const int wy,
-                                       f4a (*lds_win)[2][9][64], const unsigned slot)
+                                       f4a (*mine)[64], f4a (*other)[64], const unsigned slot)
 {
     March5Ctx cx;
     cx.lane = threadIdx.x;
@@ -185,10 +205,8 @@ __device__ __forceinline__ void march5(const StepArgs &a, const int x0, const in
     else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
     cx.store_lane = cx.lane >= 1 && cx.lane <= 62 && xr < a.nx;
     cx.ym = ym; cx.n_iter = len + 4; cx.wy = wy; cx.slot = slot;
-    cx.W3 = lds_win[wy][0];
-    cx.W4 = lds_win[wy][1];
-    cx.P3 = lds_win[wy ^ 1][0];
-    cx.P4 = lds_win[wy ^ 1][1];
+    cx.W3 = mine; cx.W4 = mine + 9; cx.R2 = mine + 18;         // (slots: window 3, window 4, PF: the ring of window 2)
+    cx.P3 = other; cx.P4 = other + 9; cx.Q2 = other + 18;
     March5State st = {};
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
     Row1 cur;
@@ -208,7 +226,7 @@ constexpr int step5_strips(int nx) { return (nx + STEP5_VALID - 1) / STEP5_VALID
 template <int BC, bool MASK, bool MACRO, bool PF>
 __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step5(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
-    __shared__ f4a lds_win[STEP4_WAVES][2][9][64];
+    __shared__ f4a lds_win[STEP4_WAVES][PF ? 24 : 18][64];
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int item = xcd_item(blockIdx.x, gridDim.x);
     const unsigned slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u;
@@ -231,8 +249,8 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step5(const StepArgs a,
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
     const int x0 = sx * STEP5_VALID - STEP5_SKIRT;
-    if (wy == 0) march5<BC, MASK, MACRO, PF, true>(a, x0, ym, ym - ya, 0, lds_win, slot);
-    else march5<BC, MASK, MACRO, PF, false>(a, x0, ym, yb - ym, 1, lds_win, slot);
+    if (wy == 0) march5<BC, MASK, MACRO, PF, true>(a, x0, ym, ym - ya, 0, lds_win[0], lds_win[1], slot);
+    else march5<BC, MASK, MACRO, PF, false>(a, x0, ym, yb - ym, 1, lds_win[1], lds_win[0], slot);
 }
 
 }  // namespace
