@@ -20,7 +20,7 @@ def main():
         rng = np.random.default_rng(9000 + seed)
         nx = int(rng.choice((512, 516, 768, 1000, 1024, 1284, 2048)))
         ny = int(rng.integers(8, 700))
-        variant = int(rng.choice((-1, 97 | 256, 97, 97 | 128, 33, 1)))
+        variant = int(rng.choice((-1, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1)))
         mask = None
         if rng.integers(0, 2):
             mask = rng.random((nx, ny)) < 0.03
