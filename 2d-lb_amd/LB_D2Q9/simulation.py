@@ -207,7 +207,7 @@ class Simulation(object):
     def run(self, num_iterations, wait=True):
         """num_iterations fused time steps.  The reference returns with the work complete (it waits after
         every kernel); pass wait=False to only enqueue (never blocks the host).  A blocking run of at least four
-        times the tuning pass (4 x 281 + 7 = 1131 steps; 4 x 761 + 7 on grids <= 768^2) first times the candidate kernel
+        times the tuning pass (4 x 305 + 7 = 1227 steps; 4 x 833 + 7 on grids <= 768^2) first times the candidate kernel
         configurations on its own first steps (lb_autotune_quick: they are bitwise equivalent, the trajectory is
         unchanged) and keeps the fastest for this grid; shorter runs use the size heuristic (or call autotune())."""
         n = int(num_iterations)

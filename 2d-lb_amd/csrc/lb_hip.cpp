@@ -74,6 +74,7 @@ int fail(int code, const char *fmt, ...)
 #include "kernels_fused.h"
 #include "kernels_step4.h"
 #include "kernels_step5.h"
+#include "kernels_step6.h"
 #include "kernels_tile.h"
 #include "kernels_phases.h"
 #include "kernels_step5c.h"
@@ -305,6 +306,10 @@ int effective_variant(const lb_sim *s)
     // 8192^2 327-346 against 306-319 k; pipe 8192^2 346 against 309 k: profiles/r04_experiments.txt section 10), in every family,
     // whole grids and slabs (cycle_depth) alike
     if (cells >= 1280.0 * 1280.0) v |= 4096;
+    // ... and six (k_step6: six waves per CU, one more stage window in the LDS they leave) on the large whole grids: periodic
+    // 8192^2 414 against 320-327 k MLUPS, 4096^2 370 / 315 k, 3072^2 337 / 293 k, 2048^2 281 / 287 k; pipe 8192^2 351-373 / 325 k,
+    // 4096^2 275 / 306 k (profiles/r04_experiments.txt section 14); slabs stay on five (ten ghost rows)
+    if (!s->multi_slab() && cells >= (s->p.bc_mode == LB_BC_PERIODIC ? 2560.0 * 2560.0 : 6000.0 * 6000.0)) v |= 16384;
     return v;
 }
 
@@ -347,7 +352,9 @@ void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int ite
     const dim3 block(64, waves), grid(depth >= 4 ? items : (items + waves - 1) / waves);
 #define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
     do {                                                                                                         \
-        if (depth == 5)                                                                                          \
+        if (depth == 6)                                                                                          \
+            hipLaunchKernelGGL((k_step6<BC, MASK, MACRO>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end); \
+        else if (depth == 5)                                                                                        \
             hipLaunchKernelGGL((k_step5<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end); \
         else if (depth == 4) {                                                                                      \
             if (step4_prefetch(BC, MASK, MACRO) && pf_on)                                                        \
@@ -431,6 +438,8 @@ bool step4_applicable(const lb_sim *s)
 
 // five steps per pass (k_step5) on a whole-grid handle (slabs: inside the ten-step halo cycle, cycle_depth)
 bool step5_applicable(const lb_sim *s) { return step4_applicable(s); }
+// six steps per pass (k_step6): whole-grid handles; not the velocity-inlet family (its wall-row bands stop at five)
+bool step6_applicable(const lb_sim *s) { return step4_applicable(s) && s->p.bc_mode != LB_BC_VELOCITY_INLET; }
 
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
@@ -459,7 +468,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
     // (k_step5: overlapping strips, 248 cells apart)
-    const int strips = depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W;
+    const int strips = depth == 6 ? step6_strips(s->p.nx) : (depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     int segs, seg_rows, extra_items = 0;
     if (nsegs_fixed > 0) {
         segs = nsegs_fixed;
@@ -471,6 +480,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         int waves_per_cu = s->tuned_wpc > 0 ? s->tuned_wpc : 8;
         static const int wpc_env = getenv("LB_STEP2_WAVES_PER_CU") ? atoi(getenv("LB_STEP2_WAVES_PER_CU")) : 0;   // tuning knob
         if (wpc_env > 0) waves_per_cu = wpc_env;
+        if (depth == 6 && waves_per_cu > 6) waves_per_cu = 6;        // (k_step6: 48 KB of LDS per workgroup, three per CU)
         // (k_step4: an item is a PAIR of segments, marched by the two waves of a workgroup from its middle line: two
         //  wave slots each; `capacity`, `segs`, `seg_rows` then count pairs)
         const int per_item = (depth >= 4) ? STEP4_WAVES : 1;
@@ -494,7 +504,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         //  301-305 k MLUPS, 1.6: 306-310 k, 2.0: 322-339 k, 2.5: 329-348 k, 3.0: 321-328 k; 4096^2: 252 / 274 / 290 / 298 / 276 k;
         //  pipe and cavity stay at 1.2: profiles/r04_experiments.txt section 10)
         const double edge_cost = edge_env > 0.0 ? edge_env
-                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : 1.2);
+                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : (depth == 6 ? 2.0 : 1.2));
         if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
             const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
             const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
@@ -973,16 +983,16 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
 int next_advance(int allowed, int left)
 {
     int D = 1;
-    for (int d = 2; d <= 5; ++d)
+    for (int d = 2; d <= 6; ++d)
         if (allowed & (1 << d)) D = d;
     const int rem = left % D;
     for (int d = std::min(rem == 0 ? D : rem, left); d > 1; --d)
         if (allowed & (1 << d)) return d;
     return 1;
 }
-int depth_mask(bool two, bool three, bool four = false, bool five = false)
+int depth_mask(bool two, bool three, bool four = false, bool five = false, bool six = false)
 {
-    return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0) | (five ? 32 : 0);
+    return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0) | (five ? 32 : 0) | (six ? 64 : 0);
 }
 
 // Both compute streams wait for the other one's kernel and for the halo of the lattice just written.
@@ -1089,10 +1099,11 @@ int whole_grid_depths(const lb_sim *s)
     if (use_tile_kernel(s)) return depth_mask(false, false, true);      // k_tile4 + single steps for the remainder
     if (s->variant < 0 && s->tuned_steps)
         return depth_mask(step2_applicable(s) && s->tuned_steps >= 2, step3_applicable(s) && s->tuned_steps >= 3,
-                          step4_applicable(s) && s->tuned_steps >= 4, step5_applicable(s) && s->tuned_steps >= 5);
+                          step4_applicable(s) && s->tuned_steps >= 4, step5_applicable(s) && s->tuned_steps >= 5,
+                          step6_applicable(s) && s->tuned_steps >= 6);
     const int v = effective_variant(s);
     return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s),
-                      (v & 4096) && step5_applicable(s));
+                      (v & 4096) && step5_applicable(s), (v & 16384) && step6_applicable(s));
 }
 
 // A d-step pass (d = 3, 4, 5) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
@@ -1176,7 +1187,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
     // (k_step4 at 8192^2 on one box: 4 waves per CU 189 k MLUPS, 6: 243 k, 8: 232 k, 12: 210 k -- profiles/r02_experiments.txt)
-    const Cand cands[] = {{5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
+    const Cand cands[] = {{6, 6}, {5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
     // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1 (the five-step candidates: 2 x 5; compared by time per step);
     // small grids: 36, so that the single-step candidate runs the way it would (hipGraph replay of 16 launches)
     const int per12 = small_grid(s) ? 36 : 12;
@@ -1211,7 +1222,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     bool usable[NC];
     for (int c = 0; c < NC; ++c) {
         ms_min[c] = 0.f;
-        usable[c] = !(cands[c].steps == 5 && !step5_applicable(s)) &&
+        usable[c] = !(cands[c].steps == 6 && !step6_applicable(s)) && !(cands[c].steps == 5 && !step5_applicable(s)) &&
                     !(cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) && !(cands[c].wpc < 0 && !tile_applicable(s)) &&
                     !(cands[c].steps == 3 && !step3_applicable(s)) && !(cands[c].steps == 2 && !step2_applicable(s));
     }
@@ -1281,8 +1292,8 @@ int corners_patch(lb_sim *s, int which)
     return LB_OK;
 }
 
-// steps a quick (one-round) tuning pass consumes at most: 10 candidates x 2 samples x 12 (36) steps, 2 x 2 x 10, + 1
-int autotune_quick_cost(const lb_sim *s) { return 10 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 1; }
+// steps a quick (one-round) tuning pass consumes at most: 11 candidates x 2 samples x 12 (36) steps, 2 x 2 x 10, + 1
+int autotune_quick_cost(const lb_sim *s) { return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 1; }
 
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)
@@ -2680,7 +2691,7 @@ int lb_steps_per_launch(lb_sim *s)
     if (s->p.semantics == LB_SEM_CYTHON) return cython_march(s) ? 5 : (cython_tiles(s) ? TILE_T : 1);
     if (!s->multi_slab()) {
         const int depths = whole_grid_depths(s);
-        for (int d = 2; d <= 5; ++d)
+        for (int d = 2; d <= 6; ++d)
             if (depths & (1 << d)) n = d;
     } else {
         const int v = effective_variant(s);
@@ -2728,6 +2739,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";
+        else if (spl == 6) kernel = "k_step6 (marching strips, six steps per pass: two stage windows in registers, one split, two in wave-private LDS)";
         else if (spl == 5) kernel = "k_step5 (marching strips, five steps per pass: two stage windows in registers, two in wave-private LDS)";
         else if (spl == 4) kernel = "k_step4 (marching strips, stage windows in registers + wave-private LDS)";
         else if (spl == 3) kernel = "k_step3 (marching strips, register windows)";

@@ -312,7 +312,8 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * k_step4 without its one-row-ahead gather, bit 11 k_step4 / k_step5 without the priority turns of the two waves of a SIMD,
  * bit 12 five time steps per pass on overlapping strips (k_step5: whole-grid handles where bit 8 applies and slabs of >= 80
  * rows -- the ten-step halo cycle; what the automatic choice takes from 1200^2 periodic / 1850^2 walled cells of a whole
- * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 13
+ * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 14 six time steps per pass (k_step6: whole-grid handles,
+ * not the velocity-inlet family; automatic from 2560^2 periodic / 6000^2 walled cells), bit 13
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);

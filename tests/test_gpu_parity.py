@@ -201,12 +201,12 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
     sims = []
     # single step / two-step / + NT stores / three-step (+ two-step remainder) / four-step (+ remainders) /
     # four steps through LDS tiles (+ single-step remainders) / five-step on overlapping strips (+ remainders)
-    for variant in (0, 32, 33, 97, 97 | 256, 512, 97 | 256 | 4096):
+    for variant in (0, 32, 33, 97, 97 | 256, 512, 97 | 256 | 4096, 97 | 256 | 4096 | 16384):
         s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
-        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4, 4449: 5}[variant]
+        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4, 4449: 5, 20833: 6}[variant]
         s.set_f(f0)
-        s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step) = 2+5 (five-step)
+        s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step) = 2+5 (five-step) = 1+6
         s.run(4)                      # 4 = 2+2 = 1+3 = 4
         sims.append(s.get_fields(("f", "rho", "u", "v")))
     for k in ("f", "rho", "u", "v"):
@@ -216,6 +216,7 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
         assert np.array_equal(sims[0][k], sims[4][k]), k          # four steps per pass (LDS windows): still bitwise
         assert np.array_equal(sims[0][k], sims[5][k]), k          # four steps per pass (LDS tiles): still bitwise
         assert np.array_equal(sims[0][k], sims[6][k]), k          # five steps per pass (overlapping strips): still bitwise
+        assert np.array_equal(sims[0][k], sims[7][k]), k          # six steps per pass (k_step6): still bitwise
     code = {"pipe": oracle.BC_PIPE, "periodic": oracle.BC_PERIODIC, "cavity": oracle.BC_CAVITY}[bc]
     o = oracle.O2Sim(nx, ny, 1.6, code, 1.004, 1., 0.06, 1., mask=mask)
     o.set_f(f0)
@@ -223,12 +224,13 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
     assert_fields_close(sims[1], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
 
 
-@pytest.mark.parametrize("nx", [512, 740, 744, 748, 992, 996, 1000, 1236, 1241, 1488])
+@pytest.mark.parametrize("nx", [512, 716, 720, 724, 740, 744, 748, 960, 964, 992, 996, 1000, 1196, 1236, 1241, 1440, 1488])
 @pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
-def test_five_step_kernel_strip_boundaries(lbhip, bc, nx):
-    """k_step5 marches overlapping strips laid 248 cells apart, each starting 4 cells early: widths around the multiples of
-    248 (the last strip stores 4, 0 + 248 or 244 cells; odd widths in the walled families), heights around the segment sizes,
-    with an obstacle mask whose solid cells sit on the strip seams, against the single-step kernel, bit for bit."""
+def test_five_and_six_step_kernel_strip_boundaries(lbhip, bc, nx):
+    """k_step5 / k_step6 march overlapping strips laid 248 / 240 cells apart, each starting 4 / 8 cells early: widths around the
+    multiples of 248 and 240 (the last strip stores a few cells, or none + a whole strip; odd widths in the walled families),
+    heights around the segment sizes, with an obstacle mask whose solid cells sit on the strip seams, against the single-step
+    kernel, bit for bit."""
     from LB_D2Q9.simulation import Simulation
     if bc == "periodic" and nx % 4:
         nx += 4 - nx % 4
@@ -236,24 +238,25 @@ def test_five_step_kernel_strip_boundaries(lbhip, bc, nx):
     rng = np.random.default_rng(nx)
     f0 = _random_state(rng, nx, ny)
     mask = rng.random((nx, ny)) < 0.02
-    for seam in range(244, nx - 1, 248):                  # the last stored cells of a strip and the first of the next one
+    for seam in list(range(244, nx - 1, 248)) + list(range(236, nx - 1, 240)):     # the last stored cells of a strip and the first of the next
         mask[seam:seam + 8, ::3] = True
     if bc != "periodic":
         mask[0, :] = mask[-1, :] = False
         mask[:, 0] = mask[:, -1] = False
     out = []
-    for variant in (0, 97 | 256 | 4096):
+    for variant in (0, 97 | 256 | 4096, 97 | 256 | 4096 | 16384):
         s = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, inlet_rho=1.003, lid_u=0.05)
         s.set_variant(variant)
         if variant:
-            assert s.steps_per_launch() == 5 and "k_step5" in s.hot_kernel()
+            spl = 6 if variant & 16384 else 5
+            assert s.steps_per_launch() == spl and ("k_step%d" % spl) in s.hot_kernel()
         s.set_f(f0)
-        s.run(10)
+        s.run(12)
         s.run(7)
         out.append(s.get_fields(("f", "rho", "u", "v")))
         s.close()
     for k in out[0]:
-        assert np.array_equal(out[0][k], out[1][k]), k
+        assert np.array_equal(out[0][k], out[1][k]) and np.array_equal(out[0][k], out[2][k]), k
 
 
 @pytest.mark.parametrize("bc,nx,ny", [("pipe", 96, 64), ("periodic", 64, 96), ("cavity", 130, 70), ("periodic", 256, 256),

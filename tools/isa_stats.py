@@ -26,6 +26,7 @@ namespace { constexpr int GHOST = 10; constexpr int MASK_GHOST = LB_MASK_HALO_RO
 #include "%(csrc)s/kernels_fused.h"
 #include "%(csrc)s/kernels_step4.h"
 #include "%(csrc)s/kernels_step5.h"
+#include "%(csrc)s/kernels_step6.h"
 #include "%(csrc)s/kernels_tile.h"
 #include "%(csrc)s/kernels_phases.h"
 #include "%(csrc)s/kernels_step5c.h"

@@ -13,6 +13,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from LB_D2Q9.simulation import Simulation  # noqa: E402
 
 W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+SIX = "--six" in sys.argv                       # k_step6 (variant bit 14) instead of k_step5 (bit 12)
+DEEP = 97 | 256 | 4096 | (16384 if SIX else 0)
+DEEP_SPL = 6 if SIX else 5
 
 
 def state(rng, nx, ny, amp=0.02):
@@ -32,7 +35,7 @@ def bitwise():
             mask[0, :] = mask[-1, :] = False
             mask[:, 0] = mask[:, -1] = False
         out = []
-        for variant in (0, 97 | 256 | 4096):
+        for variant in (0, DEEP):
             kw = dict(inlet_rho=1.004, lid_u=0.06)
             if bc == "pipe_i":
                 s = Simulation(nx, ny, 1.6, bc="pipe", obstacle_mask=mask, semantics="d2q9i", **kw)
@@ -40,7 +43,7 @@ def bitwise():
                 s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
             s.set_variant(variant)
             if variant:
-                assert s.steps_per_launch() == 5, s.steps_per_launch()
+                assert s.steps_per_launch() == DEEP_SPL, s.steps_per_launch()
             s.set_f(f0)
             s.run(7)
             s.run(13)
@@ -60,7 +63,7 @@ def bitwise():
 def timing(sizes):
     for n in sizes:
         for bc in ("periodic", "pipe"):
-            for name, variant in (("k_step4", 353), ("k_step5", 353 | 4096), ("k_step4", 353), ("k_step5", 353 | 4096)):
+            for name, variant in (("k_step5", 353 | 4096), ("k_step6", 353 | 4096 | 16384), ("k_step5", 353 | 4096), ("k_step6", 353 | 4096 | 16384)):
                 s = Simulation(n, n, 1.7, bc=bc, inlet_rho=1.003)
                 s.set_variant(variant)
                 spl = s.steps_per_launch()
