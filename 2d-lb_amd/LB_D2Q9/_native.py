@@ -29,7 +29,7 @@ EXPORTS = (
     "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_run",
     "lb_step_boundary", "lb_step_interior", "lb_step_finish", "lb_halo_export", "lb_halo_import",
     "lb_halo_floats", "lb_set_mask_halo", "lb_run_group", "lb_run_batch",
-    "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_autotune",
+    "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_plan_launches", "lb_autotune",
     "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state", "lb_check", "lb_set_debug_sync",
     "lb_peer_export", "lb_peer_connect", "lb_set_params_f64",
 )
@@ -66,6 +66,7 @@ def lib():
                  "lb_collide_particles", "lb_zero_velocity_in_obstacle", "lb_init_pop", "lb_step_finish",
                  "lb_timer_start", "lb_steps_per_launch", "lb_autotune"):
         getattr(L, name).argtypes = [h]
+    L.lb_plan_launches.argtypes = [h, I, ct.POINTER(ct.c_int), I]
     L.lb_set_stream.argtypes = [h, vp]
     L.lb_set_macro.argtypes = [h, vp, vp, vp]
     L.lb_get_macro.argtypes = [h, vp, vp, vp]

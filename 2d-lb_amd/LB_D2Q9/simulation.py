@@ -461,6 +461,15 @@ class Simulation(object):
         check(self._lib.lb_hot_kernel(self._h, buf, len(buf)))
         return buf.value.decode()
 
+    def plan_launches(self, num_iterations):
+        """The time steps of each launch run(num_iterations) would make, in order (whole-grid OpenCL-path GPU handles; None
+        elsewhere): every launch of a marching kernel moves the same bytes whatever number of steps it fuses."""
+        buf = (ct.c_int * 256)()
+        n = self._lib.lb_plan_launches(self._h, int(num_iterations), buf, 256)
+        if n < 0:
+            return None
+        return [int(buf[i]) for i in range(min(n, 256))]
+
     def steps_per_launch(self):
         """Time steps one launch of run()'s hot kernel advances for this grid / variant / tuning: 4, 3, 2 or 1."""
         n = self._lib.lb_steps_per_launch(self._h)

@@ -504,7 +504,9 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         //  301-305 k MLUPS, 1.6: 306-310 k, 2.0: 322-339 k, 2.5: 329-348 k, 3.0: 321-328 k; 4096^2: 252 / 274 / 290 / 298 / 276 k;
         //  pipe and cavity stay at 1.2: profiles/r04_experiments.txt section 10)
         const double edge_cost = edge_env > 0.0 ? edge_env
-                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : (depth == 6 ? 2.0 : 1.2));
+                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6)
+                                    // (k_step6, 8192^2, edge cost 1.6 / 2.0 / 2.5 / 3.0: pipe 358 / 376 / 377 / 361 k MLUPS, cavity 391 / 376 / 376 / 360 k)
+                                    : (depth == 6 ? (s->p.bc_mode == LB_BC_CAVITY ? 1.6 : 2.2) : 1.2));
         if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
             const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
             const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
@@ -977,18 +979,33 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
     return LB_OK;
 }
 
-// How many time steps the next launch of a run with `left` steps to go advances.  `allowed`: bit d set =
-// the d-step kernel may be used (bit 1 always is).  The deepest kernel D carries the bulk, the remainder
-// left % D goes first, to the deepest kernel that fits it (left = 4a + rem, rem -> 3, 2 or 1 ...).
+// How many time steps the next launch of a run with `left` steps to go advances.  `allowed`: bit d set = the d-step kernel may be
+// used (bit 1 always is).  A launch of a marching kernel costs about the same whatever number of steps it fuses (it moves the
+// same bytes): relative costs below, 8192^2 (k_step 0.79 ms, k_step2 0.85, k_step3 0.89, k_step4 0.86, k_step5 0.96, k_step6 1.00).
+// The cheapest way to split `left` into allowed depths, by dynamic programming over the last 64 steps of a run (before that: the
+// deepest kernel); shallow launches first.  20 steps with depths up to 6: 4 + 4 + 6 + 6 (3.72 ms), not 2 + 6 + 6 + 6 (3.85);
+// up to 5: 4 x 5; 60 steps: 10 x 6.
 int next_advance(int allowed, int left)
 {
+    static const float cost[7] = {0.f, 0.79f, 0.85f, 0.89f, 0.86f, 0.96f, 1.00f};
     int D = 1;
     for (int d = 2; d <= 6; ++d)
         if (allowed & (1 << d)) D = d;
-    const int rem = left % D;
-    for (int d = std::min(rem == 0 ? D : rem, left); d > 1; --d)
-        if (allowed & (1 << d)) return d;
-    return 1;
+    if (left > 64) return D;
+    float best[65];
+    int first[65];                       // the shallowest launch of a cheapest split of m steps
+    best[0] = 0.f; first[0] = 0;
+    for (int m = 1; m <= left; ++m) {
+        best[m] = 1e30f; first[m] = 1;
+        for (int d = 1; d <= D && d <= m; ++d) {
+            if (d > 1 && !(allowed & (1 << d))) continue;
+            const float c = cost[d] + best[m - d];
+            // (ties: the split whose shallowest launch is deepest -- fewer kinds of kernels in a run)
+            const int f = (m - d) ? std::min(d, first[m - d]) : d;
+            if (c < best[m] - 1e-6f || (c < best[m] + 1e-6f && f > first[m])) { best[m] = c; first[m] = f; }
+        }
+    }
+    return first[left];
 }
 int depth_mask(bool two, bool three, bool four = false, bool five = false, bool six = false)
 {
@@ -2683,6 +2700,21 @@ int lb_check(lb_sim *s, int across_ranks, int64_t *n_nonfinite, float *max_mach,
 }
 
 // ---- measurement -------------------------------------------------------------------------
+int lb_plan_launches(lb_sim *s, int n_steps, int *depths, int max_launches)
+{
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (n_steps < 0) return fail(LB_ERR_ARG, "negative step count");
+    if (s->cpu || s->p.semantics == LB_SEM_CYTHON || s->multi_slab()) return LB_ERR_STATE;     // (whole-grid OpenCL-path GPU handles)
+    const int allowed = whole_grid_depths(s);
+    int n = 0;
+    for (int left = n_steps; left > 0; ++n) {
+        const int adv = next_advance(allowed, left);
+        if (depths && n < max_launches) depths[n] = adv;
+        left -= adv;
+    }
+    return n;
+}
+
 int lb_steps_per_launch(lb_sim *s)
 {
     if (s && s->cpu) return 1;

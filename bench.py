@@ -226,11 +226,12 @@ def measure_config(config, local_rank, steps, warmup, min_blocks, min_timed_s, s
         if health["n_nonfinite"] or abs(mean_rho - 1.0) > 1e-3 or not health["max_mach"] < 0.3:
             raise SystemExit("bench: non-physical state after config %d (%r)" % (config, health))
         spl = sim.steps_per_launch()
-        launch_s = ev_ms / 1e3 / steps * spl
+        plan = sim.plan_launches(steps) if hasattr(sim, "plan_launches") else None
+        launch_s = ev_ms / 1e3 / (len(plan) if plan else steps / float(spl))
         achieved = bytes_per_cell * n * n / launch_s / 1e9
         return {"config": config, "workload": what, "value": round(n * float(n) * steps / wall / 1e6, 1), "unit": "MLUPS",
                 "ms_per_step": round(wall * 1e3 / steps, 6), "steps": steps, "warmup": warmup, "blocks": len(walls),
-                "timed_s": round(total, 3), "launch_ms": round(launch_s * 1e3, 6), "steps_per_launch": spl,
+                "timed_s": round(total, 3), "launch_ms": round(launch_s * 1e3, 6), "steps_per_launch": spl, "block_plan": plan,
                 "roofline_frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_GBps": round(achieved, 1),
                 "bytes_per_cell_per_launch": bytes_per_cell, "kernel": sim.hot_kernel(), "health": health}
     finally:
@@ -473,14 +474,18 @@ def main():
         python_driven = dist is not None and args.transport == "torch"      # that path is single-step
         spl = 1 if python_driven else eng.steps_per_launch()
         kname = "k_step (python-driven exchange)" if python_driven else eng.hot_kernel()
-        # K timed steps = (K // spl) launches of the spl-step kernel (+ at most one shorter launch for the
-        # remainder, priced at the same per-step rate)
-        launch_s = ev_ms / 1e3 / args.steps * spl
+        # A block of K timed steps is a handful of launches; every launch of a marching kernel moves the same algorithmic bytes
+        # whatever number of steps it fuses, so a launch is priced at block time / launches of the block.  The engine tells how
+        # it splits K (lb_plan_launches; K = 20 with depths up to six: 4 + 4 + 6 + 6); where it cannot (slabs): K / spl launches.
+        plan = None if python_driven or not hasattr(eng, "plan_launches") else eng.plan_launches(args.steps)
+        n_launches = float(len(plan)) if plan else args.steps / float(spl)
+        launch_s = ev_ms / 1e3 / n_launches
         launch_source = ("K-step block average: HIP events on the engine's stream around each timed block of %d steps / its "
-                         "%g launches (median block)" % (args.steps, args.steps / float(spl)))
+                         "%g launches%s (median block)" % (args.steps, n_launches,
+                                                          " of %s steps" % "+".join(str(d) for d in plan) if plan else ""))
         bytes_per_launch = bytes_per_cell * n * h
         achieved = bytes_per_launch / launch_s / 1e9
-        effective = B_ALG * n * h * spl / launch_s / 1e9
+        effective = B_ALG * n * h * args.steps / (ev_ms / 1e3) / 1e9
         traffic, traffic_source = load_pmc_traffic(n if args.config == 4 else "c%d/%d" % (args.config, n), spl) \
             if dist is None else (None, "no traffic figure: counters are collected on one GPU")
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -494,6 +499,7 @@ def main():
                 "traffic_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                 "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
                 "launch_ms": round(launch_s * 1e3, 4), "launch_ms_source": launch_source, "steps_per_launch": spl,
+                "block_plan": plan,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "effective_GBps": round(effective, 1), "effective_x_roofline": round(effective / HBM_PEAK_GBS, 4),
                 "macro_fields": "rebuilt on demand from the populations (lb_get_macro / lb_check), not stored by run()"

@@ -286,6 +286,11 @@ int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_a
  * 4, 3 or 2 when a four- / three- / two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch
  * with it). */
 int lb_steps_per_launch(lb_sim *s);
+/* How lb_run(n_steps) on a whole-grid OpenCL-path GPU handle splits the run into launches with the current variant / tuning:
+ * returns the number of launches and writes the time steps of each (in launch order) into depths[0 .. max_launches-1] (NULL:
+ * count only).  Every launch of a marching kernel moves the same bytes, so bench.py prices a block of K steps by its launches.
+ * LB_ERR_STATE (no message) on slab, Cython-path and CPU handles. */
+int lb_plan_launches(lb_sim *s, int n_steps, int *depths, int max_launches);
 /* Name of that kernel, e.g. "k_step4 (...)<PERIODIC>", written into buf (NUL-terminated, truncated to buflen). */
 int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 /* Pick the fastest configuration of the fused kernels for THIS grid by timing each candidate on a few

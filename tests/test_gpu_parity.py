@@ -224,6 +224,26 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
     assert_fields_close(sims[1], o.get_fields(), dict(f=2e-6, rho=2e-6, u=2e-6, v=2e-6))
 
 
+def test_run_is_split_into_the_cheapest_launches(lbhip):
+    """lb_plan_launches: how lb_run(n) splits n steps into launches -- a launch of a marching kernel costs about the same whatever
+    it fuses, so the split minimises launches (shallow ones first): 20 steps with depths up to six = 4 + 4 + 6 + 6, with depths up
+    to five = 4 x 5; the plan sums to n, and run(n) of every plan equals the single-step kernel (the other tests)."""
+    from LB_D2Q9.simulation import Simulation
+    s = Simulation(2560, 2560, 1.5, bc="periodic")
+    assert s.steps_per_launch() == 6
+    assert s.plan_launches(20) == [4, 4, 6, 6] and s.plan_launches(60) == [6] * 10 and s.plan_launches(5) == [5]
+    assert s.plan_launches(7) == [3, 4] and s.plan_launches(0) == [] and s.plan_launches(23) == [5, 6, 6, 6]
+    for n in (1, 2, 3, 11, 13, 29, 64, 65, 100, 131):
+        p = s.plan_launches(n)
+        assert sum(p) == n and all(1 <= d <= 6 for d in p) and (n > 64 or p == sorted(p)), (n, p)
+    s.set_variant(353 | 4096)
+    assert s.plan_launches(20) == [5] * 4 and s.plan_launches(23) == [4, 4, 5, 5, 5]
+    s.set_variant(9)
+    assert s.plan_launches(4) == [1, 1, 1, 1]
+    slab = Simulation(1024, 256, 1.5, bc="periodic", y0=0, local_ny=128)
+    assert slab.plan_launches(8) is None
+
+
 @pytest.mark.parametrize("nx", [512, 716, 720, 724, 740, 744, 748, 960, 964, 992, 996, 1000, 1196, 1236, 1241, 1440, 1488])
 @pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
 def test_five_and_six_step_kernel_strip_boundaries(lbhip, bc, nx):
