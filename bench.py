@@ -541,7 +541,7 @@ def main():
             line["other_configs"] = []
             for c in (2, 3, 5):
                 try:
-                    line["other_configs"].append(measure_config(c, local_rank, 20, 8, args.min_blocks, args.min_timed_s))
+                    line["other_configs"].append(measure_config(c, local_rank, 60, 12, args.min_blocks, args.min_timed_s))    # (60 = whole launches of every depth)
                 except (Exception, SystemExit) as exc:             # noqa: BLE001 - a side line must not take the headline down
                     line["other_configs"].append({"config": c, "error": str(exc)})
         if world == 1 and not args.no_cpu_baseline and args.config == 4:
