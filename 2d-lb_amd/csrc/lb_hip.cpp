@@ -477,7 +477,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     } else {
         // as many wave-items as the chip holds at once (waves per CU from the kernel's register
         // budget; tunable), each marching an equal share of the rows
-        int waves_per_cu = s->tuned_wpc > 0 ? s->tuned_wpc : 8;
+        // (lb_autotune's waves per CU belong to the depth it found fastest: the shallower launches of a run's remainder keep 8)
+        int waves_per_cu = (s->tuned_wpc > 0 && depth == s->tuned_steps) ? s->tuned_wpc : 8;
         static const int wpc_env = getenv("LB_STEP2_WAVES_PER_CU") ? atoi(getenv("LB_STEP2_WAVES_PER_CU")) : 0;   // tuning knob
         if (wpc_env > 0) waves_per_cu = wpc_env;
         if (depth == 6 && waves_per_cu > 6) waves_per_cu = 6;        // (k_step6: 48 KB of LDS per workgroup, three per CU)
