@@ -5,7 +5,8 @@
 // kernel moves its bytes at the ceiling of the marching waves' access pattern (~6.0 TB/s counted, 1.08 x the compulsory bytes),
 // and its vector ALU idles a third of the time.  A launch costs about the same whatever it computes per row, so the way up is a
 // FIFTH time step per pass -- provided the kernel keeps eight waves per CU (timing probe on the diagnostic build,
-// tools/r04_fifth_stage.sh: with a third LDS window, i.e. six waves per CU, the gain is gone).  Hence: the windows between steps
+// tools/r04_fifth_stage.sh: with a third LDS window, i.e. six waves per CU, the gain is gone -- for k_step4's halo-lane form, which
+// the probe ran; THIS kernel turned out to run as fast at six waves per CU, which is what kernels_step6.h builds on).  Hence: the windows between steps
 // 1/2 AND 2/3 in registers (2 x 36), those between 3/4 and 4/5 in LDS (the 36 KB per workgroup k_step4 uses).
 //
 // Overlapping strips instead of halo lanes.  k_step4 recomputes the cells beyond its 256-cell strip as scalar cells in "halo

@@ -1473,7 +1473,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->bytes = 2 * lat_bytes + 3 * fld_bytes + (size_t)s->pitch * s->H;
     // A periodic box whose width is not a multiple of 4 cannot use the marching kernels (their lanes hold four consecutive
     // cells, and the wrap at x = nx must fall on a lane boundary): above the Infinity Cache that costs a factor of two or
-    // more (LDS tiles / single steps instead of k_step4).  Say so once instead of being silently slow; LB_QUIET=1 mutes it.
+    // more (LDS tiles / single steps instead of k_step5 / k_step6).  Say so once instead of being silently slow; LB_QUIET=1 mutes it.
     if (p->bc_mode == LB_BC_PERIODIC && (p->nx % 4) != 0 && (double)p->nx * s->H >= 1950.0 * 1950.0) {
         static bool warned = false;
         if (!warned && !(getenv("LB_QUIET") && atoi(getenv("LB_QUIET")) != 0)) {
