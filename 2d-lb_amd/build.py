@@ -2,18 +2,29 @@
 """Build liblbhip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
     python 2d-lb_amd/build.py            # -> 2d-lb_amd/LB_D2Q9/liblbhip.so
+    python 2d-lb_amd/build.py --diag     # -> 2d-lb_amd/LB_D2Q9/liblbhip_diag.so (ablation switches, tools/ablate.py)
 
-hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.  One translation unit per kernel
+family (csrc/launchers.h), compiled in parallel; objects under 2d-lb_amd/build/ (git- and gpurun-ignored) are reused while
+neither their source nor any header is newer.
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "lb_hip.cpp")            # one translation unit; includes the csrc/*.h kernels
+CSRC = os.path.join(HERE, "csrc")
 HDR = os.path.join(os.path.dirname(HERE), "include", "lb_hip.h")
 OUT = os.path.join(HERE, "LB_D2Q9", "liblbhip.so")
+OBJ = os.path.join(HERE, "build")
+# (largest first: the pool starts them in this order)
+UNITS = ["march6.cpp", "march5.cpp", "march4.cpp", "lb_hip.cpp", "march23.cpp", "tile.cpp", "step1.cpp"]
+# -ffp-contract=on: a*b+c fuses to an FMA only inside one source expression, so every kernel instantiation (single step,
+# multi-step, slab edge rows) -- in whichever translation unit -- rounds identically: results are bitwise independent of the
+# kernel variant and of the slab partition.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():
@@ -23,41 +34,57 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
 
 
+def headers():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [HDR, __file__]
+
+
 def sources():
-    csrc = os.path.join(HERE, "csrc")
-    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".cpp", ".h"))] + [HDR, __file__]
+    return [os.path.join(CSRC, u) for u in UNITS] + headers()
 
 
-def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in sources())
+def up_to_date(out=OUT):
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(p) for p in sources())
 
 
-def build_diag():
-    """Diagnostic build with the ablation switches compiled in (tools/ablate.py): liblbhip_diag.so.
-    Never used by the product; select it with LB_LIB=<path>."""
-    out = OUT.replace("liblbhip.so", "liblbhip_diag.so")
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-DLB_DIAG",
-                           "-fPIC", "-shared", SRC, "-o", out, "-ldl"])
+def _compile(unit, tag, extra, verbose):
+    src = os.path.join(CSRC, unit)
+    obj = os.path.join(OBJ, "%s%s.o" % (os.path.splitext(unit)[0], tag))
+    deps = [src] + headers()
+    if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(p) for p in deps):
+        return obj
+    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj
+
+
+def _build(out, tag, extra, force, verbose, jobs):
+    if not force and up_to_date(out):
+        return out
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            if f.endswith(tag + ".o"):
+                os.remove(os.path.join(OBJ, f))
+    jobs = jobs or int(os.environ.get("LB_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(lambda u: _compile(u, tag, extra, verbose), UNITS))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out, "-ldl"])
     return out
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return OUT
-    # -ffp-contract=on: a*b+c fuses to an FMA only inside one source expression, so every kernel
-    # instantiation (single step, two-step, slab edge rows) rounds identically: results are bitwise
-    # independent of the kernel variant and of the slab partition.
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", SRC, "-o", OUT, "-ldl"]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return OUT
+def build_diag(force=False, verbose=False, jobs=0):
+    """Diagnostic build with the ablation switches compiled in (tools/ablate.py): liblbhip_diag.so.
+    Never used by the product; select it with LB_LIB=<path>."""
+    return _build(OUT.replace("liblbhip.so", "liblbhip_diag.so"), "_diag", ["-DLB_DIAG"], force, verbose, jobs)
+
+
+def build(force=False, verbose=False, jobs=0):
+    return _build(OUT, "", [], force, verbose, jobs)
 
 
 if __name__ == "__main__":
-    if "--diag" in sys.argv:
-        print(build_diag())
-    else:
-        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    kw = dict(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    print(build_diag(**kw) if "--diag" in sys.argv else build(**kw))

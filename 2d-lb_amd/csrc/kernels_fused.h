@@ -5,8 +5,8 @@
 #include <type_traits>
 #include "d2q9_cell.h"
 
-namespace {
-
+// (external linkage: the argument block crosses translation units -- the host side in lb_hip.cpp fills it, the launchers of
+//  launchers.h, one translation unit per kernel family, hand it to their kernels)
 struct StepArgs {
     const float *src;      // plane 0, row 0, x 0 of the lattice being read
     float *dst;            // same element of the lattice being written
@@ -33,6 +33,15 @@ struct StepArgs {
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)
 };
+
+// several lattices of one geometry advanced by one launch (k_step_batch)
+constexpr int BATCH_MAX = 8;
+struct BatchArgs {
+    StepArgs a[BATCH_MAX];
+};
+
+namespace {
+
 
 // Template value of the PIPE family run with the kernels of the reference's D2Q9i.cl fork (lb_params.semantics =
 // LB_SEM_OPENCL_D2Q9I); not a public lb_bc_mode.
@@ -390,10 +399,6 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a)
 // reference's research forks (porous_media/single_component.cl:338-375 `move_periodic` streams population `cur_field`
 // of a [jumper][population][y][x] array; here every population is a lattice of its own with its own relaxation rate,
 // and stream + collide are fused as everywhere).  Same cell code as k_step: bitwise equal to separate launches.
-constexpr int BATCH_MAX = 8;
-struct BatchArgs {
-    StepArgs a[BATCH_MAX];
-};
 template <int BC, bool MASK, bool MACRO>
 __global__ __launch_bounds__(256) void k_step_batch(const BatchArgs b)
 {

@@ -20,8 +20,10 @@
 //                                                         plane = (H+2*GHOST)*pitch);
 // rho, u, v are [H][pitch]; the obstacle mask is uint8 [H + 2*LB_MASK_HALO_ROWS][pitch], row y at mask + y*pitch
 // (7 rows of each neighbour).
-// Source layout (one translation unit): d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2,
-// k_step3), kernels_step4.h (k_step4), kernels_tile.h (k_tile4), kernels_phases.h (un-fused phases, halo pack/unpack), this file (RCCL loader, host side, C ABI).
+// Source layout: d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2, k_step3), kernels_step4.h / 5 / 6 (k_step4 ...
+// k_step6), kernels_tile.h (k_tile4, k_vel_band), kernels_phases.h (un-fused phases, halo pack / unpack, peer transport);
+// every fused kernel family is instantiated in a translation unit of its own (launchers.h), this file holds the RCCL loader,
+// the host side, the C ABI and the small kernels of kernels_phases.h.
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
 // 16-byte loads that are misaligned by one element (gfx950 global loads only need dword alignment).
 #include <hip/hip_runtime.h>
@@ -77,7 +79,10 @@ int fail(int code, const char *fmt, ...)
 #include "kernels_step6.h"
 #include "kernels_tile.h"
 #include "kernels_phases.h"
-#include "kernels_step5c.h"
+#ifdef LB_DIAG
+#include "kernels_step5c.h"     // k1_step5, the Cython path's marching form: diagnostic build only since round 5
+#endif
+#include "launchers.h"          // the fused kernels are instantiated in their own translation units
 
 namespace {
 
@@ -247,36 +252,6 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     return a;
 }
 
-template <int BC, bool MASK, bool MACRO>
-void launch_step_nt(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, int variant)
-{
-#define LB_LAUNCH(NTL, NTS, XCD) \
-    hipLaunchKernelGGL((k_step<BC, MASK, MACRO, NTL, NTS, XCD>), grid, block, 0, s->stream, a)
-    switch (variant & 19) {           // bit 0: NT stores, bit 1: NT loads, bit 4: XCD-aware tile order
-    case 0: LB_LAUNCH(false, false, false); break;
-    case 1: LB_LAUNCH(false, true, false); break;
-    case 2: LB_LAUNCH(true, false, false); break;
-    case 3: LB_LAUNCH(true, true, false); break;
-    case 16: LB_LAUNCH(false, false, true); break;
-    case 17: LB_LAUNCH(false, true, true); break;
-    case 18: LB_LAUNCH(true, false, true); break;
-    default: LB_LAUNCH(true, true, true); break;
-    }
-#undef LB_LAUNCH
-}
-
-template <int BC>
-void launch_step_bc(const lb_sim *s, const StepArgs &a, dim3 grid, dim3 block, bool macro, int variant)
-{
-    if (s->has_mask) {
-        if (macro) launch_step_nt<BC, true, true>(s, a, grid, block, variant);
-        else launch_step_nt<BC, true, false>(s, a, grid, block, variant);
-    } else {
-        if (macro) launch_step_nt<BC, false, true>(s, a, grid, block, variant);
-        else launch_step_nt<BC, false, false>(s, a, grid, block, variant);
-    }
-}
-
 // variant < 0 = automatic, from one-GPU sweeps (tools/sweep.py, tools/rect_probe.py;
 // profiles/r01_sweep_variants.txt):
 //   >= 1024^2 / 1280^2 cells on this GPU : temporal blocking -- three / four time steps per pass (marching
@@ -326,91 +301,29 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
     dim3 block(64 * waves_x, rows_per_block);
     const int lanes_x = (int)(s->pitch / 4);
     dim3 grid((lanes_x + block.x - 1) / block.x, (row_count + rows_per_block - 1) / rows_per_block);
-    switch (kernel_bc(s)) {
-    case LB_BC_PIPE_I: launch_step_bc<LB_BC_PIPE_I>(s, a, grid, block, macro, variant); break;
-    case LB_BC_PIPE: launch_step_bc<LB_BC_PIPE>(s, a, grid, block, macro, variant); break;
-    case LB_BC_PERIODIC: launch_step_bc<LB_BC_PERIODIC>(s, a, grid, block, macro, variant); break;
-    case LB_BC_VELOCITY_INLET: launch_step_bc<LB_BC_VELOCITY_INLET>(s, a, grid, block, macro, variant); break;
-    default: launch_step_bc<LB_BC_CAVITY>(s, a, grid, block, macro, variant); break;
-    }
+    lbk_launch_step(kernel_bc(s), s->has_mask, macro, variant, grid, block, s->stream, a);
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
 
-// Two fused time steps in one pass (k_step2).
-template <int BC>
-void launch_step2_bc(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows,
-                     int nsegs, int row_end, bool macro, bool nts, int depth)
+// A marching launch of `depth` time steps per pass (k_step2 ... k_step6), by the translation unit that instantiates that depth.
+// k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
+// instantiation without an obstacle mask but the D2Q9i fork's); variant bit 10 switches it off (A/B runs).
+void launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs, int row_end,
+                  bool macro, int depth)
 {
-    const int waves = (depth >= 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4 / k_step5: the two directions of ONE item
+    const int waves = (depth >= 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4 ... k_step6: the two directions of ONE item
                                                            // (a segment pair); the others: four independent items
-    // k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
-    // instantiation without an obstacle mask but the D2Q9i fork's, and -- since the stage rows stopped being joined with zero
-    // rows, round 4 -- the pipe / cavity families with a mask, whose waves waited 28 % of their cycles without it:
-    // profiles/r03_sq_counters.txt).  Variant bit 10 switches it off (A/B runs).
-    const bool pf_on = !(effective_variant(s) & 1024);
-    const dim3 block(64, waves), grid(depth >= 4 ? items : (items + waves - 1) / waves);
-#define LB_LAUNCH2(MASK, MACRO, NTS)                                                                             \
-    do {                                                                                                         \
-        if (depth == 6)                                                                                          \
-            hipLaunchKernelGGL((k_step6<BC, MASK, MACRO>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end); \
-        else if (depth == 5)                                                                                        \
-            hipLaunchKernelGGL((k_step5<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs, row_end); \
-        else if (depth == 4) {                                                                                      \
-            if (step4_prefetch(BC, MASK, MACRO) && pf_on)                                                        \
-                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, false, step4_prefetch(BC, MASK, MACRO)>), grid, block, 0, st, a, \
-                                   strips, seg_rows, nsegs, row_end);                                            \
-            else                                                                                                 \
-                hipLaunchKernelGGL((k_step4<BC, MASK, MACRO, false, false>), grid, block, 0, st, a, strips, seg_rows,  \
-                                   nsegs, row_end);                                                              \
-        } else if (depth == 3)                                                                                   \
-            hipLaunchKernelGGL((k_step3<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs,\
-                               row_end);                                                                         \
-        else                                                                                                     \
-            hipLaunchKernelGGL((k_step2<BC, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, nsegs,\
-                               row_end);                                                                         \
-    } while (0)
-    if (s->has_mask) {
-        if (macro) { if (nts) LB_LAUNCH2(true, true, true); else LB_LAUNCH2(true, true, false); }
-        else       { if (nts) LB_LAUNCH2(true, false, true); else LB_LAUNCH2(true, false, false); }
-    } else {
-        if (macro) { if (nts) LB_LAUNCH2(false, true, true); else LB_LAUNCH2(false, true, false); }
-        else       { if (nts) LB_LAUNCH2(false, false, true); else LB_LAUNCH2(false, false, false); }
-    }
-#undef LB_LAUNCH2
-}
-
-// The velocity-inlet family.  Its wall rows exchange links with each other, which one marching pass over the whole grid can
-// follow for two time steps (step 1 reads memory through the remapped source rows) but not for three: k_step2 takes whole
-// grids, k_step3 / k_step4 only the rows that no wall-row link reaches within the pass (vel_band_pass does the rest).
-void launch_step2_vel(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs,
-                      int row_end, bool macro, bool nts, int depth)
-{
-    const int waves = (depth >= 4) ? STEP4_WAVES : 4;
-    const dim3 block(64, waves), grid(depth >= 4 ? items : (items + waves - 1) / waves);
-#define LB_LAUNCHV(MASK, MACRO, NTS)                                                                                      \
-    do {                                                                                                                  \
-        if (depth == 5)                                                                                                   \
-            hipLaunchKernelGGL((k_step5<LB_BC_VELOCITY_INLET, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows, \
-                               nsegs, row_end);                                                                           \
-        else if (depth == 4)                                                                                              \
-            hipLaunchKernelGGL((k_step4<LB_BC_VELOCITY_INLET, MASK, MACRO, false, false>), grid, block, 0, st, a, strips,   \
-                               seg_rows, nsegs, row_end);                                                                 \
-        else if (depth == 3)                                                                                              \
-            hipLaunchKernelGGL((k_step3<LB_BC_VELOCITY_INLET, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows,\
-                               nsegs, row_end);                                                                           \
-        else                                                                                                              \
-            hipLaunchKernelGGL((k_step2<LB_BC_VELOCITY_INLET, MASK, MACRO, false>), grid, block, 0, st, a, strips, seg_rows,\
-                               nsegs, row_end);                                                                           \
-    } while (0)
-    if (s->has_mask) {
-        if (macro) { if (nts) LB_LAUNCHV(true, true, true); else LB_LAUNCHV(true, true, false); }
-        else       { if (nts) LB_LAUNCHV(true, false, true); else LB_LAUNCHV(true, false, false); }
-    } else {
-        if (macro) { if (nts) LB_LAUNCHV(false, true, true); else LB_LAUNCHV(false, true, false); }
-        else       { if (nts) LB_LAUNCHV(false, false, true); else LB_LAUNCHV(false, false, false); }
-    }
-#undef LB_LAUNCHV
+    MarchLaunch g;
+    g.block = dim3(64, waves);
+    g.grid = dim3(depth >= 4 ? items : (items + waves - 1) / waves);
+    g.stream = st;
+    g.strips = strips; g.seg_rows = seg_rows; g.nsegs = nsegs; g.row_end = row_end;
+    const int bc = kernel_bc(s);
+    if (depth == 6) lbk_launch_march6(bc, s->has_mask, macro, g, a);
+    else if (depth == 5) lbk_launch_march5(bc, s->has_mask, macro, g, a);
+    else if (depth == 4) lbk_launch_march4(bc, s->has_mask, macro, !(effective_variant(s) & 1024), g, a);
+    else lbk_launch_march23(depth, bc, s->has_mask, macro, g, a);
 }
 
 // The marching kernels address the nine planes of a row through ONE scalar base and a 32-bit byte offset per lane that carries the
@@ -528,9 +441,10 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
     a.nts = nts ? 1 : 0;                       // (the marching kernels take it at run time)
+#ifdef LB_DIAG
     if (s->p.semantics == LB_SEM_CYTHON) {
-        // the Cython path's five-step march (k1_step5): `macro` = this is the run's last launch -- it stores rho, u, v and is not
-        // followed by the next step's boundary rule
+        // the Cython path's five-step march (k1_step5; diagnostic build only): `macro` = this is the run's last launch -- it
+        // stores rho, u, v and is not followed by the next step's boundary rule
         a.rule_last = macro ? 0 : 1;
         const dim3 block(64, STEP4_WAVES), grid(items);
         if (s->has_mask) {
@@ -543,31 +457,14 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         HIP_TRY(hipGetLastError());
         return LB_OK;
     }
-    switch (kernel_bc(s)) {
-    case LB_BC_PIPE_I: launch_step2_bc<LB_BC_PIPE_I>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
-    case LB_BC_VELOCITY_INLET: launch_step2_vel(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
-    case LB_BC_PIPE: launch_step2_bc<LB_BC_PIPE>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
-    case LB_BC_PERIODIC: launch_step2_bc<LB_BC_PERIODIC>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
-    default: launch_step2_bc<LB_BC_CAVITY>(s, st, a, items, strips, seg_rows, segs, row_end, macro, nts, depth); break;
-    }
+#endif
+    launch_march(s, st, a, items, strips, seg_rows, segs, row_end, macro, depth);
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
 
-template <int BC, int TW, int TH, int CPT>
-void launch_tile_shape(const lb_sim *s, const StepArgs &a, bool macro)
-{
-    const int tiles_x = (s->p.nx + TW - 1) / TW, tiles_y = (s->H + TH - 1) / TH, n_tiles = tiles_x * tiles_y;
-    const dim3 grid((n_tiles + 7) / 8 * 8), block(TileShape<TW, TH, CPT>::THREADS);     // (eight equal shares: xcd_band_tile)
-#define LB_LAUNCHT(MASK, MACRO) \
-    hipLaunchKernelGGL((k_tile4<BC, MASK, MACRO, TW, TH, CPT>), grid, block, 0, s->stream, a, tiles_x, n_tiles)
-    if (s->has_mask) { if (macro) LB_LAUNCHT(true, true); else LB_LAUNCHT(true, false); }
-    else             { if (macro) LB_LAUNCHT(false, true); else LB_LAUNCHT(false, false); }
-#undef LB_LAUNCHT
-}
-
-template <int BC>
-void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
+// which of k_tile4's three shapes (launchers.h: lbk_launch_tile4)
+int tile_shape_of(const lb_sim *s)
 {
     // 32 x 16 tiles (512 threads, two cells per thread, 49-60 VGPR: four workgroups per CU -- with 32 x 32 tiles and
     // four cells per thread the same kernel ran at 117 instead of 144 k MLUPS at 1024^2: occupancy is what hides
@@ -580,9 +477,8 @@ void launch_tile_bc(const lb_sim *s, const StepArgs &a, bool macro)
     //  periodic 512^2 122-124 / 123 k, 640^2 125-128 / 133-135 k, 768^2 145 / 156 k, 896^2 152 / 170 k; cavity 512^2 110 / 107 k,
     //  640^2 112 / 121 k, 896^2 139 / 156 k: profiles/r03_experiments.txt section 16)
     static const long long cpt2_env = getenv("LB_TILE_CPT2_SIDE") ? atoll(getenv("LB_TILE_CPT2_SIDE")) : 576;     // tuning knob
-    if (cells >= cpt2_env * cpt2_env) launch_tile_shape<BC, 32, 16, 2>(s, a, macro);
-    else if (cells >= 330LL * 330) launch_tile_shape<BC, 32, 16, 1>(s, a, macro);
-    else launch_tile_shape<BC, 16, 16, 1>(s, a, macro);
+    if (cells >= cpt2_env * cpt2_env) return 0;
+    return cells >= 330LL * 330 ? 1 : 2;
 }
 
 // Four time steps of a whole-grid handle through LDS tiles.
@@ -590,12 +486,7 @@ int launch_tile4(lb_sim *s, bool macro)
 {
     macro = macro && !lazy_macro(s);
     const StepArgs a = step_args(s, 0, 1, s->H);
-    switch (kernel_bc(s)) {
-    case LB_BC_PIPE_I: launch_tile_bc<LB_BC_PIPE_I>(s, a, macro); break;
-    case LB_BC_PIPE: launch_tile_bc<LB_BC_PIPE>(s, a, macro); break;
-    case LB_BC_PERIODIC: launch_tile_bc<LB_BC_PERIODIC>(s, a, macro); break;
-    default: launch_tile_bc<LB_BC_CAVITY>(s, a, macro); break;
-    }
+    lbk_launch_tile4(kernel_bc(s), s->has_mask, macro, tile_shape_of(s), s->p.nx, s->H, s->stream, a);
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
@@ -1141,15 +1032,7 @@ int vel_band_pass(lb_sim *s, int d, bool macro)
     HIP_TRY(hipStreamWaitEvent(q, s->ev_interior, 0));
     const StepArgs a = step_args(s, 0, 1, H);
     const dim3 grid((unsigned)((s->p.nx + (64 - 2 * d) - 1) / (64 - 2 * d))), blk(256);
-#define LB_LAUNCHB(MASK, MACRO)                                                                          \
-    do {                                                                                                 \
-        if (d == 5) hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 5>), grid, blk, 0, q, a);                \
-        else if (d == 4) hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 4>), grid, blk, 0, q, a);           \
-        else hipLaunchKernelGGL((k_vel_band<MASK, MACRO, 3>), grid, blk, 0, q, a);                       \
-    } while (0)
-    if (s->has_mask) { if (macro) LB_LAUNCHB(true, true); else LB_LAUNCHB(true, false); }
-    else             { if (macro) LB_LAUNCHB(false, true); else LB_LAUNCHB(false, false); }
-#undef LB_LAUNCHB
+    lbk_launch_vel_band(s->has_mask, macro, d, grid, blk, q, a);
     HIP_TRY(hipGetLastError());
     // the interior, from the same source lattice, on the compute stream
     if ((rc = launch_step2(s, s->stream, d, H - d, macro, 0, 0, 0, 0, d))) return rc;
@@ -1321,6 +1204,9 @@ bool cython_tiles(const lb_sim *s) { return s->p.nx >= 64 && s->H >= 64 && (s->v
 // MLUPS, 8192^2: 205 against 193 k; profiles/r04_experiments.txt section 11) -- not the default
 bool cython_march(const lb_sim *s)
 {
+#ifndef LB_DIAG
+    return false;       // (round 5: k1_step5 left the product -- slower than the tiles at the reference's sizes; the diagnostic build keeps it)
+#endif
     if (s->p.nx < 512 || s->H < 128 || !marching_planes_fit(s)) return false;
     return s->variant >= 0 && (s->variant & 4096) != 0;
 }
@@ -2457,13 +2343,7 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps)
         BatchArgs b;
         for (int i = 0; i < count; ++i) b.a[i] = step_args(sims[i], 0, 1, sims[i]->H);
         const bool macro = (it == n_steps - 1) && !lazy;
-        if (s0->has_mask) {
-            if (macro) hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, true, true>), grid, block, 0, s0->stream, b);
-            else hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, true, false>), grid, block, 0, s0->stream, b);
-        } else {
-            if (macro) hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, false, true>), grid, block, 0, s0->stream, b);
-            else hipLaunchKernelGGL((k_step_batch<LB_BC_PERIODIC, false, false>), grid, block, 0, s0->stream, b);
-        }
+        lbk_launch_step_batch(s0->has_mask, macro, grid, block, s0->stream, b);
         HIP_TRY(hipGetLastError());
         for (int i = 0; i < count; ++i) sims[i]->cur ^= 1;
     }
