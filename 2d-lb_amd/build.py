@@ -85,6 +85,15 @@ def build(force=False, verbose=False, jobs=0):
     return _build(OUT, "", [], force, verbose, jobs)
 
 
+def build_variant(tag, flags, force=False, verbose=False, jobs=0):
+    """An experimental build with extra compiler flags: liblbhip_<tag>.so (A/B timing through LB_LIB; never the product)."""
+    return _build(OUT.replace("liblbhip.so", "liblbhip_%s.so" % tag), "_" + tag, list(flags), force, verbose, jobs)
+
+
 if __name__ == "__main__":
     kw = dict(force="--force" in sys.argv, verbose="-v" in sys.argv)
-    print(build_diag(**kw) if "--diag" in sys.argv else build(**kw))
+    if "--variant" in sys.argv:          # --variant <tag> <flag> [<flag> ...]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [f for f in sys.argv[i + 2:] if f.startswith("-D")], **kw))
+    else:
+        print(build_diag(**kw) if "--diag" in sys.argv else build(**kw))

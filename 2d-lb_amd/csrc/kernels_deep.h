@@ -1,0 +1,214 @@
+// kernels_deep.h -- D time steps per pass, D = 6, 7, 8, ...: the marching kernel of kernels_step5.h / kernels_step6.h written once
+// for any depth (round 5).  Read those headers first: overlapping strips (a wave's 64 lanes x 4 cells are the strip and its skirt),
+// segment pairs (the two waves of a workgroup start back to back at the pair's middle line and hand each other the links that
+// cross it while their pipelines fill), peeled pipeline fill, stage windows.
+//
+// What round 5 measured (profiles/r05_experiments.txt):
+//   * k_step6 is bound by INSTRUCTION ISSUE, not by HBM: with every global access removed (diagnostic build) its launch still takes
+//     0.86 ms of 1.08; with the arithmetic removed 0.92.  At six waves per CU two SIMDs of every CU hold two waves and two hold one,
+//     all waves have the same rows to march, and the pairs set the pace.
+//   * A gfx950 SIMD issues one vector instruction per ~2.5 cycles (v_pk_*_f32: ~3.5) when TWO waves feed it, and a single wave no
+//     faster than one per ~5 cycles -- any instruction, packed or not, vector, scalar or LDS (tools/valu_issue_probe.hip).
+//   So the kernel is parametrised on where a wave's state lives:
+//     RW   stage windows kept in registers (the first RW of the D - 1), the others in wave-private LDS, nine 1-KiB slots each;
+//     PFD  rows gathered ahead (0: none -- two waves per SIMD cover each other's waits; 1: the next row's gather is in flight while
+//          this one is computed -- ONE wave per SIMD, 512 registers, 40 KB of LDS: __launch_bounds__(128, 1)).
+//   The launch moves the same 72 B per cell whatever D is.  Same cell functions as every kernel: bitwise equal to k_step.
+//
+// Stage S (2..D) of an iteration reads window S - 1: links 0,1,3 of the row it is about to advance (d), the three links pulled from
+// behind of the row before that (g), and takes the three links pulled from ahead out of the row stage S - 1 has just produced; that
+// row then enters the window.  The skirt is D - 1 cells deep: two lanes (8 cells) for D <= 9, strips 240 cells apart (STEP6_VALID).
+#pragma once
+
+#ifdef LB_DIAG
+#define LB_DEEP_NOCOLLIDE if (!(a.diag & 1))
+#else
+#define LB_DEEP_NOCOLLIDE
+#endif
+
+namespace {
+
+template <int RW>
+struct DeepState {
+    Window w[RW > 0 ? RW : 1];          // stage windows 1..RW (registers)
+    unsigned mhist;                     // obstacle-mask history (per byte: bit j = the row loaded j iterations ago, j = 1..D-1)
+};
+struct DeepCtx {
+    int lane, x4, ym, n_iter;
+    bool store_lane;
+    f4a (*mine)[64], (*other)[64];      // my LDS windows RW+1..D-1 (nine slots each, in that order), the other wave's
+};
+
+// Stages S..D of one iteration, S >= 2.  qin = the row stage S - 1 produced in this iteration (position i - (S - 2)).
+template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S>
+__device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it, DeepState<RW> &st,
+                                           f4a (&qin)[9], f4a &r4, f4a &u4, f4a &v4)
+{
+    if constexpr (S <= D) {
+        constexpr int K = S - 1;                                   // the window this stage reads
+        const int lane = cx.lane, x4 = cx.x4;
+        f4a (*W)[64] = cx.mine + (K - RW - 1) * 9;                 // (meaningful for K > RW only)
+        if constexpr (NST >= S) {
+            int r, t0_, t1_;
+            (void)step1_rows(a, DOWN ? cx.ym - 1 - (i - K) : cx.ym + (i - K), r, t0_, t1_);
+            f4a t[9];
+            // (every window takes its new row as soon as its old one has been gathered from: qin dies here)
+            if constexpr (K <= RW) {
+                skirt_gather<DOWN>(st.w[K - 1], qin, t);
+                window_push_dir<DOWN>(st.w[K - 1], qin);
+            } else {
+                Window w;
+                lds_window_load(W, lane, it, w);
+                skirt_gather<DOWN>(w, qin, t);
+                lds_window_push<DOWN>(W, lane, it, qin);
+            }
+            LB_DEEP_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
+            if constexpr (S == D) {
+#ifdef LB_DIAG
+                if (!(a.diag & (1 << 22)))
+#endif
+                if (cx.store_lane) {
+                    float *d = a.dst + (long long)r * a.pitch;     // row start, uniform
+                    store_row9<false>(a.nts != 0, d, a.plane, x4, t);
+                    if (MACRO) {
+                        const long long m = (long long)r * a.fpitch;
+                        store4<false>(lane_ptr(a.rho + m, x4), r4);
+                        store4<false>(lane_ptr(a.u + m, x4), u4);
+                        store4<false>(lane_ptr(a.v + m, x4), v4);
+                    }
+                }
+            } else {
+                if constexpr (NST == S) {
+                    // my position 0 after step S -> what the other wave's stage S + 1 pulls from behind ITS position 0: into its
+                    // window S -- the ring slot it reads as "the older row" in its next iteration (i = S: 3 + 3 (S & 1)) --, or,
+                    // a register window, through its still idle last LDS window (read at the top of its next iteration)
+                    if constexpr (S <= RW) lds_publish<DOWN>(cx.other + (D - 2 - RW) * 9, lane, S == 1 ? 6 : 3, t);
+                    else lds_publish<DOWN>(cx.other + (S - RW - 1) * 9, lane, 3 + 3 * (S & 1), t);
+                }
+                deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
+            }
+        } else if constexpr (NST == S - 1) {
+            // position 0 after step K enters window K (its d slots and the ring slot of this parity; the other wave fills the other one)
+            if constexpr (K <= RW) window_push_dir<DOWN>(st.w[K - 1], qin);
+            else lds_window_push<DOWN>(W, lane, it, qin);
+        }
+    }
+}
+
+// One iteration: position i takes step 1, position i - 1 step 2, ..., position i - (D - 1) step D (stored).  NST = number of stages
+// that have a row: 1..D-1 in iterations 0..D-2 (code of their own, i a constant: the pipeline fills, the two waves of the pair hand
+// over), D in the loop.  PFD = 1: `cur` holds position i on entry and position i + 1 is gathered into `nxt` first; the caller swaps
+// the two from one iteration to the next.  PAR >= 0: the parity of i as a constant (the LDS ring slots become immediate offsets).
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST, int PAR = -1>
+__device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, const int i_, DeepState<RW> &st, Row1 &cur, Row1 &nxt)
+{
+    static_assert(RW >= 0 && RW <= 2 && D - 1 - RW >= 1 && D - 2 > RW, "register windows hand over through the last LDS window while it is idle");
+    const int lane = cx.lane, x4 = cx.x4;
+    const int i = NST < D ? NST - 1 : i_;
+    const int it = PAR >= 0 ? PAR : i;              // (only its parity is used)
+    auto row_at = [&](int p) { return DOWN ? cx.ym - 1 - p : cx.ym + p; };
+    // ---- what the other wave published for "position -1" of the register windows in its previous iteration ---------------
+    f4a (*MB)[64] = cx.mine + (D - 2 - RW) * 9;     // my last LDS window, idle until iteration D - 2: the mailbox
+    if (RW >= 1 && NST == 2) { st.w[0].g2 = MB[6][lane]; st.w[0].g5 = MB[7][lane]; st.w[0].g6 = MB[8][lane]; }
+    if (RW >= 2 && NST == 3) { st.w[RW >= 2 ? 1 : 0].g2 = MB[3][lane]; st.w[RW >= 2 ? 1 : 0].g5 = MB[4][lane]; st.w[RW >= 2 ? 1 : 0].g6 = MB[5][lane]; }
+    // ---- step 1 of position i (from memory) --------------------------------------------------------------------------------
+    // (behind the last position the last row is gathered again -- a cache hit that nobody consumes: no condition on i)
+#ifdef LB_DIAG
+    if (!((a.diag & (1 << 23)) && i > 0))
+#endif
+    {
+        if (PFD) row1_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, false, 0, nxt);
+        else row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
+    }
+    f4a (&q1)[9] = cur.q;
+    f4a r4, u4, v4;
+    const uc4 mk = cur.mk;
+    if (cur.have) {
+        gather_merge<BC, true>(a, x4, q1, cur.wp);
+        LB_DEEP_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
+    }
+    if (NST == 1) {
+        if constexpr (RW >= 1) lds_publish<DOWN>(cx.other + (D - 2 - RW) * 9, lane, 6, q1);      // (mailbox)
+        else lds_publish<DOWN>(cx.other, lane, 3 + 3 * 1, q1);
+    }
+    deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
+    if (MASK) st.mhist = ((st.mhist | mask_word(mk)) << 1) & (0x01010101u * (unsigned)(((1 << D) - 2) & 0xff));
+    if (NST < D) __syncthreads();                   // what was published in this iteration is consumed in the next
+}
+
+// the filling iterations 0..D-2, one after the other (NST = 1..D-1); PFD = 1: the two row buffers swap roles every iteration
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST>
+__device__ __forceinline__ void deep_fill(const StepArgs &a, const DeepCtx &cx, DeepState<RW> &st, Row1 &ra, Row1 &rb)
+{
+    if constexpr (NST < D) {
+        if (PFD == 1 && (NST & 1) == 0) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, rb, ra);
+        else deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, ra, PFD ? rb : ra);
+        deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, NST + 1>(a, cx, st, ra, rb);
+    }
+}
+
+// One wave's march: columns [x0, x0 + 256) of which [x0 + 8, x0 + 248) are stored, `len` rows from the pair's middle line `ym`
+// upward or downward; len + D - 1 iterations.
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN>
+__device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, const int ym, const int len, f4a (*mine)[64],
+                                           f4a (*other)[64])
+{
+    DeepCtx cx;
+    cx.lane = threadIdx.x;
+    const int xr = x0 + cx.lane * 4;                 // true column of my first cell: -8 .. ; may lie beyond either end of the box
+    // lanes beyond an end of the box: the periodic images as far as the skirt reaches (behind it: the last image lane's lines), or
+    // -- walls -- copies of the lane at that end (a wall column's rule rebuilds whatever it pulled from outside)
+    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (xr - a.nx < STEP6_SKIRT ? xr - a.nx : 4) : xr);
+    else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
+    cx.store_lane = cx.lane >= 2 && cx.lane <= 61 && xr < a.nx;
+    cx.ym = ym; cx.n_iter = len + D - 1;
+    cx.mine = mine; cx.other = other;
+    DeepState<RW> st = {};
+    auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
+    Row1 ra, rb;
+    if (PFD) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
+    deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, 1>(a, cx, st, ra, rb);
+    if (PFD == 1) {
+        // position i is in ra for even i, in rb for odd i; the steady iterations in pairs
+        constexpr int P0 = (D - 1) & 1;
+        int i = D - 1;
+        for (; i + 1 < cx.n_iter; i += 2) {
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, 1 - P0>(a, cx, i + 1, st, P0 ? ra : rb, P0 ? rb : ra);
+        }
+        if (i < cx.n_iter) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
+    } else {
+        for (int i = D - 1; i < cx.n_iter; ++i) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D>(a, cx, i, st, ra, ra);
+    }
+}
+
+// Launch geometry as k_step5 / k_step6: one workgroup = one segment pair of one strip (two waves), XCD-transposed order, shorter
+// segments for the two wall-column strips.  LDS: (D - 1 - RW) x 9 KiB per wave.
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD>
+__global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+{
+    __shared__ f4a lds_win[STEP4_WAVES][(D - 1 - RW) * 9][64];
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int item = xcd_item(blockIdx.x, gridDim.x);
+    int sx, sy;
+    if (item < strips * nsegs) {
+        sx = item % strips;
+        sy = item / strips;
+    } else {
+        if (!a.edge_seg_rows) return;
+        const int j = item - strips * nsegs;
+        sx = (j & 1) ? strips - 1 : 0;
+        sy = nsegs + (j >> 1);
+    }
+    int stride = a.seg_stride;
+    if (a.edge_seg_rows && (sx == 0 || sx == strips - 1)) stride = seg_rows = a.edge_seg_rows;
+    const int ya = a.row_begin + sy * stride;
+    if (ya >= row_end) return;                          // (both waves of the workgroup: the barriers stay matched)
+    const int yb = min(ya + seg_rows, row_end);
+    const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
+    const int x0 = sx * STEP6_VALID - STEP6_SKIRT;
+    if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+    else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+}
+
+}  // namespace

@@ -42,8 +42,33 @@ struct March5Ctx {
 
 // gather of the next stage for my 4 cells from a window {d0,d1,d3,g2,g5,g6} and the newest row q; what lanes 0 / 63 take
 // from beyond the wave is their own value: wrong, and never within reach of a stored cell
-__device__ __forceinline__ f4a skirt_left(f4a v) { return f4a{__shfl_up(v.w, 1), v.x, v.y, v.z}; }
-__device__ __forceinline__ f4a skirt_right(f4a v) { return f4a{v.y, v.z, v.w, __shfl_down(v.x, 1)}; }
+// (the neighbour lane's element by a DPP move -- wave_shr:1 / wave_shl:1, one vector-ALU pass; lanes 0 / 63, which have no such
+//  neighbour, get 0.0: as wrong as their own value, and as far from every stored cell.  Round 5; until then -- and with
+//  -DLB_SKIRT_BPERMUTE -- by ds_bpermute: an LDS-queue round trip per element, 36 per row of six stages.  Bitwise equal, same speed
+//  at two waves per SIMD, +2 % at one: profiles/r05_experiments.txt)
+#ifndef LB_SKIRT_BPERMUTE
+#define LB_SKIRT_DPP 1
+#endif
+__device__ __forceinline__ float wave_from_left(float v)
+{
+#ifdef LB_SKIRT_DPP
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x138, 0xf, 0xf, true));
+#else
+    return __shfl_up(v, 1);
+#endif
+}
+__device__ __forceinline__ float wave_from_right(float v)
+{
+#ifdef LB_SKIRT_DPP
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x130, 0xf, 0xf, true));
+#else
+    return __shfl_down(v, 1);
+#endif
+}
+__device__ __forceinline__ f4a skirt_left(f4a v) { return f4a{wave_from_left(v.w), v.x, v.y, v.z}; }
+__device__ __forceinline__ f4a skirt_right(f4a v) { return f4a{v.y, v.z, v.w, wave_from_right(v.x)}; }
 template <bool DOWN>
 __device__ __forceinline__ void skirt_gather(const Window &w, const f4a (&q)[9], f4a (&t)[9])
 {

@@ -10,6 +10,15 @@
 // bitwise equal to k_step.
 #pragma once
 
+// diagnostic build (tools/ablate.py; timing only, wrong results): LB_DIAG bit 0 = no cell arithmetic in any stage, bit 21 = strips
+// 256 cells apart without skirts (rows start on 1-KiB boundaries), bit 22 = no stores, bit 23 = only the first row of a segment is
+// loaded
+#ifdef LB_DIAG
+#define LB_DIAG_NOCOLLIDE if (!(a.diag & 1))
+#else
+#define LB_DIAG_NOCOLLIDE
+#endif
+
 namespace {
 
 constexpr int STEP6_SKIRT = 8;                          // cells a strip starts before / ends behind its stored cells (two lanes)
@@ -46,19 +55,25 @@ __device__ __forceinline__ void ring_push(f4a (*R)[64], int lane, int it, const 
 // One iteration: position i is loaded and takes step 1, position i-1 step 2 (window 1), i-2 step 3 (window 2), i-3 step 4 (window 3),
 // i-4 step 5 (window 4), i-5 step 6 (window 5; stored).  NST = number of stages that have a row: 1..5 in iterations 0..4 (code of
 // their own: the pipeline fills, the two waves of the pair hand over), 6 in the loop.
-template <int BC, bool MASK, bool MACRO, bool DOWN, int NST>
-__device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &cx, const int i_, March6State &st)
+// PFD = rows gathered ahead (0: the row is loaded where it is consumed; 1, 2: `cur` holds position i on entry, gathered PFD
+// iterations ago, and position i + PFD is gathered into `nxt` at the top of the iteration -- the form for ONE wave per SIMD, whose
+// 512 registers hold the rows in flight and who has no second wave to cover its waits).
+// PAR (PFD >= 1, steady iterations in pairs): the parity of i as a constant -- the ring slots of the LDS windows become immediate
+// offsets, and the two row buffers swap roles from one iteration to the next instead of being copied.
+template <int BC, bool MASK, bool MACRO, int PFD, bool DOWN, int NST, int PAR = -1>
+__device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &cx, const int i_, March6State &st, Row1 &cur,
+                                            Row1 &nxt)
 {
     const int lane = cx.lane, x4 = cx.x4;
     const long long S = a.plane;
     const int i = NST < 6 ? NST - 1 : i_;
-    const int it = i;
+    const int it = PAR >= 0 ? PAR : i;               // (only its parity is used)
     auto row_at = [&](int p) { return DOWN ? cx.ym - 1 - p : cx.ym + p; };
     f4a(*W4)[64] = cx.W4;
     f4a(*W5)[64] = cx.W5;
     Window &w1 = st.w1, &w2 = st.w2;
 
-    if (a.prio_turns > 0 && (i & 3) == 0) {            // the two waves of a SIMD take turns at the higher priority (march4_iter)
+    if (PFD == 0 && a.prio_turns > 0 && (i & 3) == 0) {   // (one wave per SIMD -- PFD >= 1 -- has nobody to take turns with)            // the two waves of a SIMD take turns at the higher priority (march4_iter)
         const unsigned turn = (unsigned)(__builtin_amdgcn_s_memrealtime() >> a.prio_turns) & 1u;
         if (turn == cx.slot) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
@@ -69,14 +84,20 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
     if (NST == 2) { w1.g2 = W5[6][lane]; w1.g5 = W5[7][lane]; w1.g6 = W5[8][lane]; }
     if (NST == 3) { w2.g2 = W5[3][lane]; w2.g5 = W5[4][lane]; w2.g6 = W5[5][lane]; }
     // ---- step 1 of position i (from memory) --------------------------------------------------------------------
-    Row1 cur;
-    row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
+    // (behind the last position the last row is gathered again -- a cache hit that nobody consumes: no condition on i)
+#ifdef LB_DIAG
+    if (!((a.diag & (1 << 23)) && i > 0))
+#endif
+    {
+    if (PFD) row1_load<BC, MASK>(a, row_at(min(i + PFD, cx.n_iter - 1)), x4, false, 0, nxt);
+    else row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
+    }
     f4a (&q1)[9] = cur.q;
     f4a r4, u4, v4;
     const uc4 mk = cur.mk;
     if (cur.have) {
         gather_merge<BC, true>(a, x4, q1, cur.wp);
-        collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
+        LB_DIAG_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
     }
     if (NST == 1) lds_publish<DOWN>(cx.P5, lane, 6, q1);        // my position 0 after step 1 -> the other wave's window 1 (mailbox)
     // ---- step 2 of position i-1 (window 1, registers) ----------------------------------------------------------
@@ -86,7 +107,7 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
         (void)step1_rows(a, row_at(i - 1), r2, t0_, t1_);
         skirt_gather<DOWN>(w1, q1, q2);
         window_push_dir<DOWN>(w1, q1);
-        collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(st.mhist, 1), r4, u4, v4);
+        LB_DIAG_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r2, q2, mask_bits(st.mhist, 1), r4, u4, v4);
         if (NST == 2) lds_publish<DOWN>(cx.P5, lane, 3, q2);    // my position 0 after step 2 -> the other wave's window 2 (mailbox)
     } else {
         window_push_dir<DOWN>(w1, q1);
@@ -98,7 +119,7 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
         (void)step1_rows(a, row_at(i - 2), r3, t0_, t1_);
         skirt_gather<DOWN>(w2, q2, q3);
         window_push_dir<DOWN>(w2, q2);
-        collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(st.mhist, 2), r4, u4, v4);
+        LB_DIAG_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r3, q3, mask_bits(st.mhist, 2), r4, u4, v4);
         if (NST == 3) lds_publish<DOWN>(cx.Q3, lane, 3, q3);    // my position 0 after step 3 -> the other wave's ring of window 3
     } else if (NST == 2) {
         window_push_dir<DOWN>(w2, q2);
@@ -114,7 +135,7 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
         skirt_gather<DOWN>(w3, q3, q4);
         ring_push<DOWN>(cx.R3, lane, it, q3);
         cx.R3[6][lane] = q3[0]; cx.R3[7][lane] = q3[1]; st.w3d3 = q3[3];
-        collide_row<BC, MASK>(a, x4, a.y0 + r4_, q4, mask_bits(st.mhist, 3), r4, u4, v4);
+        LB_DIAG_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r4_, q4, mask_bits(st.mhist, 3), r4, u4, v4);
         if (NST == 4) lds_publish<DOWN>(cx.P4, lane, 3, q4);    // my position 0 after step 4 -> the other wave's window 4
     } else if (NST == 3) {
         ring_push<DOWN>(cx.R3, lane, it, q3);       // position 0 after step 3: ring row of even iterations (the other wave fills the odd one)
@@ -129,7 +150,7 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
         lds_window_load(W4, lane, it, w4);
         skirt_gather<DOWN>(w4, q4, q5);
         lds_window_push<DOWN>(W4, lane, it, q4);
-        collide_row<BC, MASK>(a, x4, a.y0 + r5, q5, mask_bits(st.mhist, 4), r4, u4, v4);
+        LB_DIAG_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r5, q5, mask_bits(st.mhist, 4), r4, u4, v4);
         if (NST == 5) lds_publish<DOWN>(cx.P5, lane, 6, q5);    // my position 0 after step 5 -> the other wave's window 5
     } else if (NST == 4) {
         lds_window_push<DOWN>(W4, lane, it, q4);    // position 0 after step 4: the d slots and ring slot 6 (the other wave fills slot 3)
@@ -143,7 +164,10 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
         f4a t[9];
         skirt_gather<DOWN>(w5, q5, t);
         lds_window_push<DOWN>(W5, lane, it, q5);
-        collide_row<BC, MASK>(a, x4, a.y0 + r6, t, mask_bits(st.mhist, 5), r4, u4, v4);
+        LB_DIAG_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r6, t, mask_bits(st.mhist, 5), r4, u4, v4);
+#ifdef LB_DIAG
+        if (!(a.diag & (1 << 22)))
+#endif
         if (cx.store_lane) {
             const long long o = (long long)r6 * a.pitch;    // row start, uniform
             float *d = a.dst + o;
@@ -164,7 +188,7 @@ __device__ __forceinline__ void march6_iter(const StepArgs &a, const March6Ctx &
 
 // One wave's march: columns [x0, x0 + 256) of which [x0 + 8, x0 + 248) are stored, `len` rows from the pair's middle line `ym`
 // upward or downward; len + 5 iterations.
-template <int BC, bool MASK, bool MACRO, bool DOWN>
+template <int BC, bool MASK, bool MACRO, int PFD, bool DOWN>
 __device__ __forceinline__ void march6(const StepArgs &a, const int x0, const int ym, const int len, const int wy,
                                        f4a (*mine)[64], f4a (*other)[64], const unsigned slot)
 {
@@ -176,22 +200,47 @@ __device__ __forceinline__ void march6(const StepArgs &a, const int x0, const in
     if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (xr - a.nx < STEP6_SKIRT ? xr - a.nx : 4) : xr);
     else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
     cx.store_lane = cx.lane >= 2 && cx.lane <= 61 && xr < a.nx;
+#ifdef LB_DIAG
+    if (a.diag & (1 << 21)) { cx.x4 = xr; cx.store_lane = true; }
+#endif
     cx.ym = ym; cx.n_iter = len + 5; cx.wy = wy; cx.slot = slot;
     cx.R3 = mine; cx.W4 = mine + 8; cx.W5 = mine + 17;          // (slots: window 3's ring + its links 0, 1; window 4; window 5)
     cx.Q3 = other; cx.P4 = other + 8; cx.P5 = other + 17;
     March6State st = {};
-    march6_iter<BC, MASK, MACRO, DOWN, 1>(a, cx, 0, st);
-    march6_iter<BC, MASK, MACRO, DOWN, 2>(a, cx, 1, st);
-    march6_iter<BC, MASK, MACRO, DOWN, 3>(a, cx, 2, st);
-    march6_iter<BC, MASK, MACRO, DOWN, 4>(a, cx, 3, st);
-    march6_iter<BC, MASK, MACRO, DOWN, 5>(a, cx, 4, st);
-    for (int i = 5; i < cx.n_iter; ++i) march6_iter<BC, MASK, MACRO, DOWN, 6>(a, cx, i, st);
+    auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
+    Row1 ra, rb, rc;
+    if (PFD >= 1) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
+    if (PFD >= 2) row1_load<BC, MASK>(a, row_at(1), cx.x4, false, 0, rb);
+    if (PFD == 1) {
+        // rows in flight: one; the two buffers swap roles every iteration (position i in ra for even i, in rb for odd i)
+        march6_iter<BC, MASK, MACRO, PFD, DOWN, 1>(a, cx, 0, st, ra, rb);
+        march6_iter<BC, MASK, MACRO, PFD, DOWN, 2>(a, cx, 1, st, rb, ra);
+        march6_iter<BC, MASK, MACRO, PFD, DOWN, 3>(a, cx, 2, st, ra, rb);
+        march6_iter<BC, MASK, MACRO, PFD, DOWN, 4>(a, cx, 3, st, rb, ra);
+        march6_iter<BC, MASK, MACRO, PFD, DOWN, 5>(a, cx, 4, st, ra, rb);
+        int i = 5;
+        for (; i + 1 < cx.n_iter; i += 2) {
+            march6_iter<BC, MASK, MACRO, PFD, DOWN, 6, 1>(a, cx, i, st, rb, ra);
+            march6_iter<BC, MASK, MACRO, PFD, DOWN, 6, 0>(a, cx, i + 1, st, ra, rb);
+        }
+        if (i < cx.n_iter) march6_iter<BC, MASK, MACRO, PFD, DOWN, 6, 1>(a, cx, i, st, rb, ra);
+        return;
+    }
+    // rows in flight: ra = position i, (PFD = 2: rb = i + 1,) the newest one lands in rc
+#define LB_M6(NST, I)                                                                                   \
+    do {                                                                                                \
+        march6_iter<BC, MASK, MACRO, PFD, DOWN, NST>(a, cx, I, st, ra, PFD == 2 ? rc : ra);             \
+        if (PFD == 2) { ra = rb; rb = rc; }                                                             \
+    } while (0)
+    LB_M6(1, 0); LB_M6(2, 1); LB_M6(3, 2); LB_M6(4, 3); LB_M6(5, 4);
+    for (int i = 5; i < cx.n_iter; ++i) LB_M6(6, i);
+#undef LB_M6
 }
 
 // Launch geometry as k_step5: one workgroup = one segment pair of one strip (two waves), XCD-transposed order, shorter segments
 // for the two wall-column strips.  48 KB of LDS: three workgroups per CU.
-template <int BC, bool MASK, bool MACRO>
-__global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step6(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+template <int BC, bool MASK, bool MACRO, int PFD = 0>
+__global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_step6(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     __shared__ f4a lds_win[STEP4_WAVES][26][64];
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -213,9 +262,12 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, 2) void k_step6(const StepArgs a,
     if (ya >= row_end) return;                          // (both waves of the workgroup: the barriers stay matched)
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
-    const int x0 = sx * STEP6_VALID - STEP6_SKIRT;
-    if (wy == 0) march6<BC, MASK, MACRO, true>(a, x0, ym, ym - ya, 0, lds_win[0], lds_win[1], slot);
-    else march6<BC, MASK, MACRO, false>(a, x0, ym, yb - ym, 1, lds_win[1], lds_win[0], slot);
+    int x0 = sx * STEP6_VALID - STEP6_SKIRT;
+#ifdef LB_DIAG
+    if (a.diag & (1 << 21)) x0 = sx * STRIP_W;
+#endif
+    if (wy == 0) march6<BC, MASK, MACRO, PFD, true>(a, x0, ym, ym - ya, 0, lds_win[0], lds_win[1], slot);
+    else march6<BC, MASK, MACRO, PFD, false>(a, x0, ym, yb - ym, 1, lds_win[1], lds_win[0], slot);
 }
 
 }  // namespace

@@ -381,7 +381,10 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
     // (k_step5: overlapping strips, 248 cells apart)
-    const int strips = depth == 6 ? step6_strips(s->p.nx) : (depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
+    int strips = depth == 6 ? step6_strips(s->p.nx) : (depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
+#ifdef LB_DIAG
+    if (depth == 6 && (s->diag & (1 << 21))) strips = (s->p.nx + STRIP_W - 1) / STRIP_W;    // (timing only: k_step6 on 256-cell strips without skirts)
+#endif
     int segs, seg_rows, extra_items = 0;
     if (nsegs_fixed > 0) {
         segs = nsegs_fixed;

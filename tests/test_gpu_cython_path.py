@@ -157,6 +157,12 @@ def test_cython_path_marching_kernel_equals_single_step_pass(lbhip, nx, ny, mask
     for variant in (0, 4096 | 512):
         s = Simulation(nx, ny, 1.3, bc="pipe", semantics="cython", inlet_rho=1.004, outlet_rho=1.0, obstacle_mask=mask)
         s.set_variant(variant)
+        if variant and "k1_step5" not in s.hot_kernel():
+            # round 5: k1_step5 left the product build (slower than the tiles at the reference's sizes); the
+            # diagnostic build (LB_LIB=.../liblbhip_diag.so) keeps it, and there this test holds it to the single-step pass
+            assert s.steps_per_launch() == 4 and "k1_tile4" in s.hot_kernel()
+            s.close()
+            pytest.skip("k1_step5 is compiled into the diagnostic build only")
         assert s.steps_per_launch() == (5 if variant else 1) and ("k1_step5" in s.hot_kernel()) == bool(variant)
         s.set_fields(f0.sum(axis=2), u0, v0)
         s.set_f(f0)

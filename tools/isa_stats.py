@@ -27,6 +27,7 @@ namespace { constexpr int GHOST = 10; constexpr int MASK_GHOST = LB_MASK_HALO_RO
 #include "%(csrc)s/kernels_step4.h"
 #include "%(csrc)s/kernels_step5.h"
 #include "%(csrc)s/kernels_step6.h"
+#include "%(csrc)s/kernels_deep.h"
 #include "%(csrc)s/kernels_tile.h"
 #include "%(csrc)s/kernels_phases.h"
 #include "%(csrc)s/kernels_step5c.h"
@@ -120,8 +121,18 @@ def main():
             for op, n in sorted(hist.items(), key=lambda t: -t[1]):
                 print("      %-28s %d" % (op, n))
     if dump:
-        out = os.path.join(tmp, "kernel.s")
         print("assembly:", os.path.join(tmp, asm))
+        if loops:                                        # the largest loop, instruction by instruction, next to the assembly
+            a, b, tgt = max(loops, key=lambda t: t[1] - t[0])
+            out = os.path.join(tmp, "loop.s")
+            open(out, "w").write("\n".join(s for op, s in insts[a:b + 1]) + "\n")
+            hist = {}
+            for op, s in insts[a:b + 1]:
+                if classify(op) != "valu":
+                    hist[op] = hist.get(op, 0) + 1
+            print("largest loop %s -> %s; its non-VALU instructions:" % (tgt, out))
+            for op, n in sorted(hist.items(), key=lambda t: -t[1]):
+                print("      %-28s %d" % (op, n))
 
 
 if __name__ == "__main__":
