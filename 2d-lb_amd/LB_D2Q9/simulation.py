@@ -457,7 +457,7 @@ class Simulation(object):
 
     def hot_kernel(self):
         """Name of the kernel run() spends its time in for this grid / variant / tuning (lb_hot_kernel)."""
-        buf = ct.create_string_buffer(160)
+        buf = ct.create_string_buffer(256)
         check(self._lib.lb_hot_kernel(self._h, buf, len(buf)))
         return buf.value.decode()
 

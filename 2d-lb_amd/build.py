@@ -20,7 +20,7 @@ HDR = os.path.join(os.path.dirname(HERE), "include", "lb_hip.h")
 OUT = os.path.join(HERE, "LB_D2Q9", "liblbhip.so")
 OBJ = os.path.join(HERE, "build")
 # (largest first: the pool starts them in this order)
-UNITS = ["march6.cpp", "march5.cpp", "march4.cpp", "lb_hip.cpp", "march23.cpp", "tile.cpp", "step1.cpp"]
+UNITS = ["deep7.cpp", "deep6.cpp", "march5.cpp", "march4.cpp", "lb_hip.cpp", "march23.cpp", "tile.cpp", "step1.cpp"]
 # -ffp-contract=on: a*b+c fuses to an FMA only inside one source expression, so every kernel instantiation (single step,
 # multi-step, slab edge rows) -- in whichever translation unit -- rounds identically: results are bitwise independent of the
 # kernel variant and of the slab partition.

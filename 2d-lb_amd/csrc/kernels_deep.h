@@ -10,7 +10,9 @@
 //   * A gfx950 SIMD issues one vector instruction per ~2.5 cycles (v_pk_*_f32: ~3.5) when TWO waves feed it, and a single wave no
 //     faster than one per ~5 cycles -- any instruction, packed or not, vector, scalar or LDS (tools/valu_issue_probe.hip).
 //   So the kernel is parametrised on where a wave's state lives:
-//     RW   stage windows kept in registers (the first RW of the D - 1), the others in wave-private LDS, nine 1-KiB slots each;
+//     RW   stage windows kept in registers (the first RW of the D - 1), the others in wave-private LDS: eight 1-KiB slots each
+//          (links 1, 3 of the newest row and the two-row ring of the three links pulled from behind; link 0, which no stage shifts,
+//          stays in four registers per window) -- five of them fill the 40 KB a wave has at four waves per CU: D = 7 with RW = 1;
 //     PFD  rows gathered ahead (0: none -- two waves per SIMD cover each other's waits; 1: the next row's gather is in flight while
 //          this one is computed -- ONE wave per SIMD, 512 registers, 40 KB of LDS: __launch_bounds__(128, 1)).
 //   The launch moves the same 72 B per cell whatever D is.  Same cell functions as every kernel: bitwise equal to k_step.
@@ -28,26 +30,61 @@
 
 namespace {
 
-template <int RW>
+// The skirt is D - 1 cells deep, i.e. whole lanes of four cells that are computed and never stored, at either end of a strip
+constexpr int deep_skirt_lanes(int D) { return (D - 1 + 3) / 4; }
+constexpr int deep_valid(int D) { return STRIP_W - 8 * deep_skirt_lanes(D); }           // cells stored per strip and row (D = 6..9: 240)
+constexpr int deep_strips(int nx, int D) { return (nx + deep_valid(D) - 1) / deep_valid(D); }
+// Where a wave's state lives, per depth (see the header comment): windows in registers, rows gathered ahead
+constexpr int deep_rw(int D) { return 1; }
+constexpr int DEEP_WSLOTS = 8;          // LDS slots of a stage window
+constexpr int deep_pfd(int D) { return 1; }
+
+template <int RW, int NL>
 struct DeepState {
     Window w[RW > 0 ? RW : 1];          // stage windows 1..RW (registers)
+    f4a d0[NL];                         // link 0 of the newest row of the LDS windows RW+1..D-1
     unsigned mhist;                     // obstacle-mask history (per byte: bit j = the row loaded j iterations ago, j = 1..D-1)
 };
 struct DeepCtx {
     int lane, x4, ym, n_iter;
     bool store_lane;
-    f4a (*mine)[64], (*other)[64];      // my LDS windows RW+1..D-1 (nine slots each, in that order), the other wave's
+    f4a (*mine)[64], (*other)[64];      // my LDS windows RW+1..D-1 (DEEP_WSLOTS slots each, in that order), the other wave's
 };
+
+// An LDS window: slot 0, 1 = links 1, 3 of the newest row; slots 2..4 / 5..7 = links A, B, C (pulled from behind) of the newest two
+// rows, a ring: the iteration's parity picks the OLDER row, which is read, then overwritten
+__device__ __forceinline__ void deep_window_load(f4a (*W)[64], int lane, int it, f4a d0, Window &w)
+{
+    const int gs = 2 + 3 * (it & 1);
+    w.d0 = d0; w.d1 = W[0][lane]; w.d3 = W[1][lane];
+    w.g2 = W[gs][lane]; w.g5 = W[gs + 1][lane]; w.g6 = W[gs + 2][lane];
+}
+template <bool DOWN>
+__device__ __forceinline__ void deep_window_push(f4a (*W)[64], int lane, int it, f4a &d0, const f4a (&q)[9])
+{
+    typedef Dir<DOWN> D_;
+    const int gs = 2 + 3 * (it & 1);
+    d0 = q[0]; W[0][lane] = q[1]; W[1][lane] = q[3];
+    W[gs][lane] = q[D_::A]; W[gs + 1][lane] = q[D_::B]; W[gs + 2][lane] = q[D_::C];
+}
+// the three links of row q that cross the pair's middle line, into the OTHER wave's window at ring slots gs..gs+2
+template <bool DOWN>
+__device__ __forceinline__ void deep_publish(f4a (*W)[64], int lane, int gs, const f4a (&q)[9])
+{
+    typedef Dir<DOWN> D_;
+    W[gs][lane] = q[D_::An]; W[gs + 1][lane] = q[D_::Bn]; W[gs + 2][lane] = q[D_::Cn];
+}
 
 // Stages S..D of one iteration, S >= 2.  qin = the row stage S - 1 produced in this iteration (position i - (S - 2)).
 template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S>
-__device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it, DeepState<RW> &st,
-                                           f4a (&qin)[9], f4a &r4, f4a &u4, f4a &v4)
+__device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it,
+                                           DeepState<RW, D - 1 - RW> &st, f4a (&qin)[9], f4a &r4, f4a &u4, f4a &v4)
 {
     if constexpr (S <= D) {
         constexpr int K = S - 1;                                   // the window this stage reads
         const int lane = cx.lane, x4 = cx.x4;
-        f4a (*W)[64] = cx.mine + (K - RW - 1) * 9;                 // (meaningful for K > RW only)
+        constexpr int L = K > RW ? K - RW - 1 : 0;                 // my LDS window's index (meaningful for K > RW only)
+        f4a (*W)[64] = cx.mine + L * DEEP_WSLOTS;
         if constexpr (NST >= S) {
             int r, t0_, t1_;
             (void)step1_rows(a, DOWN ? cx.ym - 1 - (i - K) : cx.ym + (i - K), r, t0_, t1_);
@@ -58,9 +95,9 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                 window_push_dir<DOWN>(st.w[K - 1], qin);
             } else {
                 Window w;
-                lds_window_load(W, lane, it, w);
+                deep_window_load(W, lane, it, st.d0[L], w);
                 skirt_gather<DOWN>(w, qin, t);
-                lds_window_push<DOWN>(W, lane, it, qin);
+                deep_window_push<DOWN>(W, lane, it, st.d0[L], qin);
             }
             LB_DEEP_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
             if constexpr (S == D) {
@@ -80,17 +117,17 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
             } else {
                 if constexpr (NST == S) {
                     // my position 0 after step S -> what the other wave's stage S + 1 pulls from behind ITS position 0: into its
-                    // window S -- the ring slot it reads as "the older row" in its next iteration (i = S: 3 + 3 (S & 1)) --, or,
+                    // window S -- the ring row it reads as "the older one" in its next iteration (i = S: 2 + 3 (S & 1)) --, or,
                     // a register window, through its still idle last LDS window (read at the top of its next iteration)
-                    if constexpr (S <= RW) lds_publish<DOWN>(cx.other + (D - 2 - RW) * 9, lane, S == 1 ? 6 : 3, t);
-                    else lds_publish<DOWN>(cx.other + (S - RW - 1) * 9, lane, 3 + 3 * (S & 1), t);
+                    if constexpr (S <= RW) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, S == 1 ? 5 : 2, t);
+                    else deep_publish<DOWN>(cx.other + (S - RW - 1) * DEEP_WSLOTS, lane, 2 + 3 * (S & 1), t);
                 }
                 deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
             }
         } else if constexpr (NST == S - 1) {
-            // position 0 after step K enters window K (its d slots and the ring slot of this parity; the other wave fills the other one)
+            // position 0 after step K enters window K (its d slots and the ring row of this parity; the other wave fills the other one)
             if constexpr (K <= RW) window_push_dir<DOWN>(st.w[K - 1], qin);
-            else lds_window_push<DOWN>(W, lane, it, qin);
+            else deep_window_push<DOWN>(W, lane, it, st.d0[L], qin);
         }
     }
 }
@@ -100,17 +137,19 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
 // over), D in the loop.  PFD = 1: `cur` holds position i on entry and position i + 1 is gathered into `nxt` first; the caller swaps
 // the two from one iteration to the next.  PAR >= 0: the parity of i as a constant (the LDS ring slots become immediate offsets).
 template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST, int PAR = -1>
-__device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, const int i_, DeepState<RW> &st, Row1 &cur, Row1 &nxt)
+__device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, const int i_, DeepState<RW, D - 1 - RW> &st, Row1 &cur,
+                                          Row1 &nxt)
 {
     static_assert(RW >= 0 && RW <= 2 && D - 1 - RW >= 1 && D - 2 > RW, "register windows hand over through the last LDS window while it is idle");
+    static_assert((D - 1 - RW) * DEEP_WSLOTS <= 40, "a wave has 40 KB of LDS at four waves per CU");
     const int lane = cx.lane, x4 = cx.x4;
     const int i = NST < D ? NST - 1 : i_;
     const int it = PAR >= 0 ? PAR : i;              // (only its parity is used)
     auto row_at = [&](int p) { return DOWN ? cx.ym - 1 - p : cx.ym + p; };
     // ---- what the other wave published for "position -1" of the register windows in its previous iteration ---------------
-    f4a (*MB)[64] = cx.mine + (D - 2 - RW) * 9;     // my last LDS window, idle until iteration D - 2: the mailbox
-    if (RW >= 1 && NST == 2) { st.w[0].g2 = MB[6][lane]; st.w[0].g5 = MB[7][lane]; st.w[0].g6 = MB[8][lane]; }
-    if (RW >= 2 && NST == 3) { st.w[RW >= 2 ? 1 : 0].g2 = MB[3][lane]; st.w[RW >= 2 ? 1 : 0].g5 = MB[4][lane]; st.w[RW >= 2 ? 1 : 0].g6 = MB[5][lane]; }
+    f4a (*MB)[64] = cx.mine + (D - 2 - RW) * DEEP_WSLOTS;       // my last LDS window, idle until iteration D - 2: the mailbox
+    if (RW >= 1 && NST == 2) { st.w[0].g2 = MB[5][lane]; st.w[0].g5 = MB[6][lane]; st.w[0].g6 = MB[7][lane]; }
+    if (RW >= 2 && NST == 3) { st.w[RW >= 2 ? 1 : 0].g2 = MB[2][lane]; st.w[RW >= 2 ? 1 : 0].g5 = MB[3][lane]; st.w[RW >= 2 ? 1 : 0].g6 = MB[4][lane]; }
     // ---- step 1 of position i (from memory) --------------------------------------------------------------------------------
     // (behind the last position the last row is gathered again -- a cache hit that nobody consumes: no condition on i)
 #ifdef LB_DIAG
@@ -128,8 +167,8 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
         LB_DEEP_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
     }
     if (NST == 1) {
-        if constexpr (RW >= 1) lds_publish<DOWN>(cx.other + (D - 2 - RW) * 9, lane, 6, q1);      // (mailbox)
-        else lds_publish<DOWN>(cx.other, lane, 3 + 3 * 1, q1);
+        if constexpr (RW >= 1) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, 5, q1);      // (mailbox)
+        else deep_publish<DOWN>(cx.other, lane, 2 + 3 * 1, q1);
     }
     deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
     if (MASK) st.mhist = ((st.mhist | mask_word(mk)) << 1) & (0x01010101u * (unsigned)(((1 << D) - 2) & 0xff));
@@ -138,7 +177,7 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
 
 // the filling iterations 0..D-2, one after the other (NST = 1..D-1); PFD = 1: the two row buffers swap roles every iteration
 template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST>
-__device__ __forceinline__ void deep_fill(const StepArgs &a, const DeepCtx &cx, DeepState<RW> &st, Row1 &ra, Row1 &rb)
+__device__ __forceinline__ void deep_fill(const StepArgs &a, const DeepCtx &cx, DeepState<RW, D - 1 - RW> &st, Row1 &ra, Row1 &rb)
 {
     if constexpr (NST < D) {
         if (PFD == 1 && (NST & 1) == 0) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, rb, ra);
@@ -147,7 +186,7 @@ __device__ __forceinline__ void deep_fill(const StepArgs &a, const DeepCtx &cx, 
     }
 }
 
-// One wave's march: columns [x0, x0 + 256) of which [x0 + 8, x0 + 248) are stored, `len` rows from the pair's middle line `ym`
+// One wave's march: columns [x0, x0 + 256) of which all but the skirt lanes at either end are stored, `len` rows from the pair's middle line `ym`
 // upward or downward; len + D - 1 iterations.
 template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN>
 __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, const int ym, const int len, f4a (*mine)[64],
@@ -158,12 +197,13 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     const int xr = x0 + cx.lane * 4;                 // true column of my first cell: -8 .. ; may lie beyond either end of the box
     // lanes beyond an end of the box: the periodic images as far as the skirt reaches (behind it: the last image lane's lines), or
     // -- walls -- copies of the lane at that end (a wall column's rule rebuilds whatever it pulled from outside)
-    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (xr - a.nx < STEP6_SKIRT ? xr - a.nx : 4) : xr);
+    constexpr int SKL = deep_skirt_lanes(D);
+    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (xr - a.nx < 4 * SKL ? xr - a.nx : 4 * (SKL - 1)) : xr);
     else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
-    cx.store_lane = cx.lane >= 2 && cx.lane <= 61 && xr < a.nx;
+    cx.store_lane = cx.lane >= SKL && cx.lane <= 63 - SKL && xr < a.nx;
     cx.ym = ym; cx.n_iter = len + D - 1;
     cx.mine = mine; cx.other = other;
-    DeepState<RW> st = {};
+    DeepState<RW, D - 1 - RW> st = {};
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
     Row1 ra, rb;
     if (PFD) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
@@ -183,13 +223,16 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
 }
 
 // Launch geometry as k_step5 / k_step6: one workgroup = one segment pair of one strip (two waves), XCD-transposed order, shorter
-// segments for the two wall-column strips.  LDS: (D - 1 - RW) x 9 KiB per wave.
+// segments for the two wall-column strips.  LDS: (D - 1 - RW) x 8 KiB per wave.
 template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD>
 __global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
-    __shared__ f4a lds_win[STEP4_WAVES][(D - 1 - RW) * 9][64];
+    __shared__ f4a lds_win[STEP4_WAVES][(D - 1 - RW) * DEEP_WSLOTS][64];
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int item = xcd_item(blockIdx.x, gridDim.x);
+#ifdef LB_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+#endif
     int sx, sy;
     if (item < strips * nsegs) {
         sx = item % strips;
@@ -206,9 +249,21 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const 
     if (ya >= row_end) return;                          // (both waves of the workgroup: the barriers stay matched)
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
-    const int x0 = sx * STEP6_VALID - STEP6_SKIRT;
+    const int x0 = sx * deep_valid(D) - 4 * deep_skirt_lanes(D);
     if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
     else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+#ifdef LB_DIAG
+    if ((a.diag & 4096) && threadIdx.x == 0) {
+        // per-wave timeline into the (otherwise unused) rho array: start, end (100 MHz ticks), XCC id, HW id, item, rows (tools/wave_timeline.py)
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned *o = reinterpret_cast<unsigned *>(a.rho) + 8 * (item * STEP4_WAVES + wy);
+        o[0] = (unsigned)diag_t0; o[1] = (unsigned)(diag_t0 >> 32); o[2] = (unsigned)t1; o[3] = (unsigned)(t1 >> 32);
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+        o[6] = (unsigned)(item * STEP4_WAVES + wy); o[7] = (unsigned)(wy ? yb - ym : ym - ya);
+    }
+#endif
 }
 
 }  // namespace

@@ -2,7 +2,7 @@
 //
 // Until round 5 liblbhip.so was ONE translation unit: 368 kernel instantiations compiled one after the other, six and a half
 // minutes on eight cores.  Now every kernel family is instantiated in a file of its own (step1.cpp, march23.cpp, march4.cpp,
-// march5.cpp, march6.cpp, tile.cpp), which build.py compiles in parallel; lb_hip.cpp keeps the host side, the C ABI and the
+// march5.cpp, deep6.cpp, deep7.cpp, tile.cpp), which build.py compiles in parallel; lb_hip.cpp keeps the host side, the C ABI and the
 // small un-fused kernels.  A family's file exports one plain function -- below -- that picks the instantiation (boundary family,
 // obstacle mask, rho/u/v epilogue, ...) and launches it; arguments are the kernels' own (StepArgs, kernels_fused.h) plus the launch
 // geometry.  Every kernel stays a template in a header: a translation unit only pays for what it launches.
@@ -10,7 +10,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels_fused.h"
 
-// geometry of a marching launch (k_step2 ... k_step6; launch_step2 in lb_hip.cpp computes it)
+// geometry of a marching launch (k_step2 ... k_step5, k_deep; launch_step2 in lb_hip.cpp computes it)
 struct MarchLaunch {
     dim3 grid, block;
     hipStream_t stream;
@@ -23,7 +23,8 @@ void lbk_launch_step_batch(bool mask, bool macro, dim3 grid, dim3 block, hipStre
 void lbk_launch_march23(int depth, int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                       // march23.cpp
 void lbk_launch_march4(int bc, bool mask, bool macro, bool prefetch, const MarchLaunch &g, const StepArgs &a);                    // march4.cpp
 void lbk_launch_march5(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                   // march5.cpp
-void lbk_launch_march6(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                   // march6.cpp (not VELOCITY_INLET)
+void lbk_launch_deep6(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep6.cpp (not VELOCITY_INLET)
+void lbk_launch_deep7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep7.cpp (not VELOCITY_INLET)
 // k_tile4 over a whole grid of nx x h cells; shape 0: 32 x 16 tiles, two cells per thread; 1: 32 x 16, one; 2: 16 x 16, one
 void lbk_launch_tile4(int bc, bool mask, bool macro, int shape, int nx, int h, hipStream_t st, const StepArgs &a);                // tile.cpp (not VELOCITY_INLET)
 void lbk_launch_vel_band(bool mask, bool macro, int d, dim3 grid, dim3 block, hipStream_t st, const StepArgs &a);                 // tile.cpp (d = 3, 4, 5)

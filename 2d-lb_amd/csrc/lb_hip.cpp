@@ -20,8 +20,8 @@
 //                                                         plane = (H+2*GHOST)*pitch);
 // rho, u, v are [H][pitch]; the obstacle mask is uint8 [H + 2*LB_MASK_HALO_ROWS][pitch], row y at mask + y*pitch
 // (7 rows of each neighbour).
-// Source layout: d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2, k_step3), kernels_step4.h / 5 / 6 (k_step4 ...
-// k_step6), kernels_tile.h (k_tile4, k_vel_band), kernels_phases.h (un-fused phases, halo pack / unpack, peer transport);
+// Source layout: d2q9_cell.h (cell arithmetic), kernels_fused.h (k_step, k_step2, k_step3), kernels_step4.h / 5 (k_step4,
+// k_step5), kernels_deep.h (k_deep: six and seven steps per pass), kernels_tile.h (k_tile4, k_vel_band), kernels_phases.h (un-fused phases, halo pack / unpack, peer transport);
 // every fused kernel family is instantiated in a translation unit of its own (launchers.h), this file holds the RCCL loader,
 // the host side, the C ABI and the small kernels of kernels_phases.h.
 // All stores of the fused kernel are 16-byte aligned; the six planes with cx != 0 are read through
@@ -76,7 +76,7 @@ int fail(int code, const char *fmt, ...)
 #include "kernels_fused.h"
 #include "kernels_step4.h"
 #include "kernels_step5.h"
-#include "kernels_step6.h"
+#include "kernels_deep.h"
 #include "kernels_tile.h"
 #include "kernels_phases.h"
 #ifdef LB_DIAG
@@ -192,6 +192,7 @@ struct lb_sim {
     int diag = 0;
     int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1..4) chosen by lb_autotune
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
+    float depth_cost[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ms per launch of the d-step kernel as lb_autotune timed it (0: not timed): launch_costs
     int64_t bytes = 0;
 
     float *origin(int which) const { return lat[which] + GUARD + GHOST * rowp; }   // plane 0, row 0, x 0
@@ -281,10 +282,10 @@ int effective_variant(const lb_sim *s)
     // 8192^2 327-346 against 306-319 k; pipe 8192^2 346 against 309 k: profiles/r04_experiments.txt section 10), in every family,
     // whole grids and slabs (cycle_depth) alike
     if (cells >= 1280.0 * 1280.0) v |= 4096;
-    // ... and six (k_step6: six waves per CU, one more stage window in the LDS they leave) on the large whole grids: periodic
-    // 8192^2 414 against 320-327 k MLUPS, 4096^2 370 / 315 k, 3072^2 337 / 293 k, 2048^2 281 / 287 k; pipe 8192^2 351-373 / 325 k,
-    // 4096^2 275 / 306 k (profiles/r04_experiments.txt section 14); slabs stay on five (ten ghost rows)
-    if (!s->multi_slab() && cells >= (s->p.bc_mode == LB_BC_PERIODIC ? 2560.0 * 2560.0 : 6000.0 * 6000.0)) v |= 16384;
+    // ... and six / seven (k_deep, round 5: ONE wave per SIMD with the next row's gather in flight; kernels_deep.h) on the large whole
+    // grids -- periodic 8192^2: seven 437 k, six 402 k MLUPS against k_step5's 335 k; 4096^2: 355 / 338 / 314 k
+    // (profiles/r05_experiments.txt).  Round 4's k_step6 (six waves per CU, the size thresholds below) ran at the six-step rate.
+    if (!s->multi_slab() && cells >= (s->p.bc_mode == LB_BC_PERIODIC ? 2560.0 * 2560.0 : 6000.0 * 6000.0)) v |= 16384 | 32768;
     return v;
 }
 
@@ -306,7 +307,7 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
     return LB_OK;
 }
 
-// A marching launch of `depth` time steps per pass (k_step2 ... k_step6), by the translation unit that instantiates that depth.
+// A marching launch of `depth` time steps per pass (k_step2 ... k_step5, k_deep), by the translation unit that instantiates that depth.
 // k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
 // instantiation without an obstacle mask but the D2Q9i fork's); variant bit 10 switches it off (A/B runs).
 void launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs, int row_end,
@@ -320,7 +321,8 @@ void launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items,
     g.stream = st;
     g.strips = strips; g.seg_rows = seg_rows; g.nsegs = nsegs; g.row_end = row_end;
     const int bc = kernel_bc(s);
-    if (depth == 6) lbk_launch_march6(bc, s->has_mask, macro, g, a);
+    if (depth == 7) lbk_launch_deep7(bc, s->has_mask, macro, g, a);
+    else if (depth == 6) lbk_launch_deep6(bc, s->has_mask, macro, g, a);
     else if (depth == 5) lbk_launch_march5(bc, s->has_mask, macro, g, a);
     else if (depth == 4) lbk_launch_march4(bc, s->has_mask, macro, !(effective_variant(s) & 1024), g, a);
     else lbk_launch_march23(depth, bc, s->has_mask, macro, g, a);
@@ -351,8 +353,9 @@ bool step4_applicable(const lb_sim *s)
 
 // five steps per pass (k_step5) on a whole-grid handle (slabs: inside the ten-step halo cycle, cycle_depth)
 bool step5_applicable(const lb_sim *s) { return step4_applicable(s); }
-// six steps per pass (k_step6): whole-grid handles; not the velocity-inlet family (its wall-row bands stop at five)
-bool step6_applicable(const lb_sim *s) { return step4_applicable(s) && s->p.bc_mode != LB_BC_VELOCITY_INLET; }
+// six / seven steps per pass (k_deep): whole-grid handles; not the velocity-inlet family (its wall-row bands stop at five)
+bool deep_applicable(const lb_sim *s) { return step4_applicable(s) && s->p.bc_mode != LB_BC_VELOCITY_INLET; }
+constexpr int MAX_DEPTH = 7;            // deepest fused kernel
 
 // four steps per pass through LDS tiles (k_tile4): whole-grid handles, any width
 bool tile_applicable(const lb_sim *s)
@@ -381,10 +384,7 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     StepArgs a = step_args(s, row_begin, 1, row_end - row_begin);
     const int variant = effective_variant(s);
     // (k_step5: overlapping strips, 248 cells apart)
-    int strips = depth == 6 ? step6_strips(s->p.nx) : (depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
-#ifdef LB_DIAG
-    if (depth == 6 && (s->diag & (1 << 21))) strips = (s->p.nx + STRIP_W - 1) / STRIP_W;    // (timing only: k_step6 on 256-cell strips without skirts)
-#endif
+    const int strips = depth >= 6 ? deep_strips(s->p.nx, depth) : (depth == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     int segs, seg_rows, extra_items = 0;
     if (nsegs_fixed > 0) {
         segs = nsegs_fixed;
@@ -397,7 +397,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         int waves_per_cu = (s->tuned_wpc > 0 && depth == s->tuned_steps) ? s->tuned_wpc : 8;
         static const int wpc_env = getenv("LB_STEP2_WAVES_PER_CU") ? atoi(getenv("LB_STEP2_WAVES_PER_CU")) : 0;   // tuning knob
         if (wpc_env > 0) waves_per_cu = wpc_env;
-        if (depth == 6 && waves_per_cu > 6) waves_per_cu = 6;        // (k_step6: 48 KB of LDS per workgroup, three per CU)
+        if (depth >= 6) waves_per_cu = 4;        // (k_deep: one wave per SIMD -- 512 registers, 36 KB of LDS per wave)
+        if (depth >= 6 && wpc_env > 0) waves_per_cu = wpc_env;
         // (k_step4: an item is a PAIR of segments, marched by the two waves of a workgroup from its middle line: two
         //  wave slots each; `capacity`, `segs`, `seg_rows` then count pairs)
         const int per_item = (depth >= 4) ? STEP4_WAVES : 1;
@@ -420,15 +421,29 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         // (k_step5 has no halo-lane work, so the wall column's rule weighs more in its rows: velocity inlet, 8192^2, edge cost 1.2:
         //  301-305 k MLUPS, 1.6: 306-310 k, 2.0: 322-339 k, 2.5: 329-348 k, 3.0: 321-328 k; 4096^2: 252 / 274 / 290 / 298 / 276 k;
         //  pipe and cavity stay at 1.2: profiles/r04_experiments.txt section 10)
+        // (k_deep, one wave per SIMD: a wall-column strip's rows cost 1.5 x an interior strip's -- per-wave timeline, 8192^2 pipe,
+        //  profiles/r05_wave_timeline_deep.txt; with round 4's 2.2 and the formula below the wall strips finished at half time)
         const double edge_cost = edge_env > 0.0 ? edge_env
                                  : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6)
-                                    // (k_step6, 8192^2, edge cost 1.6 / 2.0 / 2.5 / 3.0: pipe 358 / 376 / 377 / 361 k MLUPS, cavity 391 / 376 / 376 / 360 k)
-                                    : (depth == 6 ? (s->p.bc_mode == LB_BC_CAVITY ? 1.6 : 2.2) : 1.2));
+                                    : (depth >= 6 ? (s->p.bc_mode == LB_BC_CAVITY ? 1.35 : 1.5) : 1.2));
         if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
-            const int segs_i = (int)(capacity / (strips - 2 + 2 * edge_cost));
-            const int segs_e = (capacity - (strips - 2) * segs_i) / 2;
-            const int rows_i = (rows + segs_i - 1) / segs_i, rows_e = (rows + segs_e - 1) / segs_e;
-            if (segs_i >= 1 && segs_e > segs_i && rows_e >= 8 * per_item) {
+            // the split of the wave slots between interior strips (segs_i pairs each) and the two wall-column strips (segs_e each) that
+            // finishes first: min over segs_i of max(rows_i, edge_cost x rows_e).  (Until round 5: segs_i = capacity / (strips - 2 +
+            // 2 edge_cost) rounded down, the remainder to the wall strips -- with few slots per strip the rounding gave them three
+            // times the interior's pairs.)
+            int best_i = 0, best_e = 0;
+            double best_t = 1e30;
+            for (int si = std::max(1, capacity / strips - 2); si <= capacity / strips + 1; ++si) {
+                const int se = (capacity - (strips - 2) * si) / 2;
+                if (se < si) continue;
+                const int ri = (rows + si - 1) / si, re = (rows + se - 1) / se;
+                if (re < 8 * per_item) continue;
+                const double t = std::max((double)ri + (depth - 1), edge_cost * (re + (depth - 1)));
+                if (t < best_t) { best_t = t; best_i = si; best_e = se; }
+            }
+            const int segs_i = best_i, segs_e = best_e;
+            if (segs_i >= 1 && segs_e > segs_i) {
+                const int rows_i = (rows + segs_i - 1) / segs_i, rows_e = (rows + segs_e - 1) / segs_e;
                 seg_rows = rows_i;
                 segs = (rows + rows_i - 1) / rows_i;
                 a.seg_stride = rows_i;
@@ -876,15 +891,13 @@ int slab_step_launch(lb_sim *s, int adv, bool macro)
 
 // How many time steps the next launch of a run with `left` steps to go advances.  `allowed`: bit d set = the d-step kernel may be
 // used (bit 1 always is).  A launch of a marching kernel costs about the same whatever number of steps it fuses (it moves the
-// same bytes): relative costs below, 8192^2 (k_step 0.79 ms, k_step2 0.85, k_step3 0.89, k_step4 0.86, k_step5 0.96, k_step6 1.00).
-// The cheapest way to split `left` into allowed depths, by dynamic programming over the last 64 steps of a run (before that: the
-// deepest kernel); shallow launches first.  20 steps with depths up to 6: 4 + 4 + 6 + 6 (3.72 ms), not 2 + 6 + 6 + 6 (3.85);
-// up to 5: 4 x 5; 60 steps: 10 x 6.
-int next_advance(int allowed, int left)
+// same bytes); `cost[d]` = what a d-step launch costs on this handle, in any one unit (launch_costs).  The cheapest way to split
+// `left` into allowed depths, by dynamic programming over the last 64 steps of a run (before that: the deepest kernel); shallow
+// launches first.  With the seed costs: 20 steps with depths up to 7 = 6 + 7 + 7, up to 6 = 4 + 4 + 6 + 6, up to 5 = 4 x 5.
+int next_advance(int allowed, int left, const float *cost)
 {
-    static const float cost[7] = {0.f, 0.79f, 0.85f, 0.89f, 0.86f, 0.96f, 1.00f};
     int D = 1;
-    for (int d = 2; d <= 6; ++d)
+    for (int d = 2; d <= MAX_DEPTH; ++d)
         if (allowed & (1 << d)) D = d;
     if (left > 64) return D;
     float best[65];
@@ -902,9 +915,29 @@ int next_advance(int allowed, int left)
     }
     return first[left];
 }
-int depth_mask(bool two, bool three, bool four = false, bool five = false, bool six = false)
+// Cost of a d-step launch on this handle, d = 1..MAX_DEPTH: what lb_autotune measured on it (milliseconds per launch, live
+// steps), and for the depths it did not time the seeds -- one MI355X, 8192^2 periodic: k_step 0.79 ms, k_step2 0.85, k_step3 0.89,
+// k_step4 0.86, k_step5 0.96, k_deep<6> 1.00, k_deep<7> 1.08 -- scaled to the measured ones.  (Until round 5 the seeds were the
+// whole table, for every size and family.)
+void launch_costs(const lb_sim *s, float (&cost)[MAX_DEPTH + 1])
 {
-    return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0) | (five ? 32 : 0) | (six ? 64 : 0);
+    static const float seed[MAX_DEPTH + 1] = {0.f, 0.79f, 0.85f, 0.89f, 0.86f, 0.96f, 1.00f, 1.08f};
+    double num = 0., den = 0.;
+    for (int d = 1; d <= MAX_DEPTH; ++d)
+        if (s && s->depth_cost[d] > 0.f) { num += s->depth_cost[d]; den += seed[d]; }
+    const float scale = den > 0. ? (float)(num / den) : 1.f;
+    cost[0] = 0.f;
+    for (int d = 1; d <= MAX_DEPTH; ++d) cost[d] = (s && s->depth_cost[d] > 0.f) ? s->depth_cost[d] : seed[d] * scale;
+}
+int next_advance(const lb_sim *s, int allowed, int left)
+{
+    float cost[MAX_DEPTH + 1];
+    launch_costs(s, cost);
+    return next_advance(allowed, left, cost);
+}
+int depth_mask(bool two, bool three, bool four = false, bool five = false, bool six = false, bool seven = false)
+{
+    return 2 | (two ? 4 : 0) | (three ? 8 : 0) | (four ? 16 : 0) | (five ? 32 : 0) | (six ? 64 : 0) | (seven ? 128 : 0);
 }
 
 // Both compute streams wait for the other one's kernel and for the halo of the lattice just written.
@@ -1012,10 +1045,10 @@ int whole_grid_depths(const lb_sim *s)
     if (s->variant < 0 && s->tuned_steps)
         return depth_mask(step2_applicable(s) && s->tuned_steps >= 2, step3_applicable(s) && s->tuned_steps >= 3,
                           step4_applicable(s) && s->tuned_steps >= 4, step5_applicable(s) && s->tuned_steps >= 5,
-                          step6_applicable(s) && s->tuned_steps >= 6);
+                          deep_applicable(s) && s->tuned_steps >= 6, deep_applicable(s) && s->tuned_steps >= 7);
     const int v = effective_variant(s);
     return depth_mask((v & 32) && step2_applicable(s), (v & 64) && step3_applicable(s), (v & 256) && step4_applicable(s),
-                      (v & 4096) && step5_applicable(s), (v & 16384) && step6_applicable(s));
+                      (v & 4096) && step5_applicable(s), (v & 16384) && deep_applicable(s), (v & 32768) && deep_applicable(s));
 }
 
 // A d-step pass (d = 3, 4, 5) of the velocity-inlet family.  Rows [d, ny-d) depend on nothing the wall rows do within d steps:
@@ -1063,7 +1096,7 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
     }
     const bool store_macro = final_macro && !lazy_macro(s);   // (lazy: rebuilt from the populations when asked for)
     while (left > 0) {
-        const int adv = next_advance(depths, left);
+        const int adv = next_advance(s, depths, left);
         const bool macro = store_macro && (left == adv);
         if (adv == 4 && tile) rc = launch_tile4(s, macro);
         else if (adv >= 3 && s->p.bc_mode == LB_BC_VELOCITY_INLET) rc = vel_band_pass(s, adv, macro);
@@ -1091,11 +1124,11 @@ int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
     // (k_step4 at 8192^2 on one box: 4 waves per CU 189 k MLUPS, 6: 243 k, 8: 232 k, 12: 210 k -- profiles/r02_experiments.txt)
-    const Cand cands[] = {{6, 6}, {5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
+    const Cand cands[] = {{7, 4}, {6, 4}, {5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
     // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1 (the five-step candidates: 2 x 5; compared by time per step);
     // small grids: 36, so that the single-step candidate runs the way it would (hipGraph replay of 16 launches)
     const int per12 = small_grid(s) ? 36 : 12;
-    auto per_of = [&](const Cand &c) { return c.steps == 5 ? 10 : per12; };
+    auto per_of = [&](const Cand &c) { return c.steps == 5 ? 10 : (c.steps == 7 ? 14 : per12); };
     const int keep_steps = s->tuned_steps, keep_wpc = s->tuned_wpc;
     int used = 0, best = -1;
     float best_ms = 0.f;
@@ -1126,7 +1159,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     bool usable[NC];
     for (int c = 0; c < NC; ++c) {
         ms_min[c] = 0.f;
-        usable[c] = !(cands[c].steps == 6 && !step6_applicable(s)) && !(cands[c].steps == 5 && !step5_applicable(s)) &&
+        usable[c] = !(cands[c].steps >= 6 && !deep_applicable(s)) && !(cands[c].steps == 5 && !step5_applicable(s)) &&
                     !(cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) && !(cands[c].wpc < 0 && !tile_applicable(s)) &&
                     !(cands[c].steps == 3 && !step3_applicable(s)) && !(cands[c].steps == 2 && !step2_applicable(s));
     }
@@ -1157,6 +1190,16 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     if (best < 0) return bail(0);                       // nothing applicable
     s->tuned_steps = cands[best].steps;
     s->tuned_wpc = cands[best].wpc;
+    // what a launch of each depth costs on this handle (next_advance splits runs by it): the winner's time for its depth; for the
+    // others the candidate they will be launched as -- eight waves per CU (k_deep: four), the tiles or not as the winner
+    for (int d = 0; d <= MAX_DEPTH; ++d) s->depth_cost[d] = 0.f;
+    for (int c = 0; c < NC; ++c) {
+        if (!usable[c] || small_grid(s)) continue;      // (small grids replay single steps from a graph: the sample is not a launch)
+        const Cand &k = cands[c];
+        const bool as_launched = (c == best) || (k.steps != cands[best].steps &&
+                                                 (k.steps >= 6 || k.steps == 1 || (k.steps == 4 && cands[best].wpc < 0 ? k.wpc < 0 : k.wpc == 8)));
+        if (as_launched) s->depth_cost[k.steps] = ms_min[c] * (float)k.steps;
+    }
     // one more step that stores rho,u,v so that the observable state is consistent again
     int rc = launch_step(s, 0, 1, s->H, true);
     if (rc) return rc;
@@ -1197,7 +1240,7 @@ int corners_patch(lb_sim *s, int which)
 }
 
 // steps a quick (one-round) tuning pass consumes at most: 11 candidates x 2 samples x 12 (36) steps, 2 x 2 x 10, + 1
-int autotune_quick_cost(const lb_sim *s) { return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 1; }
+int autotune_quick_cost(const lb_sim *s) { return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 2 * 14 + 1; }
 
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)
@@ -2084,7 +2127,7 @@ int lb_run(lb_sim *s, int n_steps)
     const bool three = (effective_variant(s) & 64) && step3_applicable(s, hmin);
     const bool stepped = left > 0;
     while (left > 0) {
-        const int adv = next_advance(depth_mask(two, three), left);
+        const int adv = next_advance(s, depth_mask(two, three), left);
         // 1. edge rows (edge stream) and interior rows (compute stream) of the new lattice, concurrently
         if ((rc = slab_step_launch(s, adv, left == adv))) return rc;
         // 2. halo of the lattice just written, behind the edge kernel on its stream (RCCL over xGMI),
@@ -2280,7 +2323,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
         HIP_TRY(hipStreamWaitEvent(sims[i]->edge_stream, sims[i]->ev_halo, 0));
     }
     while (left > 0) {
-        const int adv = next_advance(depth_mask(two, three), left);
+        const int adv = next_advance(sims[0], depth_mask(two, three), left);
         for (int i = 0; i < count; ++i)
             if ((rc = slab_step_launch(sims[i], adv, left == adv))) return rc;
         DBG_SYNC(1);
@@ -2592,7 +2635,7 @@ int lb_plan_launches(lb_sim *s, int n_steps, int *depths, int max_launches)
     const int allowed = whole_grid_depths(s);
     int n = 0;
     for (int left = n_steps; left > 0; ++n) {
-        const int adv = next_advance(allowed, left);
+        const int adv = next_advance(s, allowed, left);
         if (depths && n < max_launches) depths[n] = adv;
         left -= adv;
     }
@@ -2607,7 +2650,7 @@ int lb_steps_per_launch(lb_sim *s)
     if (s->p.semantics == LB_SEM_CYTHON) return cython_march(s) ? 5 : (cython_tiles(s) ? TILE_T : 1);
     if (!s->multi_slab()) {
         const int depths = whole_grid_depths(s);
-        for (int d = 2; d <= 6; ++d)
+        for (int d = 2; d <= MAX_DEPTH; ++d)
             if (depths & (1 << d)) n = d;
     } else {
         const int v = effective_variant(s);
@@ -2655,7 +2698,8 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";
-        else if (spl == 6) kernel = "k_step6 (marching strips, six steps per pass: two stage windows in registers, one split, two in wave-private LDS)";
+        else if (spl == 7) kernel = "k_deep<7> (marching strips, seven steps per pass, one wave per SIMD, stage windows in registers + LDS, gather one row ahead)";
+        else if (spl == 6) kernel = "k_deep<6> (marching strips, six steps per pass, one wave per SIMD, stage windows in registers + LDS, gather one row ahead)";
         else if (spl == 5) kernel = "k_step5 (marching strips, five steps per pass: two stage windows in registers, two in wave-private LDS)";
         else if (spl == 4) kernel = "k_step4 (marching strips, stage windows in registers + wave-private LDS)";
         else if (spl == 3) kernel = "k_step3 (marching strips, register windows)";
@@ -2663,7 +2707,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
         else kernel = "k_step (one fused pull-stream + collide pass)";
     }
     const int n = snprintf(buf, (size_t)buflen, "%s<%s%s>", kernel, bc_names[kernel_bc(s)], s->has_mask ? ", MASK" : "");
-    if (s->tuned_steps && s->tuned_wpc > 0 && strncmp(kernel, "k_step", 6) == 0 && kernel[6] != ' ' && n > 0 && n < buflen)
+    if (s->tuned_steps && s->tuned_wpc > 0 && s->tuned_steps < 6 && strncmp(kernel, "k_step", 6) == 0 && kernel[6] != ' ' && n > 0 && n < buflen)
         snprintf(buf + n, (size_t)(buflen - n), ", tuned: %d waves per CU", s->tuned_wpc);
     return LB_OK;
 }

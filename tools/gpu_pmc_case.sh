@@ -21,7 +21,7 @@ for d in sorted(glob.glob("$OUT/g*/")):
         acc={}
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0]
-            if "k_step" in k or "k_tile" in k or "k1_" in k: acc.setdefault((k,r["Counter_Name"]),[]).append(float(r["Counter_Value"]))
+            if "k_step" in k or "k_deep" in k or "k_tile" in k or "k1_" in k: acc.setdefault((k,r["Counter_Name"]),[]).append(float(r["Counter_Value"]))
         for (k,c),v in sorted(acc.items()):
             if len(v) >= 3: print("$TAG %-44s %-22s n=%3d mean=%.6g"%(k,c,len(v),st.mean(v)))
 PY

@@ -21,16 +21,13 @@ TU = r"""
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "%(root)s/include/lb_hip.h"
-namespace { constexpr int GHOST = 10; constexpr int MASK_GHOST = LB_MASK_HALO_ROWS; constexpr int GUARD = 512; }
 #include "%(csrc)s/d2q9_cell.h"
 #include "%(csrc)s/kernels_fused.h"
 #include "%(csrc)s/kernels_step4.h"
 #include "%(csrc)s/kernels_step5.h"
-#include "%(csrc)s/kernels_step6.h"
 #include "%(csrc)s/kernels_deep.h"
 #include "%(csrc)s/kernels_tile.h"
 #include "%(csrc)s/kernels_phases.h"
-#include "%(csrc)s/kernels_step5c.h"
 void isa_stats_force(hipStream_t st) { void *p = (void *)(&%(kernel)s); hipLaunchKernel(p, dim3(1), dim3(1), nullptr, 0, st); }
 """
 

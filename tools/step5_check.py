@@ -13,9 +13,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from LB_D2Q9.simulation import Simulation  # noqa: E402
 
 W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
-SIX = "--six" in sys.argv                       # k_step6 (variant bit 14) instead of k_step5 (bit 12)
-DEEP = 97 | 256 | 4096 | (16384 if SIX else 0)
-DEEP_SPL = 6 if SIX else 5
+SIX = "--six" in sys.argv                       # k_deep<6> (variant bit 14) instead of k_step5 (bit 12)
+SEVEN = "--seven" in sys.argv                   # k_deep<7> (variant bit 15)
+DEEP = 97 | 256 | 4096 | (16384 if SIX or SEVEN else 0) | (32768 if SEVEN else 0)
+DEEP_SPL = 7 if SEVEN else (6 if SIX else 5)
 
 
 def state(rng, nx, ny, amp=0.02):
@@ -63,7 +64,7 @@ def bitwise():
 def timing(sizes):
     for n in sizes:
         for bc in ("periodic", "pipe"):
-            for name, variant in (("k_step5", 353 | 4096), ("k_step6", 353 | 4096 | 16384), ("k_step5", 353 | 4096), ("k_step6", 353 | 4096 | 16384)):
+            for name, variant in (("k_step5", 353 | 4096), ("k_deep<6>", 353 | 4096 | 16384), ("k_deep<7>", 353 | 4096 | 16384 | 32768), ("k_step5", 353 | 4096), ("k_deep<6>", 353 | 4096 | 16384), ("k_deep<7>", 353 | 4096 | 16384 | 32768)):
                 s = Simulation(n, n, 1.7, bc=bc, inlet_rho=1.003)
                 s.set_variant(variant)
                 spl = s.steps_per_launch()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of one k_step4 launch (diagnostic build, LB_DIAG bit 12): when each wave started and ended, on which
-XCD / CU.  Usage (GPU box): [LB_TIMELINE_BC=pipe] python tools/wave_timeline.py [n] [waves_per_cu]"""
+"""Per-wave timeline of one k_step4 / k_deep launch (diagnostic build, LB_DIAG bit 12): when each wave started and ended, on which
+XCD / CU / SIMD.  Usage (GPU box): [LB_TIMELINE_BC=pipe] [LB_TIMELINE_DEPTH=6|7] python tools/wave_timeline.py [n] [waves_per_cu]"""
 import os
 import sys
 
@@ -22,15 +22,16 @@ def main():
     # (the records travel in the rho array: no launch stores rho, u, v on this handle, and LB_DIAG bit 12 keeps lb_get_macro
     #  from rebuilding them)
     sim = Simulation(n, ny, 1.7, bc=os.environ.get("LB_TIMELINE_BC", "periodic"), inlet_rho=1.0005)
-    sim.set_variant(353)
+    depth = int(os.environ.get("LB_TIMELINE_DEPTH", "4"))
+    sim.set_variant({4: 353, 6: 353 | 4096 | 16384, 7: 353 | 4096 | 16384 | 32768}[depth])
     sim.init_equilibrium(*shear_layer(n, ny, 0, ny))
-    sim.run(8)
-    sim.run(4)                                    # the launch whose timeline is read
+    sim.run(2 * depth)
+    sim.run(depth)                                # the launch whose timeline is read
     raw = sim.get_fields(("rho",))["rho"]
     u = np.ascontiguousarray(raw.T).view(np.uint32).reshape(-1)          # device order: [y][x]
     # device rows are pitch floats long; host rows nx: with nx % 64 == 0 they coincide
-    strips = (n + 255) // 256
-    wpc = int(os.environ.get("LB_STEP2_WAVES_PER_CU", "8"))
+    strips = (n + 255) // 256 if depth == 4 else (n + 239) // 240
+    wpc = int(os.environ.get("LB_STEP2_WAVES_PER_CU", "8" if depth == 4 else "4"))
     cap = 256 * wpc // 2                          # an item = a pair of segments = one workgroup of two waves (up / down)
     segs = max(cap // strips, 1)
     seg_rows = max(-(-ny // segs), 8)
