@@ -38,6 +38,16 @@ constexpr int deep_strips(int nx, int D) { return (nx + deep_valid(D) - 1) / dee
 constexpr int deep_rw(int D) { return 1; }
 constexpr int DEEP_WSLOTS = 8;          // LDS slots of a stage window
 constexpr int deep_pfd(int D) { return 1; }
+// Code footprint (two CUs share a 64 KB instruction cache; a lone wave has nobody to cover its fetch misses; 8192^2, k MLUPS,
+// profiles/r05_footprint.txt): the boundary rule out of line (boundary_rule_call): pipe 306 -> 383-393, cavity 319 -> 393-403; the
+// steady iterations in PAIRS (the two row buffers swap roles, the LDS ring slots become immediate offsets: -1.3 % instructions, twice
+// the loop) pay without an obstacle mask (periodic 435 against 412, cavity 403 / 383) and cost with one (periodic + mask 350 against
+// 368, pipe + mask 4096^2 250 / 263); a code path of their own for the strips without a wall column (no per-lane wall test: -36
+// instructions per row) costs more in footprint than it saves (pipe 337 against 393 with pairs, 388 / 384 without): off.
+constexpr bool deep_pairs(bool mask) { return !mask; }
+#ifndef LB_DEEP_COLS_SPLIT
+#define LB_DEEP_COLS_SPLIT 0
+#endif
 
 template <int RW, int NL>
 struct DeepState {
@@ -76,7 +86,7 @@ __device__ __forceinline__ void deep_publish(f4a (*W)[64], int lane, int gs, con
 }
 
 // Stages S..D of one iteration, S >= 2.  qin = the row stage S - 1 produced in this iteration (position i - (S - 2)).
-template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S>
+template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, bool COLS, int NST, int S>
 __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it,
                                            DeepState<RW, D - 1 - RW> &st, f4a (&qin)[9], f4a &r4, f4a &u4, f4a &v4)
 {
@@ -99,7 +109,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                 skirt_gather<DOWN>(w, qin, t);
                 deep_window_push<DOWN>(W, lane, it, st.d0[L], qin);
             }
-            LB_DEEP_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
+            LB_DEEP_NOCOLLIDE collide_row<BC, MASK, COLS, true>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
             if constexpr (S == D) {
 #ifdef LB_DIAG
                 if (!(a.diag & (1 << 22)))
@@ -122,7 +132,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                     if constexpr (S <= RW) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, S == 1 ? 5 : 2, t);
                     else deep_publish<DOWN>(cx.other + (S - RW - 1) * DEEP_WSLOTS, lane, 2 + 3 * (S & 1), t);
                 }
-                deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
+                deep_stage<BC, MASK, MACRO, D, RW, DOWN, COLS, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
             }
         } else if constexpr (NST == S - 1) {
             // position 0 after step K enters window K (its d slots and the ring row of this parity; the other wave fills the other one)
@@ -136,7 +146,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
 // that have a row: 1..D-1 in iterations 0..D-2 (code of their own, i a constant: the pipeline fills, the two waves of the pair hand
 // over), D in the loop.  PFD = 1: `cur` holds position i on entry and position i + 1 is gathered into `nxt` first; the caller swaps
 // the two from one iteration to the next.  PAR >= 0: the parity of i as a constant (the LDS ring slots become immediate offsets).
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST, int PAR = -1>
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, bool COLS, int NST, int PAR = -1>
 __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, const int i_, DeepState<RW, D - 1 - RW> &st, Row1 &cur,
                                           Row1 &nxt)
 {
@@ -164,31 +174,32 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
     const uc4 mk = cur.mk;
     if (cur.have) {
         gather_merge<BC, true>(a, x4, q1, cur.wp);
-        LB_DEEP_NOCOLLIDE collide_row<BC, MASK>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
+        LB_DEEP_NOCOLLIDE collide_row<BC, MASK, COLS, true>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
     }
     if (NST == 1) {
         if constexpr (RW >= 1) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, 5, q1);      // (mailbox)
         else deep_publish<DOWN>(cx.other, lane, 2 + 3 * 1, q1);
     }
-    deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
+    deep_stage<BC, MASK, MACRO, D, RW, DOWN, COLS, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
     if (MASK) st.mhist = ((st.mhist | mask_word(mk)) << 1) & (0x01010101u * (unsigned)(((1 << D) - 2) & 0xff));
     if (NST < D) __syncthreads();                   // what was published in this iteration is consumed in the next
 }
 
 // the filling iterations 0..D-2, one after the other (NST = 1..D-1); PFD = 1: the two row buffers swap roles every iteration
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST>
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, bool COLS, int NST>
 __device__ __forceinline__ void deep_fill(const StepArgs &a, const DeepCtx &cx, DeepState<RW, D - 1 - RW> &st, Row1 &ra, Row1 &rb)
 {
     if constexpr (NST < D) {
-        if (PFD == 1 && (NST & 1) == 0) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, rb, ra);
-        else deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, ra, PFD ? rb : ra);
-        deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, NST + 1>(a, cx, st, ra, rb);
+        if (PFD == 1 && (NST & 1) == 0) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, NST>(a, cx, NST - 1, st, rb, ra);
+        else deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, NST>(a, cx, NST - 1, st, ra, PFD ? rb : ra);
+        deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, NST + 1>(a, cx, st, ra, rb);
     }
 }
 
 // One wave's march: columns [x0, x0 + 256) of which all but the skirt lanes at either end are stored, `len` rows from the pair's middle line `ym`
 // upward or downward; len + D - 1 iterations.
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN>
+// COLS: some cell of the wave -- skirt lanes included -- may lie in a wall column (collide_row).
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, bool COLS>
 __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, const int ym, const int len, f4a (*mine)[64],
                                            f4a (*other)[64])
 {
@@ -199,7 +210,7 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     // -- walls -- copies of the lane at that end (a wall column's rule rebuilds whatever it pulled from outside)
     constexpr int SKL = deep_skirt_lanes(D);
     if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (xr - a.nx < 4 * SKL ? xr - a.nx : 4 * (SKL - 1)) : xr);
-    else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
+    else cx.x4 = COLS ? min(max(xr, 0), (a.nx - 1) & ~3) : xr;
     cx.store_lane = cx.lane >= SKL && cx.lane <= 63 - SKL && xr < a.nx;
     cx.ym = ym; cx.n_iter = len + D - 1;
     cx.mine = mine; cx.other = other;
@@ -207,18 +218,25 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
     Row1 ra, rb;
     if (PFD) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
-    deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, 1>(a, cx, st, ra, rb);
-    if (PFD == 1) {
+    deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, 1>(a, cx, st, ra, rb);
+    if (PFD == 1 && !deep_pairs(MASK)) {
+        // one iteration per trip; the row gathered ahead moves into place (position D - 1 is in ra or rb by its parity)
+        if ((D - 1) & 1) ra = rb;
+        for (int i = D - 1; i < cx.n_iter; ++i) {
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D>(a, cx, i, st, ra, rb);
+            ra = rb;
+        }
+    } else if (PFD == 1) {
         // position i is in ra for even i, in rb for odd i; the steady iterations in pairs
         constexpr int P0 = (D - 1) & 1;
         int i = D - 1;
         for (; i + 1 < cx.n_iter; i += 2) {
-            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
-            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, 1 - P0>(a, cx, i + 1, st, P0 ? ra : rb, P0 ? rb : ra);
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D, 1 - P0>(a, cx, i + 1, st, P0 ? ra : rb, P0 ? rb : ra);
         }
-        if (i < cx.n_iter) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
+        if (i < cx.n_iter) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
     } else {
-        for (int i = D - 1; i < cx.n_iter; ++i) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D>(a, cx, i, st, ra, ra);
+        for (int i = D - 1; i < cx.n_iter; ++i) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D>(a, cx, i, st, ra, ra);
     }
 }
 
@@ -250,8 +268,16 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const 
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
     const int x0 = sx * deep_valid(D) - 4 * deep_skirt_lanes(D);
-    if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
-    else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+    // a walled box: the strips whose lanes (skirt included) reach a wall column run the code with the per-lane wall test, the others
+    // -- 33 of 35 at nx = 8192 -- the code without it (periodic box: one form)
+    const bool cols = BC != LB_BC_PERIODIC && (x0 <= 0 || x0 + STRIP_W > a.nx - 1);
+    if (LB_DEEP_COLS_SPLIT && BC != LB_BC_PERIODIC && !cols) {
+        if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true, false>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+        else deep_march<BC, MASK, MACRO, D, RW, PFD, false, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+    } else {
+        if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+        else deep_march<BC, MASK, MACRO, D, RW, PFD, false, true>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+    }
 #ifdef LB_DIAG
     if ((a.diag & 4096) && threadIdx.x == 0) {
         // per-wave timeline into the (otherwise unused) rho array: start, end (100 MHz ticks), XCC id, HW id, item, rows (tools/wave_timeline.py)

@@ -57,6 +57,20 @@ __device__ __forceinline__ void boundary_rule(const StepArgs &a, Cell &c, bool w
     if (BC == LB_BC_VELOCITY_INLET && (w || e)) bc_vel_cell(c, w, e, s, n, a.u_w, a.u_e, a.corner);
 }
 
+// The same rule as a FUNCTION (one copy per kernel, called): k_deep's waves run alone on their SIMDs and pay for every byte of
+// their loop in the instruction cache -- inlined at four call sites per stage the rule was ~450 instructions per stage of code that
+// two strips in thirty-five and two rows in eight thousand ever execute (profiles/r05_experiments.txt section 6).  Values in,
+// values out (nine registers each way); p0, p1 = the family's two parameters.
+template <int BC>
+__device__ __noinline__ Cell boundary_rule_call(Cell c, int wesn, float p0, float p1)
+{
+    const bool w = wesn & 1, e = wesn & 2, s = wesn & 4, n = wesn & 8;
+    if (BC == LB_BC_PIPE) bc_pipe_cell(c, w, e, s, n, p0, p1);
+    if (BC == LB_BC_PIPE_I) bc_pipe_i_cell(c, w, e, s, n, p0, p1);
+    if (BC == LB_BC_CAVITY) bc_cavity_cell(c, w, e, s, n, p0, p1);
+    return c;
+}
+
 // Obstacle swap, moments (with the family's overrides), equilibrium and relaxation of the cell at column x (wrapped
 // into the box), local row yl -- the one sequence every fused kernel runs on every cell, vector or scalar.
 template <int BC, bool MASK>
@@ -224,7 +238,11 @@ __device__ __forceinline__ void store_row9(bool nts, float *d, long long S, int 
 }
 
 // Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.
-template <int BC, bool MASK>
+// COLS = false (k_deep, round 5): the caller guarantees that none of the wave's cells lies in a wall column -- an interior strip
+// of a walled box --, so the per-lane test for x = 0 / nx-1 and the rule's code behind it leave the wave's path altogether (a lone
+// wave pays ~5 cycles for every instruction it issues, taken or not: +17 % instructions per row in the pipe kernels otherwise).
+// OOL: the rule is called (boundary_rule_call), not inlined.
+template <int BC, bool MASK, bool COLS = true, bool OOL = false>
 __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
                                             f4a &u4, f4a &v4)
 {
@@ -235,8 +253,8 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     if (BC != LB_BC_PERIODIC) {
         const bool south = (yg == 0), north = (yg == a.ny - 1);
         bool wall_row = (BC != LB_BC_VELOCITY_INLET) && (south || north);   // (that family's wall rows need no rule: their pull is remapped)
-        bool first = (x4 == 0);
-        bool last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
+        bool first = COLS && (x4 == 0);
+        bool last = COLS && (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
         const int jl = (a.nx - 1) & 3;
 #ifdef LB_DIAG
         if (a.diag & 512) wall_row = first = last = false;    // timing only: no boundary rule
@@ -247,7 +265,13 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
                 if (wall_row || (first && j == 0) || (last && j == jl)) {
                     Cell c = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], q[8][j]};
                     const bool w = first && j == 0, e = last && j == jl;
-                    boundary_rule<BC>(a, c, w, e, south, north);
+                    if constexpr (OOL && (BC == LB_BC_PIPE || BC == LB_BC_PIPE_I || BC == LB_BC_CAVITY)) {
+                        const bool cav = (BC == LB_BC_CAVITY);
+                        c = boundary_rule_call<BC>(c, (w ? 1 : 0) | (e ? 2 : 0) | (south ? 4 : 0) | (north ? 8 : 0),
+                                                   cav ? a.lid_u : a.rho_in, cav ? a.rho0 : a.rho_out);
+                    } else {
+                        boundary_rule<BC>(a, c, w, e, south, north);
+                    }
                     q[0][j] = c.f0; q[1][j] = c.f1; q[2][j] = c.f2; q[3][j] = c.f3; q[4][j] = c.f4;
                     q[5][j] = c.f5; q[6][j] = c.f6; q[7][j] = c.f7; q[8][j] = c.f8;
                 }
