@@ -327,6 +327,9 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     }
     // the plain families: the four cells as two pairs (d2q9_cell.h, T = f2a), each in the aligned register pair its 16-byte
     // load put it in; finish_cell's sequence -- obstacle swap, moments, equilibrium, relaxation -- on both cells of a pair at once
+    // (round 5 tried the obstacle swap behind a wave-uniform "some lane holds a solid cell in this row" test -- 94 % of a wave's rows
+    //  are all fluid under the porous-medium image of BASELINE config 5 --: the join of the two paths costs more register moves than the
+    //  32 selects it skips; masked kernels 5-12 % slower, sparse masks included: profiles/r05_experiments.txt section 8)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         f2a f[9];

@@ -283,9 +283,14 @@ int effective_variant(const lb_sim *s)
     // whole grids and slabs (cycle_depth) alike
     if (cells >= 1280.0 * 1280.0) v |= 4096;
     // ... and six / seven (k_deep, round 5: ONE wave per SIMD with the next row's gather in flight; kernels_deep.h) on the large whole
-    // grids -- periodic 8192^2: seven 437 k, six 402 k MLUPS against k_step5's 335 k; 4096^2: 355 / 338 / 314 k
-    // (profiles/r05_experiments.txt).  Round 4's k_step6 (six waves per CU, the size thresholds below) ran at the six-step rate.
-    if (!s->multi_slab() && cells >= (s->p.bc_mode == LB_BC_PERIODIC ? 2560.0 * 2560.0 : 6000.0 * 6000.0)) v |= 16384 | 32768;
+    // grids.  k MLUPS, k_step5 / k_deep<6> / k_deep<7>, one box (profiles/r05_size_sweep.txt): periodic 2048^2 281 / 283 / 279,
+    // 2560^2 282 / 290 / 302, 4096^2 314 / 345 / 358, 8192^2 342 / 411 / 432 (other boxes: 346 / 436 / 459); pipe 3072^2 280 / 252 / 255,
+    // 4096^2 303 / 318 / 323, 6144^2 303 / 370 / 371, 8192^2 333 / 387 / 394; cavity 4096^2 324 / 319 / 322, 6144^2 303 / 368 / 366;
+    // with a (dense, random 1 %) obstacle mask -- 32 selects per row and stage that a lone wave pays in full --: periodic 2560^2
+    // 254 / 244 / 261, 8192^2 338 / 347 / 368; pipe 4096^2 293 / 270 / 280, 6144^2 295 / 298 / 321; cavity 6144^2 321 / 305 / 322.
+    const bool periodic_box = s->p.bc_mode == LB_BC_PERIODIC;
+    const double deep_side = periodic_box ? 2400.0 : (s->has_mask ? 5200.0 : 3800.0);
+    if (!s->multi_slab() && cells >= deep_side * deep_side) v |= 16384 | 32768;
     return v;
 }
 
@@ -421,11 +426,12 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         // (k_step5 has no halo-lane work, so the wall column's rule weighs more in its rows: velocity inlet, 8192^2, edge cost 1.2:
         //  301-305 k MLUPS, 1.6: 306-310 k, 2.0: 322-339 k, 2.5: 329-348 k, 3.0: 321-328 k; 4096^2: 252 / 274 / 290 / 298 / 276 k;
         //  pipe and cavity stay at 1.2: profiles/r04_experiments.txt section 10)
-        // (k_deep, one wave per SIMD: a wall-column strip's rows cost 1.5 x an interior strip's -- per-wave timeline, 8192^2 pipe,
-        //  profiles/r05_wave_timeline_deep.txt; with round 4's 2.2 and the formula below the wall strips finished at half time)
+        // (k_deep, one wave per SIMD, the rule out of line: a wall-column strip's rows cost ~1.8 x an interior strip's -- per-wave
+        //  timelines, profiles/r05_wave_timeline_walls.txt; scan 1.2 ... 3.0, k MLUPS, k_deep<7>: pipe 8192^2 392 (1.2-1.8) / 379
+        //  (2.0-3.0), 4096^2 285 (1.2-1.5) / 322-325 (1.8-2.0) / 319-321 (2.2-3.0), 6144^2 372-377 (1.8-2.2) / 358 (3.0); cavity
+        //  8192^2 395 (<= 1.8) / 370 (>= 2.0), 4096^2 303 / 318-321: profiles/r05_edge_cost_scan.txt)
         const double edge_cost = edge_env > 0.0 ? edge_env
-                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6)
-                                    : (depth >= 6 ? (s->p.bc_mode == LB_BC_CAVITY ? 1.35 : 1.5) : 1.2));
+                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : (depth >= 6 ? 1.8 : 1.2));
         if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
             // the split of the wave slots between interior strips (segs_i pairs each) and the two wall-column strips (segs_e each) that
             // finishes first: min over segs_i of max(rows_i, edge_cost x rows_e).  (Until round 5: segs_i = capacity / (strips - 2 +
