@@ -12,14 +12,14 @@ LB_BC_PIPE, LB_BC_PERIODIC, LB_BC_CAVITY, LB_BC_VELOCITY_INLET = 0, 1, 2, 3
 LB_FLAG_HALO = 1
 LB_FLAG_PLANAR = 2
 LB_FLAG_EAGER_MACRO = 4
-LB_MASK_HALO_ROWS = 9
+LB_MASK_HALO_ROWS = 13
 LB_PEER_HANDLE_BYTES = 384
 LB_DEVICE_CPU = -1
 LB_SEM_OPENCL, LB_SEM_CYTHON, LB_SEM_OPENCL_D2Q9I = 0, 1, 2
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
             "velocity_inlet": LB_BC_VELOCITY_INLET}
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/lb_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (

@@ -630,7 +630,7 @@ __global__ void k_check_spread(const CheckPartial *res, double *d, float *m)
 // buffers into the ghost rows.  `neg` lists rows -D..-1 (leaves north, counted from row H / arrives
 // south, counted from row 0), `pos` rows 0..D-1 (leaves south / arrives north).
 struct HaloTable {
-    signed char k[81], row[81];      // (D = 10: 9 x 10 - 9 row segments)
+    signed char k[117], row[117];    // (D = 14: 9 x 14 - 9 row segments)
     int n;
 };
 

@@ -14,7 +14,7 @@
 // is `pitch` floats (nx rounded up to 64 floats = 256 B); the nine plane-rows of one lattice row are stored together
 // ([row][plane][pitch]: the marching kernels then stream 2 regions per segment instead of 18 -- +12 % at 8192^2,
 // profiles/r02_experiments.txt; LB_FLAG_PLANAR keeps each plane contiguous, [plane][row][pitch]).  Rows -GHOST..-1 and
-// H..H+GHOST-1 are ghost rows (GHOST = 10: slab halo, deep enough for two five-step launches per exchange / don't-care
+// H..H+GHOST-1 are ghost rows (GHOST = 14: slab halo, deep enough for two seven-step launches per exchange / don't-care
 // at walls), so element (k, x, y) of a slab of H rows lives at
 //   lattice + GUARD + (y+GHOST)*rowp + k*plane + x,      rowp = 9*pitch, plane = pitch   (planar: rowp = pitch,
 //                                                         plane = (H+2*GHOST)*pitch);
@@ -45,9 +45,9 @@
 
 namespace {
 
-constexpr int GHOST = 10;  // ghost rows below row 0 and above row H-1 of every plane: a slab runs two five-step
-                           // launches per halo exchange, the first one recomputing 5 of the neighbour's rows
-constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -9)
+constexpr int GHOST = 14;  // ghost rows below row 0 and above row H-1 of every plane: a slab runs two seven-step
+                           // launches per halo exchange, the first one recomputing 7 of the neighbour's rows
+constexpr int MASK_GHOST = LB_MASK_HALO_ROWS;   // mask rows kept of each neighbouring slab (step 1 of row -13)
 constexpr int GUARD = 512; // floats in front of / behind each lattice allocation (the marching kernels' last
                            // strip reads up to 257 cells past a row's end, every kernel 1 cell before its start)
 
@@ -163,7 +163,7 @@ struct lb_sim {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int min_h = 0;              // smallest slab height over the ranks (every rank must pick the same schedule)
-    float *halo_buf = nullptr;  // 4 x HALO_SEGS_DEEP (81) x nx floats: send north, send south, recv south, recv north
+    float *halo_buf = nullptr;  // 4 x HALO_SEGS_DEEP (117) x nx floats: send north, send south, recv south, recv north
     int ghost_depth = 0;        // ghost rows of lat[cur] hold this many of the neighbours' edge rows (0, 3, 6 or 8)
     int variant = -1;           // < 0: automatic (effective_variant)
     hipGraph_t graph = nullptr;            // GRAPH_STEPS single-step launches, captured for small grids
@@ -290,7 +290,7 @@ int effective_variant(const lb_sim *s)
     // 254 / 244 / 261, 8192^2 338 / 347 / 368; pipe 4096^2 293 / 270 / 280, 6144^2 295 / 298 / 321; cavity 6144^2 321 / 305 / 322.
     const bool periodic_box = s->p.bc_mode == LB_BC_PERIODIC;
     const double deep_side = periodic_box ? 2400.0 : (s->has_mask ? 5200.0 : 3800.0);
-    if (!s->multi_slab() && cells >= deep_side * deep_side) v |= 16384 | 32768;
+    if (cells >= deep_side * deep_side) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
     return v;
 }
 
@@ -708,12 +708,13 @@ int lattice_plane_d2h(lb_sim *s, float *host, const float *origin, int k)
 //   D = 6 (45 segments): two three-step launches per exchange (lb_run's six-step cycle);
 //   D = 8 (63 segments): two four-step launches per exchange (eight-step cycle).
 //   D = 10 (81 segments): two five-step launches per exchange (ten-step cycle, k_step5).
+//   D = 12 (99), 14 (117 segments): two six- / seven-step launches per exchange (k_deep).
 // "neg" tables hold rows -D..-1 (what leaves through a north edge, counted from row H; what a south
 // ghost zone receives, counted from row 0), "pos" tables rows 0..D-1 (leaves south / received north).
 // Entry i of an OUT table of one slab pairs with entry i of the IN table of its neighbour.
 struct HaloSeg { int k, row; };
 constexpr int HALO_SEGS = 18;          // D = 3
-constexpr int HALO_SEGS_DEEP = 81;     // D = 10 (63 for D = 8, 45 for D = 6)
+constexpr int HALO_SEGS_DEEP = 117;    // D = 14 (99 for D = 12, 81 for D = 10, 63 for D = 8, 45 for D = 6)
 
 struct HaloTables {
     HaloSeg neg[HALO_SEGS_DEEP], pos[HALO_SEGS_DEEP];
@@ -747,7 +748,7 @@ struct HaloTables {
         return t;
     }
 };
-const HaloTables HALO3(3), HALO6(6), HALO8(8), HALO10(10);
+const HaloTables HALO3(3), HALO6(6), HALO8(8), HALO10(10), HALO12(12), HALO14(14);
 const HaloSeg *const NORTH_OUT = HALO3.neg;   // + H
 const HaloSeg *const SOUTH_IN = HALO3.neg;    // + 0
 const HaloSeg *const SOUTH_OUT = HALO3.pos;   // + 0
@@ -973,11 +974,17 @@ int cycle_depth(const lb_sim *s, int h)
 {
     const int v = effective_variant(s);
     if (!(v & 64) || (v & 128) || !step3_applicable(s, h) || h < 32) return 0;
+    // (k_deep on slabs, round 5: the fourteen- / twelve-step cycle, ghost zone as deep)
+    if ((v & 32768) && (v & 16384) && (v & 4096) && (v & 256) && h >= 112) return 7;
+    if ((v & 16384) && (v & 4096) && (v & 256) && h >= 96) return 6;
     // (k_step5 on slabs: the ten-step cycle, ghost zone ten rows deep)
     if ((v & 4096) && (v & 256) && h >= 80) return 5;
     return ((v & 256) && h >= 64) ? 4 : 3;
 }
-const HaloTables &cycle_halo(int depth) { return depth == 5 ? HALO10 : (depth == 4 ? HALO8 : HALO6); }
+const HaloTables &cycle_halo(int depth)
+{
+    return depth == 7 ? HALO14 : (depth == 6 ? HALO12 : (depth == 5 ? HALO10 : (depth == 4 ? HALO8 : HALO6)));
+}
 
 // bands of output rows [lo_s, hi_s) and [lo_n, hi_n): one wave per strip and band
 int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi_n, bool macro, int depth)
@@ -994,7 +1001,7 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
 // outside the slab to write to).
 int slab_cycle_first(lb_sim *s, int D, bool last = false)
 {
-    const int H = s->H, strips = D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W;
+    const int H = s->H, strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     const StepArgs probe = step_args(s, 0, 1, 1);
     const bool macro = last && !lazy_macro(s);
     int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D, H - D, (probe.ghost_n && !last) ? H + D : H,
@@ -1009,7 +1016,7 @@ int slab_cycle_first(lb_sim *s, int D, bool last = false)
 // E2 + C2 (the caller flips cur afterwards); ev_boundary = the 2D edge rows of the new lattice are complete
 int slab_cycle_second(lb_sim *s, bool macro, int D)
 {
-    const int H = s->H, strips = D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W;
+    const int H = s->H, strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     macro = macro && !lazy_macro(s);
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
     int rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D);
@@ -2240,7 +2247,7 @@ int lb_run_group(lb_sim **sims, int count, int n_steps)
     int hmin = sims[0]->H;
     for (int i = 1; i < count; ++i) hmin = std::min(hmin, sims[i]->H);
     bool two = true, three = true;
-    int D = 5;
+    int D = MAX_DEPTH;
     for (int i = 0; i < count; ++i) {
         two = two && (effective_variant(sims[i]) & 32) && step2_applicable(sims[i], hmin);
         three = three && (effective_variant(sims[i]) & 64) && step3_applicable(sims[i], hmin);

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 7
+#define LB_ABI_VERSION 8
 
 typedef enum {
     LB_OK = 0,
@@ -120,9 +120,10 @@ typedef struct {
  * semantics always store: their fields are not plain moments (imposed inlet speeds, wall overrides, momentum). */
 #define LB_FLAG_EAGER_MACRO 4
 
-/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the ten-step halo cycle
- * recomputes five of the neighbour's rows and reads the mask four rows beyond them. */
-#define LB_MASK_HALO_ROWS 9
+/* Obstacle-mask rows a slab keeps of each neighbour (lb_set_mask_halo): the fourteen-step halo cycle (two
+ * seven-step launches per exchange, ABI 8) recomputes seven of the neighbour's rows and reads the mask six rows
+ * beyond them.  (ABI 7: 9 rows, the ten-step cycle.) */
+#define LB_MASK_HALO_ROWS 13
 
 typedef struct lb_sim lb_sim; /* opaque: device buffers, streams, events, RCCL communicator */
 

@@ -227,19 +227,19 @@ def test_wall_column_strips_with_shorter_segments_bitwise(lbhip, bc, nx, ny, mas
 
 
 def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
-    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, five-step kernel, 10-deep halo)
+    """The 8-GPU decomposition of the bench workload (8 slabs of 1024 rows, k_deep<7>, 14-deep halo)
     executed as in-library virtual slabs on one device: bitwise equal to the undivided run."""
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing, partition_rows
     import bench
-    n, steps = 8192, 23                           # 2 ten-step halo cycles + 3 steps
+    n, steps = 8192, 38                           # 2 fourteen-step halo cycles + a lone seven-step half + 3 steps
     one = Simulation(n, n, 1.7, bc="periodic")
     one.init_equilibrium(*bench.shear_layer(n, n, 0, n))
     one.run(steps)
     want = one.get_fields(("rho", "u", "v"))
     one.close()
     ring = LocalSlabRing(n, n, 1.7, 8, bc="periodic")
-    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 5
+    assert ring.parts == partition_rows(n, 8) and ring.slabs[0].steps_per_launch() == 7
     for s, (y0, h) in zip(ring.slabs, ring.parts):
         s.init_equilibrium(*bench.shear_layer(n, n, y0, h))
     ring.run_in_library(steps)

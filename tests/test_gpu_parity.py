@@ -361,7 +361,7 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
     bit, for step counts that are and are not multiples of six, three and two."""
     from LB_D2Q9.simulation import Simulation
     from LB_D2Q9.slabs import LocalSlabRing
-    nx, ny = 1000, 137
+    nx, ny = 1000, 137 if nslabs == 2 else 345          # (three slabs of 115 rows: the fourteen-step cycle needs >= 112)
     rng = np.random.default_rng(17)
     f0 = _random_state(rng, nx, ny)
     mask = rng.random((nx, ny)) < 0.03
@@ -372,17 +372,20 @@ def test_in_library_slab_schedule_with_two_step_kernel_bitwise(lbhip, bc, nslabs
     one = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, **kw)
     one.set_variant(0)
     one.set_f(f0)
-    # eight-step cycles (slabs of >= 64 rows, else six-step) / six-step cycles / three-step launches without
-    # the cycle / two-step / single-step kernels on slabs
-    for variant in (97 | 256, 97, 97 | 128, 33, 1):
+    # fourteen- / twelve-step cycles of k_deep (slabs of >= 112 / 96 rows; else what fits) / ten-step (k_step5) / eight-step
+    # cycles (slabs of >= 64 rows, else six-step) / six-step cycles / three-step launches without the cycle / two-step /
+    # single-step kernels on slabs
+    first = True
+    for variant in (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1):
         ring = LocalSlabRing(nx, ny, 1.55, nslabs, bc=bc, obstacle_mask=mask, **kw)
         ring.set_variant(variant)
         ring.set_f(f0)
-        ring.run_in_library(20)                   # 3 cycles + 2 steps
-        ring.run_in_library(7)                    # 1 cycle + 1 step
+        ring.run_in_library(20)                   # e.g. 3 six-step cycles + 2 steps; one fourteen-step cycle + a lone... + remainder
+        ring.run_in_library(7)                    # 1 cycle + 1 step / one lone seven-step half
         ring.run_in_library(4)
-        if variant == (97 | 256):
+        if first:
             one.run(31)
+            first = False
         a, b = one.get_fields(("f", "rho", "u", "v")), ring.get_fields(("f", "rho", "u", "v"))
         for k in a:
             assert np.array_equal(a[k], b[k]), (variant, k)
@@ -400,7 +403,7 @@ def test_rccl_self_ring_cycles_with_mask(lbhip):
     one.set_variant(0)
     one.set_f(f0)
     one.run(61 + 29 + 4 + 5 + 16 + 7)
-    for variant in (97 | 256, 97, 97 | 128):      # eight-step cycle, six-step cycle, no cycle
+    for variant in (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256, 97, 97 | 128):      # fourteen-, twelve-, eight-step cycle, six-step cycle, no cycle
         two = Simulation(nx, ny, 1.3, bc="periodic", obstacle_mask=mask, halo=True)
         two.set_variant(variant)
         two.comm_init(comm_unique_id(), 0, 1)
@@ -440,7 +443,7 @@ def test_slab_schedule_inside_lb_run_wall_families_single_rank(lbhip, bc):
     one.set_f(f0)
     one.run(20 + 7 + 4 + 9)
     want = one.get_fields(("f", "rho", "u", "v"))
-    for variant in (97 | 256, 97, 33):
+    for variant in (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256, 97, 33):
         s = Simulation(nx, ny, 1.4, bc=bc, obstacle_mask=mask, halo=True, **kw)
         s.set_variant(variant)
         s.comm_init(comm_unique_id(), 0, 1)

@@ -45,7 +45,7 @@ def test_peer_transport_self_ring_equals_plain_run(lbhip):
     w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
     f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)
     mask = rng.random((nx, ny)) < 0.02
-    for variant in (97 | 256 | 4096, 97 | 256, 97, 33, 1):
+    for variant in (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256 | 4096, 97 | 256, 97, 33, 1):
         one = Simulation(nx, ny, 1.6, bc="periodic", obstacle_mask=mask)
         one.set_variant(0)
         ring = Simulation(nx, ny, 1.6, bc="periodic", obstacle_mask=mask, halo=True)

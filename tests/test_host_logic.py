@@ -142,7 +142,7 @@ def test_partition_rows_and_neighbours():
 
 def test_mask_halo_rows_of_a_slab_match_the_header():
     """The obstacle-mask rows a slab keeps of its neighbours: LB_MASK_HALO_ROWS of them per side (the halo cycle
-    recomputes four of the neighbour's rows and reads the mask three rows beyond), nearest last below / nearest
+    recomputes seven of the neighbour's rows and reads the mask six rows beyond), nearest last below / nearest
     first above, wrapped in a periodic box, absent at a wall, empty outside a walled box."""
     import re
     from LB_D2Q9 import _native
@@ -153,9 +153,9 @@ def test_mask_halo_rows_of_a_slab_match_the_header():
     mask = np.zeros((nx, ny), bool)
     mask[2, :] = np.arange(ny) % 3 == 0                        # row y is solid at x=2 iff y % 3 == 0
     rows = lambda ys: np.array([[(y % ny) % 3 == 0 if x == 2 else False for x in range(nx)] for y in ys])
-    south, north = _SlabSet._mask_halo_rows(mask, 10, 12, ny, False)
+    south, north = _SlabSet._mask_halo_rows(mask, 14, 12, ny, False)
     assert south.shape == north.shape == (d, nx)
-    assert np.array_equal(south, rows(range(10 - d, 10))) and np.array_equal(north, rows(range(22, 22 + d)))
+    assert np.array_equal(south, rows(range(14 - d, 14))) and np.array_equal(north, rows(range(26, 26 + d)))
     south, north = _SlabSet._mask_halo_rows(mask, 0, 12, ny, False)          # bottom slab of a walled box
     assert south is None and np.array_equal(north, rows(range(12, 12 + d)))
     south, north = _SlabSet._mask_halo_rows(mask, 0, 12, ny, True)           # periodic: wraps to the top rows

@@ -5,7 +5,7 @@
 
 Rank r drives GPU r; the slabs exchange halos over RCCL inside lb_run.  Every rank also runs the UNDIVIDED grid
 on its own GPU with the single-step kernel and compares its rows of the slab run with it bit for bit (no gather).
-Cases: the automatic kernel choice (variant -1) on slabs of 2048 x 1024 cells -- the ten-step halo cycle on
+Cases: the automatic kernel choice (variant -1) on slabs of 2048 x 1024 cells -- the deepest halo cycle that fits, on
 k_step5 that bench.py --gpus N runs -- and every explicit schedule (ten-step, eight-step, six-step cycle, three-step
 launches without the cycle, two-step, single-step) on small slabs; three boundary families, with an obstacle mask;
 step counts that are and are not multiples of the cycle.  Prints one line per case and exits non-zero on a mismatch.
@@ -34,7 +34,7 @@ def main():
     bad = 0
     cases = [(2048, 1024 * world, -1, (23, 10, 5))]                      # automatic: ten-step cycle on k_step5
     if not quick:
-        cases += [(1024, 128 * world, v, (20, 7, 4)) for v in (97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1)]
+        cases += [(1024, 128 * world, v, (20, 7, 4)) for v in (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1)]
     for nx, ny, variant, runs in cases:
         rng = np.random.default_rng(3)
         f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)
