@@ -68,7 +68,7 @@ MIN_BLOCKS, MIN_TIMED_S, MAX_BLOCKS = 5, 0.5, 2000
 #   priced the plain launch.
 #   (The default block is 60 steps since the default kernel fuses five steps -- 48 until then, with four: a block should be whole
 #   launches of the deepest kernel, 60 = lcm(1..5); K is on the line.  Not a change of method.)
-METHODOLOGY = "r3-block-avg"
+METHODOLOGY = "r5-block-avg-plan-priced"
 
 
 def shear_layer(nx, ny, y0, h, U=0.04, seed=0):
@@ -145,24 +145,31 @@ def cpu_baseline(budgets=((256, 3.0), (1024, 4.0), (4096, 10.0)), all_cores_budg
     return out
 
 
-def load_pmc_traffic(key, steps_per_launch=1):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this workload
-    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py; key = grid side, or "c<config>/<side>" for the
-    configurations other than the default).  Returns (bytes, source); bytes None with the reason in `source` when no
-    profile of that workload has been committed."""
+def load_pmc_traffic(key, plan):
+    """HBM bytes per launch, averaged over the launches of one timed block, from the committed rocprofv3 --pmc summaries of this
+    workload (profiles/pmc_traffic.json, produced by tools/pmc_summary.py; key = grid side, or "c<config>/<side>" for the
+    configurations other than the default; one entry per fused depth, "<key>/<steps per launch>").  `plan` = the depths of the
+    block's launches (lb_plan_launches): a block of 20 steps is 6 + 7 + 7, i.e. one launch of the six-step and two of the
+    seven-step kernel, each priced with its own counted bytes.  Returns (mean bytes per launch, source, per-depth bytes);
+    bytes None with the reason in `source` when a depth of the plan has no committed profile."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    name = "%s/%d" % (key, steps_per_launch)
     try:
         with open(path) as fh:
             d = json.load(fh)
     except (OSError, ValueError) as exc:
-        return None, "no traffic figure: %s unreadable (%s)" % (path, exc)
-    ent = d.get(name)
-    if not ent:
-        return None, "no traffic figure: profiles/pmc_traffic.json holds no --pmc profile for %r (has: %s)" % (
-            name, ", ".join(sorted(d)))
-    return ent.get("hbm_bytes_per_launch"), "committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
-        "command, read side calibrated on k_copy4), not measured in this run" % ent.get("source", "profiles/pmc_traffic.json")
+        return None, "no traffic figure: %s unreadable (%s)" % (path, exc), None
+    per_depth, srcs = {}, []
+    for depth in sorted(set(plan)):
+        ent = d.get("%s/%d" % (key, depth))
+        if not ent or not ent.get("hbm_bytes_per_launch"):
+            return None, "no traffic figure: profiles/pmc_traffic.json holds no --pmc profile for %r (has: %s)" % (
+                "%s/%d" % (key, depth), ", ".join(sorted(d))), None
+        per_depth[depth] = ent["hbm_bytes_per_launch"]
+        srcs.append(ent.get("source", "profiles/pmc_traffic.json"))
+    mean = sum(per_depth[x] for x in plan) / float(len(plan))
+    return mean, "committed profiles %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side calibrated on k_copy4), the " \
+        "block's launches %s each priced with its own kernel's bytes; not measured in this run" % (
+            ", ".join(sorted(set(srcs))), "+".join(str(x) for x in plan)), per_depth
 
 
 def workload(config, n, omega, local_rank, eager_macro=False):
@@ -238,6 +245,49 @@ def measure_config(config, local_rank, steps, warmup, min_blocks, min_timed_s, s
         sim.close()
 
 
+def reference_case(path, local_rank):
+    """The reference's ONE published benchmark on this engine, on the driver's clock: Pipe_Flow_Cylinder(diameter=1, rho=1,
+    viscosity=1, pressure_grad=-10, pipe_length=3, N=125, cylinder_center=[.75, .5], cylinder_radius=.1) = 3751 x 1251 cells,
+    1000 steps timed by the wall clock around run() and MLUPS = nx ny steps / t / 1e6, exactly as the notebook does
+    (docs/python_cython_opencl_comparison.ipynb:136, 233, 271-273: 317.5 MLUPS on a GTX Titan Black; Cython class :404-406:
+    5.9 MLUPS, 20 steps) -- through the drop-in classes: path = "opencl" (hip_dim: the fused kernels) or "cython"
+    (cython_dim: the reference's CPU semantics on the GPU)."""
+    from LB_D2Q9.dimensionless import cython_dim, hip_dim
+    mod = hip_dim if path == "opencl" else cython_dim
+    sim = mod.Pipe_Flow_Cylinder(diameter=1., rho=1., viscosity=1., pressure_grad=-10., pipe_length=3., N=125,
+                                 cylinder_center=[.75, .5], cylinder_radius=.1, verbose=False)
+    eng = getattr(sim, "_sim", None)
+    try:
+        if eng is not None and hasattr(eng, "autotune"):
+            eng.autotune()
+        steps = 1000
+        sim.run(140)                                 # warm-up (untimed)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sim.run(steps)                           # returns with the work complete, like the reference's run()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        nx, ny = int(sim.nx), int(sim.ny)
+        mlups = nx * ny * steps / best / 1e6
+        spl = eng.steps_per_launch() if eng is not None else None
+        plan = eng.plan_launches(steps) if eng is not None and hasattr(eng, "plan_launches") else None
+        launches = len(plan) if plan else (steps / float(spl) if spl else None)
+        out = {"config": "reference_case", "path": path,
+               "workload": "the reference's published benchmark: Pipe_Flow_Cylinder N=125, %d x %d cells, %d steps, wall clock around "
+                           "run() (docs/python_cython_opencl_comparison.ipynb:136, 233, 271-273), %s-path drop-in class" % (nx, ny, steps, path),
+               "value": round(mlups, 1), "unit": "MLUPS", "seconds": round(best, 4), "steps": steps,
+               "reference_published_MLUPS": 317.52 if path == "opencl" else 5.911,
+               "steps_per_launch": spl, "kernel": eng.hot_kernel() if eng is not None else None}
+        if launches:
+            out["launch_ms"] = round(best * 1e3 / launches, 6)
+            out["roofline_frac"] = round((B_ALG + 1.0) * nx * ny / (best / launches) / 1e9 / HBM_PEAK_GBS, 4)
+        return out
+    finally:
+        if eng is not None:
+            eng.close()
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start one rank process per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* as torch.distributed.run would set them), wait, forward rank 0's line.  This parent
@@ -294,8 +344,8 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=84)            # (84 = whole launches of every depth up to seven)
+    ap.add_argument("--warmup", type=int, default=14)
     ap.add_argument("--config", type=int, default=4, choices=[2, 3, 4, 5],
                     help="BASELINE.json configuration, 1-based: 4 (default) = 8192^2 periodic shear layer, the one the metric "
                          "is quoted on; 2 = 1024^2 lid-driven cavity Re=1000; 3 = 4096^2 Kelvin-Helmholtz; 5 = 4096^2 pipe "
@@ -486,8 +536,8 @@ def main():
         bytes_per_launch = bytes_per_cell * n * h
         achieved = bytes_per_launch / launch_s / 1e9
         effective = B_ALG * n * h * args.steps / (ev_ms / 1e3) / 1e9
-        traffic, traffic_source = load_pmc_traffic(n if args.config == 4 else "c%d/%d" % (args.config, n), spl) \
-            if dist is None else (None, "no traffic figure: counters are collected on one GPU")
+        traffic, traffic_source, traffic_by_depth = load_pmc_traffic(n if args.config == 4 else "c%d/%d" % (args.config, n), plan or [spl]) \
+            if dist is None else (None, "no traffic figure: counters are collected on one GPU", None)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_plain_launch": None if plain_ms is None or python_driven else round(bytes_per_launch / (plain_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -495,9 +545,11 @@ def main():
                 "plain_launch_source": "difference of runs of 2q and q launches / q, outside the timed region (a launch in the "
                                        "middle of a long run; first/last-launch extras of a run: %+.4f ms)" % (macro_extra_ms or 0.0),
                 "frac_of_measured_copy": round(achieved / COPY_CEILING_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic": traffic, "traffic_source": traffic_source, "traffic_by_steps_per_launch": traffic_by_depth,
                 "traffic_frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                "kernel": "%s, %d x %d cells x %d step(s) per launch" % (kname, n, h, spl),
+                "kernel": "%s, %d x %d cells x %d step(s) per launch%s" % (
+                    kname, n, h, spl, "" if not plan or set(plan) == {spl} else "; the block's launches: %s steps (the shallower ones: the "
+                    "same march with fewer stages)" % "+".join(str(d) for d in plan)),
                 "launch_ms": round(launch_s * 1e3, 4), "launch_ms_source": launch_source, "steps_per_launch": spl,
                 "block_plan": plan,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -507,9 +559,18 @@ def main():
                 "note": "achieved = %g B x cells of one launch (compulsory: each plane read once, written once%s) / "
                         "launch time; effective_GBps = 72 B x lattice updates / time is NOT an HBM rate when "
                         "steps_per_launch > 1 (effective_x_roofline = value against the single-pass roofline 8 TB/s / 72 B per "
-                        "update); frac prices ONE launch, whatever number of time steps it fuses: five since round 4 (k_step5), "
-                        "four before (k_step4: launch 0.85 ms, frac 0.71, 314 k MLUPS)"
+                        "update); frac prices ONE launch, whatever number of time steps it fuses: seven since round 5 (k_deep<7>: the launch "
+                        "is bound by instruction issue, not by HBM -- `compute`), six / five in round 4, four before (k_step4: launch "
+                        "0.85 ms, frac 0.71, 314 k MLUPS)"
                         % (bytes_per_cell, "" if bytes_per_cell == B_ALG else ", + 1 B obstacle mask")}
+        # what the kernel is actually bound by since round 5: vector-ALU issue (profiles/r05_experiments.txt).  68 fp32 operations per
+        # cell update as written (d2q9_cell.h: 23 of them FMAs) = 91 flop; the packed pipe's peak is the guide's fp32 vector figure.
+        flop_per_update, fp32_peak = 91.0, 157.3e12
+        compute = {"bound": "valu", "achieved": round(mlups * 1e6 * flop_per_update / 1e12, 2), "peak": fp32_peak / 1e12, "unit": "TFLOP/s",
+                   "frac": round(mlups * 1e6 * flop_per_update / fp32_peak, 4),
+                   "note": "informational: %g flop per lattice update (68 fp32 operations, 23 of them FMAs, all issued as v_pk_*_f32) "
+                           "against the fp32 vector peak; the collision is %d of the %d instructions a wave issues per row"
+                           % (flop_per_update, 951, 1473)}
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",
@@ -529,6 +590,7 @@ def main():
                        "baseline_config": args.config, "grid": [n, n], "bytes_per_lattice_update": B_ALG},
             "health": health,
             "roofline": roof,
+            "compute": compute,
         }
         line["methodology"] = METHODOLOGY
         if copy_gbs is not None:
@@ -541,9 +603,14 @@ def main():
             line["other_configs"] = []
             for c in (2, 3, 5):
                 try:
-                    line["other_configs"].append(measure_config(c, local_rank, 60, 12, args.min_blocks, args.min_timed_s))    # (60 = whole launches of every depth)
+                    line["other_configs"].append(measure_config(c, local_rank, 84, 14, args.min_blocks, args.min_timed_s))    # (84 = whole launches of every depth)
                 except (Exception, SystemExit) as exc:             # noqa: BLE001 - a side line must not take the headline down
                     line["other_configs"].append({"config": c, "error": str(exc)})
+            for path in ("opencl", "cython"):
+                try:
+                    line["other_configs"].append(reference_case(path, local_rank))
+                except (Exception, SystemExit) as exc:             # noqa: BLE001
+                    line["other_configs"].append({"config": "reference_case", "path": path, "error": str(exc)})
         if world == 1 and not args.no_cpu_baseline and args.config == 4:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=result_out, flush=True)

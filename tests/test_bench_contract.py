@@ -36,10 +36,10 @@ def test_cpu_baseline_leg_reports_the_contract_keys():
 
 def test_pmc_traffic_lookup_says_why_when_there_is_no_profile():
     import bench
-    b, src = bench.load_pmc_traffic(8192, 4)
-    assert b and "committed profile" in src
-    b, src = bench.load_pmc_traffic("c9/123", 4)
-    assert b is None and "no --pmc profile" in src and "8192/4" in src
+    b, src, per = bench.load_pmc_traffic(8192, [4, 4, 6, 6])
+    assert b and "committed profile" in src and sorted(per) == [4, 6] and b == pytest.approx((per[4] + per[6]) / 2.0)
+    b, src, per = bench.load_pmc_traffic("c9/123", [4])
+    assert b is None and per is None and "no --pmc profile" in src and "8192/4" in src
 
 
 def test_bench_refuses_to_run_without_a_gpu(lbhip):
@@ -112,7 +112,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert r["bound"] == "hbm" and r["peak"] == 8000.0
         assert r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-3)
         assert "workload" in d["config"] and d["vs_baseline"] is None
-        assert r["steps_per_launch"] in (1, 2, 3, 4, 5, 6)
+        assert r["steps_per_launch"] in (1, 2, 3, 4, 5, 6, 7)
         if rnd >= 2:
             # a fraction of the HBM roofline is a fraction: the bytes a launch must move (72 B x cells, whatever
             # the number of fused time steps) over its duration; the 72 B x UPDATES figure lives under another name
@@ -130,9 +130,20 @@ def test_committed_bench_line_has_the_contract_fields():
             assert t["min_ms_per_step"] <= d["ms_per_step"] <= t["max_ms_per_step"]
         if rnd >= 4:
             # the other single-GPU configurations of BASELINE.json ride behind the headline, on the same clock
-            assert d["methodology"] == "r3-block-avg"
-            oc = {o["config"]: o for o in d["other_configs"]}
+            assert d["methodology"] == ("r3-block-avg" if rnd == 4 else "r5-block-avg-plan-priced")
+            oc = {o["config"]: o for o in d["other_configs"] if o["config"] != "reference_case"}
             assert sorted(oc) == [2, 3, 5]
+            if rnd >= 5:
+                # the reference's one published benchmark (3751 x 1251 Pipe_Flow_Cylinder, 1000 steps), both drop-in classes
+                rc = {o["path"]: o for o in d["other_configs"] if o["config"] == "reference_case"}
+                assert sorted(rc) == ["cython", "opencl"]
+                for o in rc.values():
+                    for k in ("workload", "value", "unit", "seconds", "steps", "kernel", "steps_per_launch", "roofline_frac", "reference_published_MLUPS"):
+                        assert k in o, (path, k)
+                    assert o["steps"] == 1000 and "3751 x 1251" in o["workload"] and o["value"] > 10 * o["reference_published_MLUPS"]
+                    assert o["value"] == pytest.approx(3751 * 1251 * 1000 / o["seconds"] / 1e6, rel=2e-3)
+                c = d["compute"]
+                assert c["bound"] == "valu" and c["frac"] == pytest.approx(d["value"] * 1e6 * 91.0 / 157.3e12, abs=2e-3)
             for c, o in oc.items():
                 for k in ("workload", "value", "unit", "ms_per_step", "launch_ms", "roofline_frac", "kernel", "steps_per_launch", "health"):
                     assert k in o, (path, c, k)

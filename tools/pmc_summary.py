@@ -81,7 +81,7 @@ def main():
     try:
         import re
         log = open(os.path.join(src, "kt.log")).read()
-        m_l, m_v, m_k = re.search(r'"launch_ms": ([0-9.]+)', log), re.search(r'"value": ([0-9.]+)', log), re.search(r'"kernel": "(k_[a-z]+\d?)', log)
+        m_l, m_v, m_k = re.search(r'"launch_ms": ([0-9.]+)', log), re.search(r'"value": ([0-9.]+)', log), re.search(r'"kernel": "(k_[a-z]+\d?(?:<\d>)?)', log)
         if m_l and m_v:
             lines += ["", "bench.py inside this run (HIP events over the timed region): %s MLUPS, launch_ms %s of %s."
                       % (m_v.group(1), m_l.group(1), m_k.group(1) if m_k else "the hot kernel")]
@@ -89,7 +89,7 @@ def main():
         pass
 
     # calibration on the copy kernel (bytes known: lattice allocation read once, written once)
-    copy_bytes = (9 * (side + 20) * ((side + 63) // 64 * 64) + 1024) * 4      # 10 ghost rows per side, 2 x 512 guard floats
+    copy_bytes = (9 * (side + 28) * ((side + 63) // 64 * 64) + 1024) * 4      # 14 ghost rows per side (round 5; 10 before), 2 x 512 guard floats
     copy_fetch = st.mean(pmc[("k_copy4<false>", "FETCH_SIZE")]) * 1024
     copy_write = st.mean(pmc[("k_copy4<false>", "WRITE_SIZE")]) * 1024
     fetch_corr = copy_bytes / copy_fetch
@@ -102,14 +102,15 @@ def main():
               "|---|---|---|---|---|---|---|---|"]
     out = {}
     for k in sorted(dur):
-        if (k, "FETCH_SIZE") not in pmc or not (k.startswith("k_step") or k.startswith("k_tile4")):
+        if (k, "FETCH_SIZE") not in pmc or not (k.startswith("k_step") or k.startswith("k_deep") or k.startswith("k_tile4")):
             continue
         f = st.mean(pmc[(k, "FETCH_SIZE")])
         w = st.mean(pmc[(k, "WRITE_SIZE")])
         rd, wr = f * 1024 * fetch_corr, w * 1024 * write_corr
         macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS> / k_tile4<BC, MASK, MACRO, ...>
         masked = k.split(",")[1].strip() == "true"
-        spl = 4 if k.startswith("k_tile4") else (int(k[6]) if k[6:7].isdigit() else 1)        # time steps per launch
+        # time steps per launch: k_tile4: 4; k_deep<BC, MASK, MACRO, D, RW, PFD>: D; k_stepN: N
+        spl = 4 if k.startswith("k_tile4") else (int(k.split(",")[3]) if k.startswith("k_deep") else (int(k[6]) if k[6:7].isdigit() else 1))
         alg = (73.0 if masked else 72.0) * side * side + (12.0 * side * side if macro else 0.0)      # compulsory bytes of one launch, whatever spl
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
         key = ("%d/%d" % (side, spl)) if config == 4 else ("c%d/%d/%d" % (config, side, spl))
