@@ -69,6 +69,11 @@ __device__ __forceinline__ void deep_window_load(f4a (*W)[64], int lane, int it,
     w.d0 = d0; w.d1 = W[0][lane]; w.d3 = W[1][lane];
     w.g2 = W[gs][lane]; w.g5 = W[gs + 1][lane]; w.g6 = W[gs + 2][lane];
 }
+// (Round 5 also read the window rows SHIFTED -- a slot is a row of 256 cells, the cell to the left of each of a lane's cells is the
+//  same row read 4 bytes lower: gfx950 serves a ds_read_b128 at any dword address, tools/lds_unaligned_probe.hip -- through asm, one
+//  stage ahead behind scheduling barriers: 100 instructions per row fewer (three moves and a DPP per shifted link) and 5 % SLOWER,
+//  k_deep<7> 8192^2 407 against 430 k MLUPS on one box: the unaligned reads cost more LDS passes than the moves cost issue slots.
+//  profiles/r05_shifted_reads_ab.txt; not kept.)
 template <bool DOWN>
 __device__ __forceinline__ void deep_window_push(f4a (*W)[64], int lane, int it, f4a &d0, const f4a (&q)[9])
 {
