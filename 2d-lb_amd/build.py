@@ -94,6 +94,12 @@ if __name__ == "__main__":
     kw = dict(force="--force" in sys.argv, verbose="-v" in sys.argv)
     if "--variant" in sys.argv:          # --variant <tag> <flag> [<flag> ...]
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], [f for f in sys.argv[i + 2:] if f.startswith("-D")], **kw))
+        extra = []
+        for f in sys.argv[i + 2:]:
+            if f.startswith("-D"):
+                extra.append(f)
+            elif f.startswith("-mllvm="):                # -mllvm=<option>  ->  -mllvm <option>
+                extra += ["-mllvm", f[len("-mllvm="):]]
+        print(build_variant(sys.argv[i + 1], extra, **kw))
     else:
         print(build_diag(**kw) if "--diag" in sys.argv else build(**kw))
