@@ -229,8 +229,8 @@ int lb_run_batch(lb_sim **sims, int count, int n_steps);
  * lb_comm_init is collective (every rank of the communicator calls it: the ranks agree on the smallest
  * slab height there, which decides the kernels and the exchange rhythm).  lb_check(across_ranks = 1) is the only
  * other collective (two all-reduces of three scalars, outside the data path).  Afterwards lb_run on a slab
- * handle exchanges halos itself: two five-step (slabs of >= 80 rows), four-step (>= 64 rows)
- * or three-step (>= 32 rows) launches per exchange with ghost zones ten / eight / six rows deep when nx >= 512,
+ * handle exchanges halos itself: two seven- / six-step (large slabs of >= 112 / 96 rows), five-step (>= 80 rows), four-step
+ * (>= 64 rows) or three-step (>= 32 rows) launches per exchange with ghost zones 14 / 12 / 10 / 8 / 6 rows deep when nx >= 512,
  * otherwise one exchange of the 3-deep halo per launch. */
 int lb_comm_available(void);               /* 0 when librccl can be loaded in this process (no communicator is made) */
 int lb_comm_unique_id(void *unique_id_128);
@@ -281,10 +281,10 @@ int lb_timer_start(lb_sim *s);
 int lb_timer_stop(lb_sim *s, float *elapsed_ms);
 /* Device layout facts for DESIGN.md / bench.py: pitch = padded row width (floats) = row pitch of rho, u, v and (bytes) of
  * the mask; plane stride (floats) of the lattices: = pitch with interleaved rows (element (k, y, x) at
- * (y * 9 + k) * pitch + x), = (local_ny + 16) * pitch with LB_FLAG_PLANAR; bytes allocated. */
+ * (y * 9 + k) * pitch + x), = (local_ny + 28) * pitch with LB_FLAG_PLANAR; bytes allocated. */
 int lb_layout(lb_sim *s, int64_t *pitch, int64_t *plane_stride, int64_t *bytes_allocated);
 /* Time steps advanced by one launch of the hot kernel in lb_run with the current variant / tuning:
- * 4, 3 or 2 when a four- / three- / two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch
+ * 7 ... 2 when a seven- ... two-steps-per-pass kernel is in use, else 1 (bench.py prices a launch
  * with it). */
 int lb_steps_per_launch(lb_sim *s);
 /* How lb_run(n_steps) on a whole-grid OpenCL-path GPU handle splits the run into launches with the current variant / tuning:
@@ -292,7 +292,7 @@ int lb_steps_per_launch(lb_sim *s);
  * count only).  Every launch of a marching kernel moves the same bytes, so bench.py prices a block of K steps by its launches.
  * LB_ERR_STATE (no message) on slab, Cython-path and CPU handles. */
 int lb_plan_launches(lb_sim *s, int n_steps, int *depths, int max_launches);
-/* Name of that kernel, e.g. "k_step4 (...)<PERIODIC>", written into buf (NUL-terminated, truncated to buflen). */
+/* Name of that kernel, e.g. "k_deep<7> (...)<PERIODIC>", written into buf (NUL-terminated, truncated to buflen). */
 int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 /* Pick the fastest configuration of the fused kernels for THIS grid by timing each candidate on a few
  * live time steps (all candidates give bitwise identical results, so this simply advances the
@@ -301,7 +301,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 int lb_autotune(lb_sim *s);
 /* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
  * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
- * variant automatic and the pass (241 steps; 721 on grids <= 768^2) fits into max_steps; returns the number
+ * variant automatic and the pass (333 steps; 861 on grids <= 768^2) fits into max_steps; returns the number
  * of steps advanced, 0 when it did nothing. */
 int lb_autotune_quick(lb_sim *s, int max_steps);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
@@ -318,8 +318,9 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * k_step4 without its one-row-ahead gather, bit 11 k_step4 / k_step5 without the priority turns of the two waves of a SIMD,
  * bit 12 five time steps per pass on overlapping strips (k_step5: whole-grid handles where bit 8 applies and slabs of >= 80
  * rows -- the ten-step halo cycle; what the automatic choice takes from 1200^2 periodic / 1850^2 walled cells of a whole
- * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 14 six time steps per pass (k_step6: whole-grid handles,
- * not the velocity-inlet family; automatic from 2560^2 periodic / 6000^2 walled cells), bit 13
+ * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 14 six and bit 15 (with bit 14) seven time steps per pass
+ * (k_deep, one wave per SIMD: whole-grid handles and slabs of >= 96 / 112 rows -- the twelve- / fourteen-step halo cycle --, not
+ * the velocity-inlet family; automatic from 2400^2 periodic / 3800^2 walled / 5200^2 walled + obstacle-mask cells), bit 13
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);
