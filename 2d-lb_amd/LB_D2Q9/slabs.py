@@ -3,8 +3,9 @@
 The grid is cut along y (the slow axis of the device layout) into contiguous row slabs, one per
 GPU / process.  Streaming reaches one cell, so per step each slab needs from its neighbours only
 the populations that cross the shared edge (k=2,5,6 travel north, k=4,7,8 travel south).  The engine
-keeps the ghost zone ten rows deep: inside ``lb_run`` the five-step kernel runs twice per exchange
-(81 row segments of nx floats per direction; the velocity-inlet family and explicit variants: four-step, eight rows, 63); the halo this module moves itself (lb_halo_export /
+keeps the ghost zone fourteen rows deep: inside ``lb_run`` the seven-step kernel (k_deep) runs twice per exchange on large
+slabs (117 row segments of nx floats per direction; smaller slabs and explicit variants: six- / five- / four- / three-step kernels,
+12 / 10 / 8 / 6 rows, 99 / 81 / 63 / 45 segments); the halo this module moves itself (lb_halo_export /
 import) is the 3-deep one (18 row segments, include/lb_hip.h).  There is no collective on the data path.
 
 * ``partition_rows`` / ``neighbours``  - the arithmetic.

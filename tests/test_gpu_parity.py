@@ -787,7 +787,7 @@ def test_planar_layout_equals_interleaved_rows(lbhip, family):
     for planar in (False, True):
         s = Simulation(nx, ny, 1.3, planar=planar, **kw)
         assert s.layout()["planar"] == planar
-        assert s.layout()["plane_stride"] == (s.layout()["pitch"] * (ny + 20) if planar else s.layout()["pitch"])
+        assert s.layout()["plane_stride"] == (s.layout()["pitch"] * (ny + 28) if planar else s.layout()["pitch"])      # (14 ghost rows per side)
         s.set_f(f0)
         assert np.array_equal(s.get_fields(("f",))["f"], f0)
         if family == "periodic_halo":
