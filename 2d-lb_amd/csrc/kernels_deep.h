@@ -45,9 +45,6 @@ constexpr int deep_pfd(int D) { return 1; }
 // 368, pipe + mask 4096^2 250 / 263); a code path of their own for the strips without a wall column (no per-lane wall test: -36
 // instructions per row) costs more in footprint than it saves (pipe 337 against 393 with pairs, 388 / 384 without): off.
 constexpr bool deep_pairs(bool mask) { return !mask; }
-#ifndef LB_DEEP_COLS_SPLIT
-#define LB_DEEP_COLS_SPLIT 0
-#endif
 
 template <int RW, int NL>
 struct DeepState {
@@ -91,7 +88,7 @@ __device__ __forceinline__ void deep_publish(f4a (*W)[64], int lane, int gs, con
 }
 
 // Stages S..D of one iteration, S >= 2.  qin = the row stage S - 1 produced in this iteration (position i - (S - 2)).
-template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, bool COLS, int NST, int S>
+template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S>
 __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it,
                                            DeepState<RW, D - 1 - RW> &st, f4a (&qin)[9], f4a &r4, f4a &u4, f4a &v4)
 {
@@ -114,7 +111,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                 skirt_gather<DOWN>(w, qin, t);
                 deep_window_push<DOWN>(W, lane, it, st.d0[L], qin);
             }
-            LB_DEEP_NOCOLLIDE collide_row<BC, MASK, COLS, true>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
+            LB_DEEP_NOCOLLIDE collide_row<BC, MASK, true>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
             if constexpr (S == D) {
 #ifdef LB_DIAG
                 if (!(a.diag & (1 << 22)))
@@ -137,7 +134,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                     if constexpr (S <= RW) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, S == 1 ? 5 : 2, t);
                     else deep_publish<DOWN>(cx.other + (S - RW - 1) * DEEP_WSLOTS, lane, 2 + 3 * (S & 1), t);
                 }
-                deep_stage<BC, MASK, MACRO, D, RW, DOWN, COLS, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
+                deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
             }
         } else if constexpr (NST == S - 1) {
             // position 0 after step K enters window K (its d slots and the ring row of this parity; the other wave fills the other one)
@@ -151,7 +148,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
 // that have a row: 1..D-1 in iterations 0..D-2 (code of their own, i a constant: the pipeline fills, the two waves of the pair hand
 // over), D in the loop.  PFD = 1: `cur` holds position i on entry and position i + 1 is gathered into `nxt` first; the caller swaps
 // the two from one iteration to the next.  PAR >= 0: the parity of i as a constant (the LDS ring slots become immediate offsets).
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, bool COLS, int NST, int PAR = -1>
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST, int PAR = -1>
 __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, const int i_, DeepState<RW, D - 1 - RW> &st, Row1 &cur,
                                           Row1 &nxt)
 {
@@ -179,32 +176,31 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
     const uc4 mk = cur.mk;
     if (cur.have) {
         gather_merge<BC, true>(a, x4, q1, cur.wp);
-        LB_DEEP_NOCOLLIDE collide_row<BC, MASK, COLS, true>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
+        LB_DEEP_NOCOLLIDE collide_row<BC, MASK, true>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
     }
     if (NST == 1) {
         if constexpr (RW >= 1) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, 5, q1);      // (mailbox)
         else deep_publish<DOWN>(cx.other, lane, 2 + 3 * 1, q1);
     }
-    deep_stage<BC, MASK, MACRO, D, RW, DOWN, COLS, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
+    deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
     if (MASK) st.mhist = ((st.mhist | mask_word(mk)) << 1) & (0x01010101u * (unsigned)(((1 << D) - 2) & 0xff));
     if (NST < D) __syncthreads();                   // what was published in this iteration is consumed in the next
 }
 
 // the filling iterations 0..D-2, one after the other (NST = 1..D-1); PFD = 1: the two row buffers swap roles every iteration
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, bool COLS, int NST>
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST>
 __device__ __forceinline__ void deep_fill(const StepArgs &a, const DeepCtx &cx, DeepState<RW, D - 1 - RW> &st, Row1 &ra, Row1 &rb)
 {
     if constexpr (NST < D) {
-        if (PFD == 1 && (NST & 1) == 0) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, NST>(a, cx, NST - 1, st, rb, ra);
-        else deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, NST>(a, cx, NST - 1, st, ra, PFD ? rb : ra);
-        deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, NST + 1>(a, cx, st, ra, rb);
+        if (PFD == 1 && (NST & 1) == 0) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, rb, ra);
+        else deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, NST>(a, cx, NST - 1, st, ra, PFD ? rb : ra);
+        deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, NST + 1>(a, cx, st, ra, rb);
     }
 }
 
 // One wave's march: columns [x0, x0 + 256) of which all but the skirt lanes at either end are stored, `len` rows from the pair's middle line `ym`
 // upward or downward; len + D - 1 iterations.
-// COLS: some cell of the wave -- skirt lanes included -- may lie in a wall column (collide_row).
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, bool COLS>
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN>
 __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, const int ym, const int len, f4a (*mine)[64],
                                            f4a (*other)[64])
 {
@@ -215,7 +211,7 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     // -- walls -- copies of the lane at that end (a wall column's rule rebuilds whatever it pulled from outside)
     constexpr int SKL = deep_skirt_lanes(D);
     if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (xr - a.nx < 4 * SKL ? xr - a.nx : 4 * (SKL - 1)) : xr);
-    else cx.x4 = COLS ? min(max(xr, 0), (a.nx - 1) & ~3) : xr;
+    else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
     cx.store_lane = cx.lane >= SKL && cx.lane <= 63 - SKL && xr < a.nx;
     cx.ym = ym; cx.n_iter = len + D - 1;
     cx.mine = mine; cx.other = other;
@@ -223,12 +219,12 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
     Row1 ra, rb;
     if (PFD) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
-    deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, 1>(a, cx, st, ra, rb);
+    deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, 1>(a, cx, st, ra, rb);
     if (PFD == 1 && !deep_pairs(MASK)) {
         // one iteration per trip; the row gathered ahead moves into place (position D - 1 is in ra or rb by its parity)
         if ((D - 1) & 1) ra = rb;
         for (int i = D - 1; i < cx.n_iter; ++i) {
-            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D>(a, cx, i, st, ra, rb);
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D>(a, cx, i, st, ra, rb);
             ra = rb;
         }
     } else if (PFD == 1) {
@@ -236,12 +232,12 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
         constexpr int P0 = (D - 1) & 1;
         int i = D - 1;
         for (; i + 1 < cx.n_iter; i += 2) {
-            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
-            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D, 1 - P0>(a, cx, i + 1, st, P0 ? ra : rb, P0 ? rb : ra);
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
+            deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, 1 - P0>(a, cx, i + 1, st, P0 ? ra : rb, P0 ? rb : ra);
         }
-        if (i < cx.n_iter) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
+        if (i < cx.n_iter) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D, P0>(a, cx, i, st, P0 ? rb : ra, P0 ? ra : rb);
     } else {
-        for (int i = D - 1; i < cx.n_iter; ++i) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, COLS, D>(a, cx, i, st, ra, ra);
+        for (int i = D - 1; i < cx.n_iter; ++i) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D>(a, cx, i, st, ra, ra);
     }
 }
 
@@ -273,16 +269,8 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const 
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
     const int x0 = sx * deep_valid(D) - 4 * deep_skirt_lanes(D);
-    // a walled box: the strips whose lanes (skirt included) reach a wall column run the code with the per-lane wall test, the others
-    // -- 33 of 35 at nx = 8192 -- the code without it (periodic box: one form)
-    const bool cols = BC != LB_BC_PERIODIC && (x0 <= 0 || x0 + STRIP_W > a.nx - 1);
-    if (LB_DEEP_COLS_SPLIT && BC != LB_BC_PERIODIC && !cols) {
-        if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true, false>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
-        else deep_march<BC, MASK, MACRO, D, RW, PFD, false, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
-    } else {
-        if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
-        else deep_march<BC, MASK, MACRO, D, RW, PFD, false, true>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
-    }
+    if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+    else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
 #ifdef LB_DIAG
     if ((a.diag & 4096) && threadIdx.x == 0) {
         // per-wave timeline into the (otherwise unused) rho array: start, end (100 MHz ticks), XCC id, HW id, item, rows (tools/wave_timeline.py)

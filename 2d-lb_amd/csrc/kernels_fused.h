@@ -238,11 +238,7 @@ __device__ __forceinline__ void store_row9(bool nts, float *d, long long S, int 
 }
 
 // Boundary rule, obstacle swap, moments, equilibrium and relaxation of the 4 gathered cells, in place.
-// COLS = false (k_deep, round 5): the caller guarantees that none of the wave's cells lies in a wall column -- an interior strip
-// of a walled box --, so the per-lane test for x = 0 / nx-1 and the rule's code behind it leave the wave's path altogether (a lone
-// wave pays ~5 cycles for every instruction it issues, taken or not: +17 % instructions per row in the pipe kernels otherwise).
-// OOL: the rule is called (boundary_rule_call), not inlined.
-template <int BC, bool MASK, bool COLS = true, bool OOL = false>
+template <int BC, bool MASK, bool OOL = false>
 __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f4a (&q)[9], uc4 mk, f4a &r4,
                                             f4a &u4, f4a &v4)
 {
@@ -253,8 +249,8 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     if (BC != LB_BC_PERIODIC) {
         const bool south = (yg == 0), north = (yg == a.ny - 1);
         bool wall_row = (BC != LB_BC_VELOCITY_INLET) && (south || north);   // (that family's wall rows need no rule: their pull is remapped)
-        bool first = COLS && (x4 == 0);
-        bool last = COLS && (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
+        bool first = (x4 == 0);
+        bool last = (x4 <= a.nx - 1 && a.nx - 1 < x4 + 4);
         const int jl = (a.nx - 1) & 3;
 #ifdef LB_DIAG
         if (a.diag & 512) wall_row = first = last = false;    // timing only: no boundary rule

@@ -508,6 +508,18 @@ def main():
         if 0.5 * t1 / q < a <= 1.02 * t1 / q:          # (else: keep the block average below)
             plain_ms, macro_extra_ms = a, max(t1 - q * a, 0.0)
 
+    # the six-step kernel beside the default (seven steps per launch since round 5): the launch the previous rounds' `frac` priced
+    six = None
+    if dist is None and args.variant is None and args.config == 4 and eng.steps_per_launch() == 7:
+        eng.set_variant(353 | 4096 | 16384)            # k_deep<6> (bitwise equal: these are ordinary time steps)
+        if eng.steps_per_launch() == 6:
+            sim.run(12, wait=False)
+            t6 = statistics.median(sim.timed_run(6 * 10) for _ in range(5)) / 10.0
+            six = {"kernel": eng.hot_kernel(), "launch_ms": round(t6, 4),
+                   "frac": round(bytes_per_cell * n * h / (t6 / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "MLUPS": round(6.0 * n * h / (t6 / 1e3) / 1e6, 1)}
+        eng.set_variant(-1)
+
     # sanity: the run must have produced finite, physical numbers (guards against timing a broken kernel) -- one
     # device pass and 24 bytes to the host (lb_check) instead of downloading a 268 MB plane
     health = sim.check() if dist is not None else eng.check()
@@ -552,6 +564,7 @@ def main():
                     "same march with fewer stages)" % "+".join(str(d) for d in plan)),
                 "launch_ms": round(launch_s * 1e3, 4), "launch_ms_source": launch_source, "steps_per_launch": spl,
                 "block_plan": plan,
+                "six_step_kernel": six,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "effective_GBps": round(effective, 1), "effective_x_roofline": round(effective / HBM_PEAK_GBS, 4),
                 "macro_fields": "rebuilt on demand from the populations (lb_get_macro / lb_check), not stored by run()"
