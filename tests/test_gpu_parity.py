@@ -261,6 +261,32 @@ def test_run_is_split_into_the_cheapest_launches(lbhip):
     assert slab.plan_launches(8) is None
 
 
+def test_launch_plan_follows_the_costs_autotune_measured(lbhip):
+    """lb_autotune leaves the handle the launch cost of every depth it timed (launch_costs in lb_hip.cpp); lb_plan_launches then
+    splits runs by THOSE costs: the plan still sums to n, uses no depth beyond the tuned one, and run(n) by that plan gives the
+    single-step kernel's bits."""
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 2560, 2304
+    rng = np.random.default_rng(5)
+    f0 = _random_state(rng, nx, ny)
+    a = Simulation(nx, ny, 1.6, bc="periodic")
+    a.set_f(f0)
+    used = a.autotune()
+    deepest = a.steps_per_launch()
+    assert used > 0 and 1 <= deepest <= 7
+    for n in (1, 5, 13, 20, 41, 64, 84):
+        p = a.plan_launches(n)
+        assert sum(p) == n and max(p) <= deepest and p == sorted(p), (n, p)
+    a.run(20)
+    a.run(13)
+    b = Simulation(nx, ny, 1.6, bc="periodic")
+    b.set_variant(0)
+    b.set_f(f0)
+    b.run(used + 33)
+    ga, gb = a.get_fields(("f",)), b.get_fields(("f",))
+    assert np.array_equal(ga["f"], gb["f"])
+
+
 @pytest.mark.parametrize("nx", [512, 716, 720, 724, 740, 744, 748, 960, 964, 992, 996, 1000, 1196, 1236, 1241, 1440, 1488])
 @pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
 def test_five_and_six_step_kernel_strip_boundaries(lbhip, bc, nx):
