@@ -276,7 +276,7 @@ def test_launch_plan_follows_the_costs_autotune_measured(lbhip):
     assert used > 0 and 1 <= deepest <= 7
     for n in (1, 5, 13, 20, 41, 64, 84):
         p = a.plan_launches(n)
-        assert sum(p) == n and max(p) <= deepest and p == sorted(p), (n, p)
+        assert sum(p) == n and max(p) <= deepest and min(p) >= 1, (n, p)      # (the order follows the measured costs)
     a.run(20)
     a.run(13)
     b = Simulation(nx, ny, 1.6, bc="periodic")
