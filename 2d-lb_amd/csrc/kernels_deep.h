@@ -52,6 +52,7 @@ struct DeepState {
     f4a d0[NL];                         // link 0 of the newest row of the LDS windows RW+1..D-1
     unsigned mhist;                     // obstacle-mask history (per byte: bit j = the row loaded j iterations ago, j = 1..D-1)
 };
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 struct DeepCtx {
     int lane, x4, ym, n_iter;
     bool store_lane;
@@ -87,6 +88,102 @@ __device__ __forceinline__ void deep_publish(f4a (*W)[64], int lane, int gs, con
     W[gs][lane] = q[D_::An]; W[gs + 1][lane] = q[D_::Bn]; W[gs + 2][lane] = q[D_::Cn];
 }
 
+// ---- a row's nine gathers and nine stores through BUFFER instructions (round 5) -----------------------------------------------
+// A global access takes a 64-bit base per instruction: nine bases per gathered row and nine lane offsets per stored row, ~55 scalar and
+// ~33 vector instructions of address arithmetic per row -- to a wave that pays ~5 cycles for each.  A buffer access adds three things
+// itself: a resource (its base: a source row's start moved one float down, so that the displaced planes need no negative offset;
+// three per gathered row, one per stored row), a scalar offset per plane (eight loop-invariant scalars) and a small immediate
+// (0 / 4 / 8 bytes: pulled from the left / same column / from the right); the lane offset is one register for all.
+#ifndef LB_DEEP_BUFFER
+#define LB_DEEP_BUFFER 1
+#endif
+// (a resource must live in scalar registers; where the compiler cannot see that a row's base is wave-uniform it wraps every access in
+//  a "waterfall" loop over the distinct values -- 15 of them per row pair in the first form of this code: say so explicitly)
+__device__ __forceinline__ float *deep_uniform(const float *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ f4a deep_buf_load(__amdgpu_buffer_rsrc_t r, int vo, int so, int imm)
+{
+    return __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(r, vo + imm, so, 0));
+}
+// row1_load (kernels_step4.h) for the strips of k_deep: no halo cell; the nine plane loads through one buffer resource
+template <int BC, bool MASK>
+__device__ __forceinline__ void deep_row_load(const StepArgs &a, int r, int x4, Row1 &o)
+{
+    int ym, yp;
+    o.have = step1_rows(a, r, o.rr, ym, yp);
+    o.mk = uc4{0, 0, 0, 0};
+    o.hsolid = false;
+    o.hxc = -1;
+    if (o.have) {
+        if (LB_DEEP_BUFFER) {
+            const long long P = a.pitch, S = a.plane;
+            const float *s = a.src;
+            const int yl = o.rr;
+            o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (BC == LB_BC_PERIODIC) {                     // (the seam lanes' wrap elements: as gather_issue)
+                const int c = a.nx - 1 - x4;
+                const bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
+                if (wrap_w) {
+                    o.wp.p1 = s[1 * S + (long long)yl * P + a.nx - 1];
+                    o.wp.p5 = s[5 * S + (long long)ym * P + a.nx - 1];
+                    o.wp.p8 = s[8 * S + (long long)yp * P + a.nx - 1];
+                }
+                if (wrap_e) {
+                    o.wp.w3 = s[3 * S + (long long)yl * P];
+                    o.wp.w6 = s[6 * S + (long long)ym * P];
+                    o.wp.w7 = s[7 * S + (long long)yp * P];
+                }
+            }
+            // one resource per source row (the row itself, the rows its cy = +1 / cy = -1 links come from: wrapped by step1_rows where
+            // the box is periodic), each based one float BELOW the row start: the immediate is 0 / 4 / 8 for a pull from the left / the
+            // same column / the right; the scalar offset is the plane's
+            const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)yl * P - 1), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)ym * P - 1), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)yp * P - 1), 0, 0x7fffffff, 0x00020000);
+            const unsigned S4 = (unsigned)a.plane * 4u;
+            const int vo = x4 * 4;
+            o.q[0] = deep_buf_load(r0, vo, 0, 4);
+            o.q[1] = deep_buf_load(r0, vo, (int)(S4), 0);
+            o.q[2] = deep_buf_load(rm, vo, (int)(2u * S4), 4);
+            o.q[3] = deep_buf_load(r0, vo, (int)(3u * S4), 8);
+            o.q[4] = deep_buf_load(rp, vo, (int)(4u * S4), 4);
+            o.q[5] = deep_buf_load(rm, vo, (int)(5u * S4), 0);
+            o.q[6] = deep_buf_load(rm, vo, (int)(6u * S4), 8);
+            o.q[7] = deep_buf_load(rp, vo, (int)(7u * S4), 8);
+            o.q[8] = deep_buf_load(rp, vo, (int)(8u * S4), 0);
+            if (MASK) o.mk = *reinterpret_cast<const uc4 *>(lane_ptr(a.mask + (long long)yl * a.fpitch, x4));
+        } else {
+            gather_issue<BC, MASK, false>(a, x4, o.rr, ym, yp, o.q, o.mk, o.wp);
+        }
+    } else {
+        o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.q[k] = f4a{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// store_row9 (kernels_fused.h) through a buffer resource based at the row
+__device__ __forceinline__ void deep_row_store(const StepArgs &a, int r, int x4, const f4a (&t)[9])
+{
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(a.dst + (long long)r * a.pitch), 0, 0x7fffffff, 0x00020000);
+    const unsigned S4 = (unsigned)a.plane * 4u;
+    const int vo = x4 * 4;
+    // (a compiler-level memory clobber, as store_row9's: without one in the loop the optimiser promotes the wave-private LDS windows
+    //  -- written in one iteration, read two later, clobbered by nothing it can see -- into "registers": 256 + 256 of them and 1.4 KB
+    //  of scratch per lane)
+    asm volatile("" ::: "memory");
+    if (a.nts != 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, t[k]), rd, vo, (int)(k * S4), 2);     // (2: nt)
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, t[k]), rd, vo, (int)(k * S4), 0);
+    }
+}
+
 // Stages S..D of one iteration, S >= 2.  qin = the row stage S - 1 produced in this iteration (position i - (S - 2)).
 template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S>
 __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it,
@@ -118,7 +215,8 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
 #endif
                 if (cx.store_lane) {
                     float *d = a.dst + (long long)r * a.pitch;     // row start, uniform
-                    store_row9<false>(a.nts != 0, d, a.plane, x4, t);
+                    if (LB_DEEP_BUFFER) deep_row_store(a, r, x4, t);
+                    else store_row9<false>(a.nts != 0, d, a.plane, x4, t);
                     if (MACRO) {
                         const long long m = (long long)r * a.fpitch;
                         store4<false>(lane_ptr(a.rho + m, x4), r4);
@@ -168,8 +266,8 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
     if (!((a.diag & (1 << 23)) && i > 0))
 #endif
     {
-        if (PFD) row1_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, false, 0, nxt);
-        else row1_load<BC, MASK>(a, row_at(i), x4, false, 0, cur);
+        if (PFD) deep_row_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, nxt);
+        else deep_row_load<BC, MASK>(a, row_at(i), x4, cur);
     }
     f4a (&q1)[9] = cur.q;
     f4a r4, u4, v4;
@@ -218,7 +316,7 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     DeepState<RW, D - 1 - RW> st = {};
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
     Row1 ra, rb;
-    if (PFD) row1_load<BC, MASK>(a, row_at(0), cx.x4, false, 0, ra);
+    if (PFD) deep_row_load<BC, MASK>(a, row_at(0), cx.x4, ra);
     deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, 1>(a, cx, st, ra, rb);
     if (PFD == 1 && !deep_pairs(MASK)) {
         // one iteration per trip; the row gathered ahead moves into place (position D - 1 is in ra or rb by its parity)
