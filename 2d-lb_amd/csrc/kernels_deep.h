@@ -44,7 +44,14 @@ constexpr int deep_pfd(int D) { return 1; }
 // the loop) pay without an obstacle mask (periodic 435 against 412, cavity 403 / 383) and cost with one (periodic + mask 350 against
 // 368, pipe + mask 4096^2 250 / 263); a code path of their own for the strips without a wall column (no per-lane wall test: -36
 // instructions per row) costs more in footprint than it saves (pipe 337 against 393 with pairs, 388 / 384 without): off.
-constexpr bool deep_pairs(bool mask) { return !mask; }
+// Since the row in flight sits in accumulation registers (LB_DEEP_MANUAL below) no buffers swap roles any more, the pairs only
+// make the ring slots immediate: periodic 458 against 452 k, but the walled kernels (2,600 instructions per iteration: the pair of
+// pairs of the two waves is ~62 KB of code) now lose by them: pipe 8192^2 392 against 384, cavity 418 / 406, pipe 4096^2 337 / 329
+// (profiles/r05_pairs_ab.txt).  Mode 1: pairs in periodic boxes without a mask only (2: wherever there is no mask; 0: nowhere).
+#ifndef LB_DEEP_PAIRS_MODE
+#define LB_DEEP_PAIRS_MODE 1
+#endif
+constexpr bool deep_pairs(bool mask, int bc) { return LB_DEEP_PAIRS_MODE == 2 ? !mask : (LB_DEEP_PAIRS_MODE == 1 ? !mask && bc == LB_BC_PERIODIC : false); }
 
 template <int RW, int NL>
 struct DeepState {
@@ -165,6 +172,109 @@ __device__ __forceinline__ void deep_row_load(const StepArgs &a, int r, int x4, 
         for (int k = 0; k < 9; ++k) o.q[k] = f4a{0.f, 0.f, 0.f, 0.f};
     }
 }
+// ---- the row gathered AHEAD, waited for by hand (round 5) --------------------------------------------------------------------------
+// The compiler's wait-count pass counts a load's younger operations exactly inside one basic block only: a row gathered in one
+// iteration and consumed in the next is waited for with a count that forgets the nine stores (and, issued first, the nine new loads)
+// between the two -- `s_waitcnt vmcnt(0..8)` where 9..18 would do: the wave drains what it has just issued and the gather "ahead"
+// hides nothing (SQ_WAIT_ANY 22 % of the wave cycles of k_deep<7>, profiles/r05_sq_deep7_8192.txt; a two-buffer loop of 30 lines
+// shows the same counts).  So the row in flight is hidden from the compiler altogether: its loads are issued by an asm block into a
+// FIXED window of accumulation registers, a[192:234], that the kernel uses for nothing else (tools/kernel_resources.py checks the
+// disassembly for strays), and taken out of it behind an `s_waitcnt vmcnt(N)` written here, N = the vector-memory instructions this
+// wave has issued since the row's last load -- the nine (MACRO: twelve) stores of the iteration in between, every steady iteration
+// issues them; none in the filling iterations --: vector-memory operations of a wave complete in issue order (loads and stores count
+// together), "all but the N youngest are done" is then exactly "the row has arrived".  A count too SMALL only waits longer; one too
+// LARGE would read registers still in flight, hence: N is 0 wherever the iteration before was not a steady one (deep_march drains the
+// counter once before its loop), and LB_DIAG builds, whose ablation bits skip loads and stores, do not use this path.
+#ifndef LB_DEEP_MANUAL
+#ifdef LB_DIAG
+#define LB_DEEP_MANUAL 0
+#else
+#define LB_DEEP_MANUAL LB_DEEP_BUFFER
+#endif
+#endif
+__device__ __forceinline__ u4v deep_rsrc_words(const float *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return u4v{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)), 0x7fffffffu,
+               0x00020000u};
+}
+// issues row r's loads into a[192:227] (planes 0..8), a[228:233] (the seam lanes' wrap elements), a234 (obstacle flags); o: rr, have
+template <int BC, bool MASK>
+__device__ __forceinline__ void deep_row_issue(const StepArgs &a, int r, int x4, Row1 &o)
+{
+    int ym, yp;
+    o.have = step1_rows(a, r, o.rr, ym, yp);
+    o.hsolid = false;
+    o.hxc = -1;
+    if (o.have) {
+        const long long P = a.pitch, S = a.plane;
+        const float *s = a.src;
+        const int yl = o.rr;
+        if (BC == LB_BC_PERIODIC) {                     // (issued first, as gather_issue does)
+            const int c = a.nx - 1 - x4;
+            const bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
+            if (wrap_w) {
+                const float *e = s + a.nx - 1;
+                asm volatile("global_load_dword a228, %0, off\n\tglobal_load_dword a229, %1, off\n\tglobal_load_dword a230, %2, off"
+                             :: "v"(e + 1 * S + (long long)yl * P), "v"(e + 5 * S + (long long)ym * P), "v"(e + 8 * S + (long long)yp * P)
+                             : "memory", "a228", "a229", "a230");
+            }
+            if (wrap_e) {
+                asm volatile("global_load_dword a231, %0, off\n\tglobal_load_dword a232, %1, off\n\tglobal_load_dword a233, %2, off"
+                             :: "v"(s + 3 * S + (long long)yl * P), "v"(s + 6 * S + (long long)ym * P), "v"(s + 7 * S + (long long)yp * P)
+                             : "memory", "a231", "a232", "a233");
+            }
+        }
+        const u4v r0 = deep_rsrc_words(s + (long long)yl * P - 1), rm = deep_rsrc_words(s + (long long)ym * P - 1),
+                  rp = deep_rsrc_words(s + (long long)yp * P - 1);
+        const unsigned S4 = (unsigned)a.plane * 4u;
+        asm volatile("buffer_load_dwordx4 a[192:195], %0, %1, 0 offen offset:4\n\t"
+                     "buffer_load_dwordx4 a[196:199], %0, %1, %4 offen\n\t"
+                     "buffer_load_dwordx4 a[200:203], %0, %2, %5 offen offset:4\n\t"
+                     "buffer_load_dwordx4 a[204:207], %0, %1, %6 offen offset:8\n\t"
+                     "buffer_load_dwordx4 a[208:211], %0, %3, %7 offen offset:4\n\t"
+                     "buffer_load_dwordx4 a[212:215], %0, %2, %8 offen\n\t"
+                     "buffer_load_dwordx4 a[216:219], %0, %2, %9 offen offset:8\n\t"
+                     "buffer_load_dwordx4 a[220:223], %0, %3, %10 offen offset:8\n\t"
+                     "buffer_load_dwordx4 a[224:227], %0, %3, %11 offen"
+                     :: "v"(x4 * 4), "s"(r0), "s"(rm), "s"(rp), "s"(S4), "s"(2u * S4), "s"(3u * S4), "s"(4u * S4), "s"(5u * S4), "s"(6u * S4),
+                        "s"(7u * S4), "s"(8u * S4)
+                     : "memory", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205",
+                       "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220",
+                       "a221", "a222", "a223", "a224", "a225", "a226", "a227");
+        if (MASK) asm volatile("global_load_dword a234, %0, off" :: "v"(lane_ptr(a.mask + (long long)yl * a.fpitch, x4)) : "memory", "a234");
+    }
+}
+// the row issued last: waits until all but the wave's N youngest vector-memory operations are done, then takes it out of the window
+template <int BC, bool MASK, int N>
+__device__ __forceinline__ void deep_row_take(Row1 &o)
+{
+    static_assert(N == 0 || N == 9 || N == 12, "the stores of one steady iteration, or nothing");
+#define LB_DEEP_TAKE_OUTS "={a[192:195]}"(o.q[0]), "={a[196:199]}"(o.q[1]), "={a[200:203]}"(o.q[2]), "={a[204:207]}"(o.q[3]), \
+                          "={a[208:211]}"(o.q[4]), "={a[212:215]}"(o.q[5]), "={a[216:219]}"(o.q[6]), "={a[220:223]}"(o.q[7]), "={a[224:227]}"(o.q[8])
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" : LB_DEEP_TAKE_OUTS :: "memory");
+#ifdef LB_DEEP_TIMING_NO_WAIT                        // timing only, wrong results: what the wait itself costs
+    else if (N == 9) asm volatile("s_waitcnt vmcnt(63)" : LB_DEEP_TAKE_OUTS :: "memory");
+#endif
+    else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" : LB_DEEP_TAKE_OUTS :: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" : LB_DEEP_TAKE_OUTS :: "memory");
+#undef LB_DEEP_TAKE_OUTS
+    o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (BC == LB_BC_PERIODIC)
+        asm volatile("" : "={a228}"(o.wp.p1), "={a229}"(o.wp.p5), "={a230}"(o.wp.p8), "={a231}"(o.wp.w3), "={a232}"(o.wp.w6), "={a233}"(o.wp.w7));
+    o.mk = uc4{0, 0, 0, 0};
+    if (MASK) {
+        unsigned m;
+        asm volatile("" : "={a234}"(m));
+        o.mk = __builtin_bit_cast(uc4, m);
+    }
+    if (!o.have) {                                      // (a row outside a walled box: nothing was issued)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.q[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        o.mk = uc4{0, 0, 0, 0};
+    }
+}
+
 // store_row9 (kernels_fused.h) through a buffer resource based at the row
 __device__ __forceinline__ void deep_row_store(const StepArgs &a, int r, int x4, const f4a (&t)[9])
 {
@@ -266,7 +376,10 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
     if (!((a.diag & (1 << 23)) && i > 0))
 #endif
     {
-        if (PFD) deep_row_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, nxt);
+        if (PFD && LB_DEEP_MANUAL) {
+            deep_row_take<BC, MASK, (NST < D ? 0 : (MACRO ? 12 : 9))>(cur);
+            deep_row_issue<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, nxt);
+        } else if (PFD) deep_row_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, nxt);
         else deep_row_load<BC, MASK>(a, row_at(i), x4, cur);
     }
     f4a (&q1)[9] = cur.q;
@@ -316,9 +429,12 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     DeepState<RW, D - 1 - RW> st = {};
     auto row_at = [&](int p) { return DOWN ? ym - 1 - p : ym + p; };
     Row1 ra, rb;
-    if (PFD) deep_row_load<BC, MASK>(a, row_at(0), cx.x4, ra);
+    if (PFD && LB_DEEP_MANUAL) deep_row_issue<BC, MASK>(a, row_at(0), cx.x4, ra);
+    else if (PFD) deep_row_load<BC, MASK>(a, row_at(0), cx.x4, ra);
     deep_fill<BC, MASK, MACRO, D, RW, PFD, DOWN, 1>(a, cx, st, ra, rb);
-    if (PFD == 1 && !deep_pairs(MASK)) {
+    // (the steady iterations wait with the count of a steady iteration's stores: the first one has none behind it)
+    if (PFD && LB_DEEP_MANUAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PFD == 1 && !deep_pairs(MASK, BC)) {
         // one iteration per trip; the row gathered ahead moves into place (position D - 1 is in ra or rb by its parity)
         if ((D - 1) & 1) ra = rb;
         for (int i = D - 1; i < cx.n_iter; ++i) {
@@ -337,6 +453,7 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
     } else {
         for (int i = D - 1; i < cx.n_iter; ++i) deep_iter<BC, MASK, MACRO, D, RW, PFD, DOWN, D>(a, cx, i, st, ra, ra);
     }
+    if (PFD && LB_DEEP_MANUAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the row gathered behind the last position)
 }
 
 // Launch geometry as k_step5 / k_step6: one workgroup = one segment pair of one strip (two waves), XCD-transposed order, shorter
