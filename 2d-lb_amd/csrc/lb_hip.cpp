@@ -288,8 +288,15 @@ int effective_variant(const lb_sim *s)
     // 4096^2 303 / 318 / 323, 6144^2 303 / 370 / 371, 8192^2 333 / 387 / 394; cavity 4096^2 324 / 319 / 322, 6144^2 303 / 368 / 366;
     // with a (dense, random 1 %) obstacle mask -- 32 selects per row and stage that a lone wave pays in full --: periodic 2560^2
     // 254 / 244 / 261, 8192^2 338 / 347 / 368; pipe 4096^2 293 / 270 / 280, 6144^2 295 / 298 / 321; cavity 6144^2 321 / 305 / 322.
+    // With the gathered row waited for by hand (kernels_deep.h, LB_DEEP_MANUAL; profiles/r05_size_sweep2.txt, another box): periodic
+    // 1536^2 253 / 252 / 263, 2048^2 279 / 309 / 307, 3072^2 290 / 314 / 327; with a mask 1536^2 229 / 236 / 248, 2560^2 272 / 256 / 292;
+    // pipe 3584^2 296 / 277 / 288, 4096^2 310 / 318 / 329; cavity 3584^2 296 / 299 / 301; pipe + mask 3584^2 280 / 259 / 264, 4096^2
+    // 291 / 293 / 298 (config 5's image: 297 / 296 / 307), 5120^2 282 / 327 / 335; cavity + mask 4096^2 292 / 302 / 309.  Whole grids
+    // from 1500^2 (periodic), 3800^2 (walled), 4000^2 (walled + mask) cells; slabs (edge bands of a deep cycle on few rows: section 9
+    // of profiles/r05_experiments.txt) keep the periodic threshold they were measured with.
     const bool periodic_box = s->p.bc_mode == LB_BC_PERIODIC;
-    const double deep_side = periodic_box ? 2400.0 : (s->has_mask ? 5200.0 : 3800.0);
+    const bool whole_grid = s->H >= s->p.ny;
+    const double deep_side = periodic_box ? (whole_grid ? 1500.0 : 2400.0) : (s->has_mask ? 4000.0 : 3800.0);
     if (cells >= deep_side * deep_side) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
     return v;
 }

@@ -264,12 +264,12 @@ def test_config5_porous_obstacles_4096_vs_oracle(lbhip, oracle):
     sim = Simulation(n, n, 1.0, bc="pipe", inlet_rho=rin, outlet_rho=1., obstacle_mask=mask)
     ref = oracle.O2Sim(n, n, 1.0, oracle.BC_PIPE, rin, 1., mask=mask)
     sim.set_f(f0); ref.set_f(f0)
-    assert sim.steps_per_launch() == 5
+    assert sim.steps_per_launch() == 7 and "k_deep<7>" in sim.hot_kernel()     # (walled + mask: k_deep from 4000^2 cells)
     sim.run(3); ref.run(3)                            # remainder launch: k_step3
     assert_fields_close(sim.get_fields(("f", "rho", "u", "v")), ref.get_fields(), dict(f=5e-7, rho=1e-6, u=1e-6, v=1e-6))
     sim.run(4); ref.run(4)                            # remainder launch: k_step4<PIPE, MASK>
     assert_fields_close(sim.get_fields(("f", "rho", "u", "v")), ref.get_fields(), dict(f=1e-6, rho=1e-6, u=1e-6, v=1e-6))
-    sim.run(10); ref.run(10)                          # two launches of k_step5<PIPE, MASK>
+    sim.run(10); ref.run(10)                          # the plan's launches of k_deep<PIPE, MASK> (and a remainder launch)
     assert_fields_close(sim.get_fields(("f", "rho", "u", "v")), ref.get_fields(), dict(f=2.5e-6, rho=2.5e-6, u=2.5e-6, v=2.5e-6))
     sim.run(183)
     g = sim.get_fields(("rho", "u", "v"))
