@@ -29,3 +29,8 @@ case("pipe", 4096, 4096, 403, True, inlet_rho=1.0005)
 case("velocity_inlet", 4096, 1000, 401, False, inlet_u=0.02)
 case("cavity", 3000, 3000, 402, False, lid_u=0.05)
 case("periodic", 8192, 8192, 203, False)
+if "--more" in sys.argv:          # (round 5: the families of k_deep's hand-waited gather at its sizes)
+    case("periodic", 8192, 8192, 150, True)
+    case("pipe", 8192, 8192, 150, False, inlet_rho=1.0005)
+    case("cavity", 6144, 6144, 150, True, lid_u=0.05)
+    case("periodic", 2048, 2048, 500, False)
