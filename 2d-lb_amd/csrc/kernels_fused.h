@@ -325,7 +325,11 @@ __device__ __forceinline__ void collide_row(const StepArgs &a, int x4, int yg, f
     // load put it in; finish_cell's sequence -- obstacle swap, moments, equilibrium, relaxation -- on both cells of a pair at once
     // (round 5 tried the obstacle swap behind a wave-uniform "some lane holds a solid cell in this row" test -- 94 % of a wave's rows
     //  are all fluid under the porous-medium image of BASELINE config 5 --: the join of the two paths costs more register moves than the
-    //  32 selects it skips; masked kernels 5-12 % slower, sparse masks included: profiles/r05_experiments.txt section 8)
+    //  32 selects it skips; masked kernels 5-12 % slower, sparse masks included: profiles/r05_experiments.txt section 8.  Twice more
+    //  at the end of the round, section 20: the swap in a divergent block of its own that all-fluid waves branch around -- no renamed
+    //  registers, ~5 vector instructions on the all-fluid path --: still 3-7 % slower under the porous image, the cylinder and a random
+    //  mask alike (a lone wave pays for every taken branch and for the scheduling barrier a block boundary is); and v_swap_b32 under the
+    //  execution mask through inline asm, whose operands -- sub-registers of the 128-bit row registers -- the compiler copies in and out)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         f2a f[9];
