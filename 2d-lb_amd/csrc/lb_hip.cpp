@@ -34,6 +34,9 @@
 #include <algorithm>
 #include <cmath>
 #include <initializer_list>
+#include <map>
+#include <mutex>
+#include <string>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -193,6 +196,7 @@ struct lb_sim {
     int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1..4) chosen by lb_autotune
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
     float depth_cost[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ms per launch of the d-step kernel as lb_autotune timed it (0: not timed): launch_costs
+    bool tune_cache_checked = false;    // LB_TUNE_CACHE has been consulted for this handle's present shape (lb_set_mask resets it)
     int64_t bytes = 0;
 
     float *origin(int which) const { return lat[which] + GUARD + GHOST * rowp; }   // plane 0, row 0, x 0
@@ -1140,6 +1144,8 @@ int run_whole_grid(lb_sim *s, int n_steps, bool final_macro = true)
 // two-step marching kernels at 8 and 4 waves per CU, and the single-step kernel.  Which one wins depends
 // on the grid's aspect ratio, the mask and the boundary family (wide, short pipes favour fewer, longer
 // segments: +20 % at 3751 x 1251).  Returns the number of steps advanced, or a negative status.
+void tune_cache_store(const lb_sim *s);                 // (LB_TUNE_CACHE, below)
+
 int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
@@ -1226,6 +1232,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     s->cur ^= 1;
     s->feq_valid = false;
     s->macro_valid = !lazy_macro(s);
+    tune_cache_store(s);
     return used + 1;
 }
 
@@ -1277,10 +1284,111 @@ bool cython_march(const lb_sim *s)
     return s->variant >= 0 && (s->variant & 4096) != 0;
 }
 
+// ---- what lb_autotune found, remembered across handles and processes (opt-in: LB_TUNE_CACHE) ------------------------------------
+// The kernel choice of a handle that was never tuned is a table of size thresholds measured on a pool of boxes that differ by +-5 %,
+// and run(n) only tunes when n pays for it.  With LB_TUNE_CACHE=<file> (or "mem": this process only) every result of lb_autotune /
+// lb_autotune_quick is stored under the handle's shape -- GPU, grid, rows owned, family, mask or not, layout, semantics -- and the
+// first lb_run / lb_autotune_quick of a later handle of that shape takes it over (choice, waves per CU and the measured launch
+// costs the launch plan is made from) without spending a step on tuning.  Every candidate is bitwise equivalent: only speed depends
+// on it.  One text line per shape; a line that does not parse or names a kernel the handle cannot run is ignored.
+struct TuneEntry { int steps, wpc; float cost[8]; };
+std::mutex g_tune_mu;
+std::map<std::string, TuneEntry> g_tune;
+std::string g_tune_loaded_from;
+
+const char *tune_cache_path()
+{
+    const char *e = getenv("LB_TUNE_CACHE");
+    return (e && *e) ? e : nullptr;
+}
+
+std::string tune_key(const lb_sim *s)
+{
+    hipDeviceProp_t pr;
+    char arch[64] = "gpu";
+    int cus = 0;
+    if (hipGetDeviceProperties(&pr, s->p.device) == hipSuccess) {
+        snprintf(arch, sizeof(arch), "%s", pr.gcnArchName);
+        for (char *c = arch; *c; ++c)
+            if (*c == ' ' || *c == '\t') *c = '_';
+        cus = pr.multiProcessorCount;
+    }
+    char k[256];
+    snprintf(k, sizeof(k), "abi%d:%s:cu%d:%dx%d:rows%d:bc%d:mask%d:flags%x:sem%d", LB_ABI_VERSION, arch, cus, s->p.nx, s->p.ny, s->H,
+             s->p.bc_mode, s->has_mask ? 1 : 0, (unsigned)s->p.flags, s->p.semantics);
+    return k;
+}
+
+void tune_cache_load_locked(const char *path)
+{
+    if (g_tune_loaded_from == path) return;
+    g_tune_loaded_from = path;
+    if (strcmp(path, "mem") == 0) return;
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char key[256];
+    TuneEntry e;
+    while (fscanf(f, "%255s %d %d %f %f %f %f %f %f %f", key, &e.steps, &e.wpc, &e.cost[1], &e.cost[2], &e.cost[3], &e.cost[4], &e.cost[5],
+                  &e.cost[6], &e.cost[7]) == 10) {
+        e.cost[0] = 0.f;
+        g_tune[key] = e;                                // (a later line of the same shape wins: the file is appended to)
+    }
+    fclose(f);
+}
+
+bool tune_entry_runs_here(const lb_sim *s, const TuneEntry &e);
+
+// takes over a remembered result; true if the handle is tuned afterwards
+bool tune_cache_apply(lb_sim *s)
+{
+    s->tune_cache_checked = true;
+    const char *path = tune_cache_path();
+    if (!path || s->variant >= 0 || s->tuned_steps) return s->tuned_steps != 0;
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    tune_cache_load_locked(path);
+    auto it = g_tune.find(tune_key(s));
+    if (it == g_tune.end() || !tune_entry_runs_here(s, it->second)) return false;
+    s->tuned_steps = it->second.steps;
+    s->tuned_wpc = it->second.wpc;
+    for (int d = 0; d <= MAX_DEPTH; ++d) s->depth_cost[d] = d ? it->second.cost[d] : 0.f;
+    return true;
+}
+
+void tune_cache_store(const lb_sim *s)
+{
+    const char *path = tune_cache_path();
+    if (!path || !s->tuned_steps) return;
+    TuneEntry e;
+    e.steps = s->tuned_steps;
+    e.wpc = s->tuned_wpc;
+    for (int d = 0; d < 8; ++d) e.cost[d] = d <= MAX_DEPTH ? s->depth_cost[d] : 0.f;
+    const std::string key = tune_key(s);
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    tune_cache_load_locked(path);
+    g_tune[key] = e;
+    if (strcmp(path, "mem") == 0) return;
+    if (FILE *f = fopen(path, "a")) {                   // (one short line per write: concurrent processes interleave whole lines)
+        fprintf(f, "%s %d %d %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n", key.c_str(), e.steps, e.wpc, e.cost[1], e.cost[2], e.cost[3], e.cost[4],
+                e.cost[5], e.cost[6], e.cost[7]);
+        fclose(f);
+    }
+}
+
 bool autotune_applies(const lb_sim *s)
 {
     return !s->multi_slab() && s->p.semantics != LB_SEM_CYTHON &&
            (step2_applicable(s) || step3_applicable(s) || tile_applicable(s));
+}
+
+bool tune_entry_runs_here(const lb_sim *s, const TuneEntry &e)
+{
+    if (!autotune_applies(s) || e.steps < 1 || e.steps > MAX_DEPTH) return false;
+    if (e.steps >= 6) return deep_applicable(s) && e.wpc == 4;
+    if (e.steps == 5) return step5_applicable(s) && (e.wpc == 8 || e.wpc == 6);
+    if (e.steps == 4) return e.wpc < 0 ? tile_applicable(s) : (step4_applicable(s) && (e.wpc == 8 || e.wpc == 6 || e.wpc == 4));
+    if (e.steps == 3) return step3_applicable(s) && (e.wpc == 8 || e.wpc == 6 || e.wpc == 4);
+    if (e.steps == 2) return step2_applicable(s) && (e.wpc == 8 || e.wpc == 4);
+    return e.wpc == 0;
 }
 
 }  // namespace
@@ -1671,6 +1779,7 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     DeviceGuard guard(s->p.device);
     if (!mask) {
+        if (s->has_mask && !s->tuned_steps) s->tune_cache_checked = false;     // (another shape as far as LB_TUNE_CACHE is concerned)
         s->has_mask = false;      // (takes effect with the next launch; nothing to upload)
         return LB_OK;
     }
@@ -1694,6 +1803,7 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     // An all-zero mask on one slab must still take the MASK kernel if the caller asked for a
     // mask: keep the flag (kernel choice is per handle, results are identical either way).
     (void)any;
+    if (!s->has_mask && !s->tuned_steps) s->tune_cache_checked = false;
     s->has_mask = true;
     return LB_OK;
 }
@@ -2034,6 +2144,7 @@ int lb_run(lb_sim *s, int n_steps)
     if (n_steps < 0) return fail(LB_ERR_ARG, "negative step count");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_run between lb_step_boundary and lb_step_finish");
     DeviceGuard guard(s->p.device);
+    if (!s->tune_cache_checked) (void)tune_cache_apply(s);
     int rc;
     if (s->p.semantics == LB_SEM_CYTHON) {
         // cython_dim.pyx:346-359: move_bcs, move, update_hydro, update_feq, collide_particles.  The boundary phase of the
@@ -2697,6 +2808,7 @@ int lb_autotune_quick(lb_sim *s, int max_steps)
     if (s && s->cpu) return 0;
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune_quick inside a split step");
+    if (!s->tune_cache_checked && tune_cache_apply(s)) return 0;       // (LB_TUNE_CACHE: an earlier handle of this shape was tuned)
     if (!autotune_applies(s) || s->variant >= 0 || s->tuned_steps || max_steps < autotune_quick_cost(s)) return 0;
     DeviceGuard guard(s->p.device);
     return autotune_whole_grid(s, 1);

@@ -302,7 +302,13 @@ int lb_autotune(lb_sim *s);
 /* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
  * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
  * variant automatic and the pass (333 steps; 861 on grids <= 768^2) fits into max_steps; returns the number
- * of steps advanced, 0 when it did nothing. */
+ * of steps advanced, 0 when it did nothing.
+ *
+ * Environment: LB_TUNE_CACHE=<file> (or "mem": this process only) remembers every result of lb_autotune / lb_autotune_quick under
+ * the handle's shape (GPU, grid, rows owned, boundary family, mask or not, layout flags, semantics; one text line each) and lets the
+ * first lb_run / lb_autotune_quick of a later handle of that shape take it over -- kernel, waves per CU and the measured launch
+ * costs lb_plan_launches splits runs by -- without spending a step on tuning.  Unset (the default): every handle starts from the
+ * size heuristic.  Only speed depends on it: every candidate gives the same bits. */
 int lb_autotune_quick(lb_sim *s, int max_steps);
 /* Calibration launch: a plain 16-byte-per-lane copy of the current lattice into the other one
  * (which is scratch between steps).  *bytes_moved = bytes read + written.  Known traffic in the

@@ -7,10 +7,14 @@ Tolerances (fp32, stated by SURVEY.md section 8c / Appendix D and re-measured he
 The HIP kernels use idiomatic fp32 (FMA, 3*cu instead of cu/cs2, float literals) where the reference
 OpenCL source has double literals and divisions, hence "within tolerance", not bit equality.
 """
+import os
+
 import numpy as np
 import pytest
 
 from conftest import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -285,6 +289,48 @@ def test_launch_plan_follows_the_costs_autotune_measured(lbhip):
     b.run(used + 33)
     ga, gb = a.get_fields(("f",)), b.get_fields(("f",))
     assert np.array_equal(ga["f"], gb["f"])
+
+
+def test_tune_cache_hands_a_result_to_the_next_handle_of_the_same_shape(lbhip, tmp_path, monkeypatch):
+    """LB_TUNE_CACHE=<file>: what lb_autotune found on one handle (kernel depth, waves per CU, the measured launch costs the plan is
+    made from) is taken over by the first run of a later handle of the same shape -- in this process and, through the file, in another
+    one -- without a tuning step; another shape is not touched; results stay the single-step kernel's bits."""
+    import subprocess
+    import sys
+    from LB_D2Q9.simulation import Simulation
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("LB_TUNE_CACHE", str(cache))
+    nx, ny = 1792, 1536
+    rng = np.random.default_rng(11)
+    f0 = _random_state(rng, nx, ny)
+    a = Simulation(nx, ny, 1.5, bc="periodic")
+    a.set_f(f0)
+    used = a.autotune()
+    assert used > 0
+    want = (a.steps_per_launch(), a.hot_kernel(), a.plan_launches(41))
+    lines = cache.read_text().strip().splitlines()
+    assert len(lines) == 1 and ":%dx%d:" % (nx, ny) in lines[0]
+    b = Simulation(nx, ny, 1.5, bc="periodic")          # same shape: tuned by its first run, no step spent on it
+    b.set_f(f0)
+    b.run(used + 9)
+    assert (b.steps_per_launch(), b.hot_kernel(), b.plan_launches(41)) == want
+    a.run(9)
+    assert np.array_equal(a.get_fields(("f",))["f"], b.get_fields(("f",))["f"])
+    c = Simulation(nx, ny + 64, 1.5, bc="periodic")     # another shape: the heuristic, as without the cache
+    c.init_equilibrium(np.ones((nx, ny + 64), np.float32), np.zeros((nx, ny + 64), np.float32), np.zeros((nx, ny + 64), np.float32))
+    c.run(3)
+    monkeypatch.delenv("LB_TUNE_CACHE")
+    d = Simulation(nx, ny + 64, 1.5, bc="periodic")
+    d.run(3)
+    assert c.hot_kernel() == d.hot_kernel() and c.plan_launches(41) == d.plan_launches(41)
+    # another process reads the file
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from LB_D2Q9.simulation import Simulation; "
+            "s = Simulation(%d, %d, 1.5, bc='periodic'); s.run(2); print(s.steps_per_launch(), '|', s.hot_kernel(), '|', s.plan_launches(41))"
+            % (os.path.join(ROOT, "2d-lb_amd"), nx, ny))
+    env = dict(os.environ, LB_TUNE_CACHE=str(cache))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "%s | %s | %s" % want
 
 
 @pytest.mark.parametrize("nx", [512, 716, 720, 724, 740, 744, 748, 960, 964, 992, 996, 1000, 1196, 1236, 1241, 1440, 1488])
