@@ -2,7 +2,7 @@
 # round 5, GPU run 32: the whole GPU suite, smoke() and the two bench lines on the library with the hand-waited gather
 set -u
 cd $GRAFT_REPO_ROOT
-timeout 3000 python3 -m pytest tests -m gpu -x -q > gpurun_out/r05_gputest_e.txt 2>&1
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r05_smoke_e.txt 2>&1
-python3 bench.py > gpurun_out/r05d_bench_default.json 2> gpurun_out/r05d_bench_default.err
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/r05d_bench_steps20.json 2> gpurun_out/r05d_bench_steps20.err
+timeout 3000 python3 -m pytest tests -m gpu -x -q > gpurun_out/r05_gputest_f.txt 2>&1
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r05_smoke_f.txt 2>&1
+python3 bench.py > gpurun_out/r05e_bench_default.json 2> gpurun_out/r05e_bench_default.err
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/r05e_bench_steps20.json 2> gpurun_out/r05e_bench_steps20.err
