@@ -33,6 +33,37 @@ def host_health(f):
     return int((~ok).sum()), float(np.sqrt(3.0 * usq[ok].max())), float(rho[ok].sum())
 
 
+@pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_deep_kernels_store_the_single_step_kernels_fields_when_eager(lbhip, bc, masked):
+    """k_deep<6> / k_deep<7> instantiated with MACRO (a handle that stores rho, u, v with the last launch of every run: the reference-named
+    classes do) -- the launch whose hand-written wait counts twelve stores instead of nine -- against the single-step kernel on such a
+    handle: populations and stored fields, bit for bit, over runs whose last launch is a deep one."""
+    from LB_D2Q9.simulation import Simulation
+    nx, ny = 1216, 320
+    rng = np.random.default_rng(77)
+    f0 = _random_state(rng, nx, ny)
+    mask = None
+    if masked:
+        mask = rng.random((nx, ny)) < 0.02
+        if bc != "periodic":
+            mask[0, :] = mask[-1, :] = False
+            mask[:, 0] = mask[:, -1] = False
+    out = []
+    for variant in (0, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768):
+        s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, eager_macro=True, inlet_rho=1.002, lid_u=0.04)
+        s.set_variant(variant)
+        if variant:
+            assert "k_deep" in s.hot_kernel()
+        s.set_f(f0)
+        for n in (7, 14, 6, 13, 1):
+            s.run(n)
+        out.append(s.get_fields(("f", "rho", "u", "v")))
+        s.close()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]) and np.array_equal(out[0][k], out[2][k]), k
+
+
 @pytest.mark.parametrize("bc,kw", FAMILIES)
 @pytest.mark.parametrize("nx,ny,variant", [(67, 29, 0), (1030, 130, -1), (1024, 256, 353), (300, 200, 512)])
 def test_fields_on_demand_equal_stored_fields_within_rounding(lbhip, bc, kw, nx, ny, variant):
