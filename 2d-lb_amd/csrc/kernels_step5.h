@@ -12,7 +12,8 @@
 // Overlapping strips instead of halo lanes.  k_step4 recomputes the cells beyond its 256-cell strip as scalar cells in "halo
 // lanes" -- a third of its vector instructions, 27 registers of delay lines, and with four cells per side and stage the first
 // version of this kernel spilled (1.37 ms instead of 0.88 ms per 8192^2 launch: profiles/r04_experiments.txt section 10).  Here a
-// wave's 64 lanes x 4 cells ARE the strip and its skirt: strips are laid 248 cells apart and start 4 cells early, step s is
+// wave's 64 lanes x 4 cells ARE the strip and its skirt: strips were laid 248 cells apart and started 4 cells early (since the end of
+// round 5: 240 apart, 8 early, LB_STEP5_ALIGN64 below), step s is
 // right for the cells at least s - 1 away from either end (what is wrong creeps in one cell per step), so after step 5 lanes
 // 1..62 hold 248 good cells and lanes 0 and 63 are never stored.  No halo cells, no delay lines, no exchange between the halo
 // lanes of a pair; the price is 256 / 248 = +3.2 % rows read and computed (the halo lanes read those cells, too) and row starts
@@ -25,7 +26,17 @@
 
 namespace {
 
-constexpr int STEP5_SKIRT = 4;                          // cells a strip starts before / ends behind its stored cells (= one lane)
+// LB_STEP5_ALIGN64 (round 5, default): strips 240 cells = 15 x 64 bytes apart instead of 248 = 15.5 x 64 -- two lanes of skirt per
+// side, of which the inner one is computed right and not stored --, so that every strip's stores begin and end on 64-byte boundaries.
+// With 248 every other seam cuts a 64-byte sector into two parts written at different times (k_step5's launches read 1.12 x the
+// compulsory bytes where the skirts account for 1.03 x: profiles/pmc_traffic.json); k_deep with seams at 8-byte offsets lost 12-23 %
+// to that (profiles/r05_experiments.txt section 23).  One box, 248 | 240 apart, k MLUPS: periodic 8192^2 334-350 | 375, pipe 8192^2
+// 351 | 369-376, cavity 3072^2 287-291 | 296-297, velocity inlet 4096^2 266-267 | 270-273; 4096^2 and below +-1 %
+// (profiles/r05_step5_align64_ab.txt): 3 % more strips, no partial sectors.
+#ifndef LB_STEP5_ALIGN64
+#define LB_STEP5_ALIGN64 1
+#endif
+constexpr int STEP5_SKIRT = LB_STEP5_ALIGN64 ? 8 : 4;   // cells a strip starts before / ends behind its stored cells (= one lane)
 constexpr int STEP5_VALID = STRIP_W - 2 * STEP5_SKIRT;  // 248 cells stored per strip and row
 
 struct March5State {
@@ -227,9 +238,9 @@ __device__ __forceinline__ void march5(const StepArgs &a, const int x0, const in
     // values are never within reach of a stored cell: the wall column's rule rebuilds what it pulled from them)
     // (periodic: only the first lane beyond the last column is anybody's skirt; the lanes behind it -- the last strip of 8192
     //  columns stores 8 cells -- read what that lane reads, i.e. the same cache lines, instead of 240 more columns)
-    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? 0 : xr);
+    if (BC == LB_BC_PERIODIC) cx.x4 = xr < 0 ? xr + a.nx : (xr >= a.nx ? (LB_STEP5_ALIGN64 && xr - a.nx < 8 ? xr - a.nx : (LB_STEP5_ALIGN64 ? 4 : 0)) : xr);
     else cx.x4 = min(max(xr, 0), (a.nx - 1) & ~3);
-    cx.store_lane = cx.lane >= 1 && cx.lane <= 62 && xr < a.nx;
+    cx.store_lane = cx.lane >= STEP5_SKIRT / 4 && cx.lane <= 63 - STEP5_SKIRT / 4 && xr < a.nx;
     cx.ym = ym; cx.n_iter = len + 4; cx.wy = wy; cx.slot = slot;
     cx.W3 = mine; cx.W4 = mine + 9; cx.R2 = mine + 18;         // (slots: window 3, window 4, PF: the ring of window 2)
     cx.P3 = other; cx.P4 = other + 9; cx.Q2 = other + 18;

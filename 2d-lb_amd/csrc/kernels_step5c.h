@@ -383,7 +383,7 @@ __device__ __forceinline__ void march5c(const StepArgs &a, const int x0, const i
     const int xr = x0 + cx.lane * 4;
     const int lx = a.nx - 1;
     cx.x4 = min(max(xr, 0), lx & ~3);                // lanes beyond the box: copies of the lane at that end
-    cx.store_lane = cx.lane >= 1 && cx.lane <= 62 && xr < a.nx;
+    cx.store_lane = cx.lane >= STEP5_SKIRT / 4 && cx.lane <= 63 - STEP5_SKIRT / 4 && xr < a.nx;
     cx.first = (cx.x4 == 0);
     cx.last = (cx.x4 <= lx && lx < cx.x4 + 4);
     cx.jl = lx & 3;

@@ -336,8 +336,8 @@ def test_tune_cache_hands_a_result_to_the_next_handle_of_the_same_shape(lbhip, t
 @pytest.mark.parametrize("nx", [512, 716, 720, 724, 740, 744, 748, 960, 964, 992, 996, 1000, 1196, 1236, 1241, 1440, 1488])
 @pytest.mark.parametrize("bc", ["periodic", "pipe", "cavity"])
 def test_five_and_six_step_kernel_strip_boundaries(lbhip, bc, nx):
-    """k_step5 / k_deep<6>, k_deep<7> march overlapping strips laid 248 / 240 cells apart, each starting 4 / 8 cells early: widths around the
-    multiples of 248 and 240 (the last strip stores a few cells, or none + a whole strip; odd widths in the walled families),
+    """k_step5 / k_deep<6>, k_deep<7> march overlapping strips laid 240 cells apart (k_step5 until the end of round 5: 248), each starting 8
+    cells early: widths around the multiples of 248 and 240 (the last strip stores a few cells, or none + a whole strip; odd widths in the walled families),
     heights around the segment sizes, with an obstacle mask whose solid cells sit on the strip seams, against the single-step
     kernel, bit for bit."""
     from LB_D2Q9.simulation import Simulation

@@ -30,7 +30,7 @@ def main():
     raw = sim.get_fields(("rho",))["rho"]
     u = np.ascontiguousarray(raw.T).view(np.uint32).reshape(-1)          # device order: [y][x]
     # device rows are pitch floats long; host rows nx: with nx % 64 == 0 they coincide
-    strips = (n + 255) // 256 if depth == 4 else (n + 239) // 240
+    strips = (n + 255) // 256 if depth == 4 else (n + 239) // 240      # (k_step5, k_deep: 240 apart)
     wpc = int(os.environ.get("LB_STEP2_WAVES_PER_CU", "8" if depth == 4 else "4"))
     cap = 256 * wpc // 2                          # an item = a pair of segments = one workgroup of two waves (up / down)
     segs = max(cap // strips, 1)
