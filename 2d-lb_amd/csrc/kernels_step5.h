@@ -28,9 +28,9 @@ namespace {
 
 // LB_STEP5_ALIGN64 (round 5, default): strips 240 cells = 15 x 64 bytes apart instead of 248 = 15.5 x 64 -- two lanes of skirt per
 // side, of which the inner one is computed right and not stored --, so that every strip's stores begin and end on 64-byte boundaries.
-// With 248 every other seam cuts a 64-byte sector into two parts written at different times (k_step5's launches read 1.12 x the
-// compulsory bytes where the skirts account for 1.03 x: profiles/pmc_traffic.json); k_deep with seams at 8-byte offsets lost 12-23 %
-// to that (profiles/r05_experiments.txt section 23).  One box, 248 | 240 apart, k MLUPS: periodic 8192^2 334-350 | 375, pipe 8192^2
+// With 248 every other seam cut a 64-byte sector into two parts written at different times; k_deep with its seams at 8-byte offsets
+// lost 12-23 % to that (profiles/r05_experiments.txt section 23).  (The counted HBM bytes do not show it -- 1.06 x compulsory before
+// and after, profiles/pmc_traffic.json --, the launch time does: 8192^2 1030 -> 894 us by rocprofv3.)  One box, 248 | 240 apart, k MLUPS: periodic 8192^2 334-350 | 375, pipe 8192^2
 // 351 | 369-376, cavity 3072^2 287-291 | 296-297, velocity inlet 4096^2 266-267 | 270-273; 4096^2 and below +-1 %
 // (profiles/r05_step5_align64_ab.txt): 3 % more strips, no partial sectors.
 #ifndef LB_STEP5_ALIGN64
