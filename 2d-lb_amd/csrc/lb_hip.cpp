@@ -450,7 +450,12 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
             // times the interior's pairs.)
             int best_i = 0, best_e = 0;
             double best_t = 1e30;
-            for (int si = std::max(1, capacity / strips - 2); si <= capacity / strips + 1; ++si) {
+            // (from two below the closed form capacity / (strips - 2 + 2 edge_cost): a window of capacity / strips - 2 ... + 1 missed the
+            //  optimum wherever the edge cost is high and the strips few -- the velocity-inlet family at 4096^2, cost 2.3, 18 strips:
+            //  54 pairs per interior strip where 48 finish first; 269-272 k MLUPS against round 4's 286-297 k on the same box,
+            //  profiles/r05_vs_r04_one_box.txt)
+            const int si_lo = std::max(1, (int)(capacity / (strips - 2 + 2.0 * edge_cost)) - 2);
+            for (int si = std::min(si_lo, std::max(1, capacity / strips - 2)); si <= capacity / strips + 1; ++si) {
                 const int se = (capacity - (strips - 2) * si) / 2;
                 if (se < si) continue;
                 const int ri = (rows + si - 1) / si, re = (rows + se - 1) / se;
