@@ -31,7 +31,11 @@
 namespace {
 
 // The skirt is D - 1 cells deep, i.e. whole lanes of four cells that are computed and never stored, at either end of a strip
+#ifdef LB_DEEP_SKIRT_LANES                               // (experiment: more skirt than needed, e.g. 4 lanes = strips 224 cells = 7 x 128 B apart)
+constexpr int deep_skirt_lanes(int D) { return LB_DEEP_SKIRT_LANES; }
+#else
 constexpr int deep_skirt_lanes(int D) { return (D - 1 + 3) / 4; }
+#endif
 constexpr int deep_valid(int D) { return STRIP_W - 8 * deep_skirt_lanes(D); }           // cells stored per strip and row (D = 6..9: 240)
 constexpr int deep_strips(int nx, int D) { return (nx + deep_valid(D) - 1) / deep_valid(D); }
 // Where a wave's state lives, per depth (see the header comment): windows in registers, rows gathered ahead

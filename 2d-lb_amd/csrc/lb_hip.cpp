@@ -440,9 +440,13 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
         // (k_deep, one wave per SIMD, the rule out of line: a wall-column strip's rows cost ~1.8 x an interior strip's -- per-wave
         //  timelines, profiles/r05_wave_timeline_walls.txt; scan 1.2 ... 3.0, k MLUPS, k_deep<7>: pipe 8192^2 392 (1.2-1.8) / 379
         //  (2.0-3.0), 4096^2 285 (1.2-1.5) / 322-325 (1.8-2.0) / 319-321 (2.2-3.0), 6144^2 372-377 (1.8-2.2) / 358 (3.0); cavity
-        //  8192^2 395 (<= 1.8) / 370 (>= 2.0), 4096^2 303 / 318-321: profiles/r05_edge_cost_scan.txt)
+        //  8192^2 395 (<= 1.8) / 370 (>= 2.0), 4096^2 303 / 318-321: profiles/r05_edge_cost_scan.txt.  Scanned again once the interior
+        //  strips had got faster -- the hand-waited gather does nothing for a wall-column strip, whose out-of-line rule drains the
+        //  memory counter at every call --: 1.8 | 2.0 | 2.2 | 2.5 | 3.2, k MLUPS, k_deep<7>: pipe 8192^2 394 | 419 | 420 | 416 | 420, 6144^2
+        //  410 | 413 | 419 | 402 | 388, 4096^2 333 | 351 | 347 | 349 | 325; cavity 4096^2 346 | 351 | 353 | 350 | 328; config 5's image 4096^2
+        //  310 | 320 | 320 | 309 | 289; k_deep<6> pipe 8192^2 381 | 406 | 403 | 406 | 407: profiles/r05_edge_cost_scan2.txt -> 2.1)
         const double edge_cost = edge_env > 0.0 ? edge_env
-                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : (depth >= 6 ? 1.8 : 1.2));
+                                 : (s->p.bc_mode == LB_BC_VELOCITY_INLET ? (depth == 5 ? 2.3 : 1.6) : (depth >= 6 ? 2.1 : 1.2));
         if (depth >= 4 && s->p.bc_mode != LB_BC_PERIODIC && strips >= 4 && edge_cost > 1.0 && segs * strips >= capacity / 2) {
             // the split of the wave slots between interior strips (segs_i pairs each) and the two wall-column strips (segs_e each) that
             // finishes first: min over segs_i of max(rows_i, edge_cost x rows_e).  (Until round 5: segs_i = capacity / (strips - 2 +
