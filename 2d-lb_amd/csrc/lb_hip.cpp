@@ -296,11 +296,20 @@ int effective_variant(const lb_sim *s)
     // 1536^2 253 / 252 / 263, 2048^2 279 / 309 / 307, 3072^2 290 / 314 / 327; with a mask 1536^2 229 / 236 / 248, 2560^2 272 / 256 / 292;
     // pipe 3584^2 296 / 277 / 288, 4096^2 310 / 318 / 329; cavity 3584^2 296 / 299 / 301; pipe + mask 3584^2 280 / 259 / 264, 4096^2
     // 291 / 293 / 298 (config 5's image: 297 / 296 / 307), 5120^2 282 / 327 / 335; cavity + mask 4096^2 292 / 302 / 309.  Whole grids
-    // from 1500^2 (periodic), 3800^2 (walled), 4000^2 (walled + mask) cells; slabs (edge bands of a deep cycle on few rows: section 9
-    // of profiles/r05_experiments.txt) keep the periodic threshold they were measured with.
+    // from 1500^2 (periodic) cells -- the walled families: below --; slabs (edge bands of a deep cycle on few rows: section 9
+    // of profiles/r05_experiments.txt) keep the thresholds they were measured with.
     const bool periodic_box = s->p.bc_mode == LB_BC_PERIODIC;
     const bool whole_grid = s->H >= s->p.ny;
-    const double deep_side = periodic_box ? (whole_grid ? 1500.0 : 2400.0) : (s->has_mask ? 4000.0 : 3800.0);
+    // Third sweep, after the wall-strip split had been repaired (its search window missed the optimum at these sizes: section 25 of the
+    // log) and the wall strips' cost re-scanned (2.1): k_step5 | k_deep<6> | k_deep<7>, profiles/r05_size_sweep3.txt / r05_size_sweep4.txt:
+    // pipe 2048^2 245 | 249 | 252, 2304^2 259 | 254 | 261, 2560^2 259 | 273 | 282, 3072^2 287 | 309 | 317, 3584^2 297 | 334 | 344; cavity
+    // likewise; with a mask: pipe 2304^2 231 | 230 | 235, 2560^2 239 | 245 | 254, 3072^2 271 | 277 | 283, 3584^2 281 | 298 | 304; cavity 2304^2
+    // 247 | 229 | 234, 2560^2 243 | 248 | 253; the reference's published case, 3751 x 1251 pipe + disc (4.69 M cells, 16 strips of short
+    // segments): 231-233 | 242-244 | 251 (profiles/r05_refcase_kernels.txt).  Walled whole grids from 2300^2, with a mask from 2150^2 cells
+    // -- just below the reference case, which gains 8 %; a square cavity with a dense mask between 2150^2 and 2500^2 loses up to 5 % --
+    // (slabs: as measured before).
+    const double deep_side = periodic_box ? (whole_grid ? 1500.0 : 2400.0)
+                                          : (s->has_mask ? (whole_grid ? 2150.0 : 4000.0) : (whole_grid ? 2300.0 : 3800.0));
     if (cells >= deep_side * deep_side) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
     return v;
 }
