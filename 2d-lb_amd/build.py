@@ -50,13 +50,20 @@ def _compile(unit, tag, extra, verbose):
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, "%s%s.o" % (os.path.splitext(unit)[0], tag))
     deps = [src] + headers()
-    if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(p) for p in deps):
+    # (an object is reused only if it was compiled with these very flags: build_variant under one tag with other flags, or an
+    #  LB_* define that changed, must not relink stale code)
+    stamp, flags = obj + ".flags", " ".join(FLAGS + extra)
+    if (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(p) for p in deps) and
+            os.path.exists(stamp) and open(stamp).read() == flags):
         return obj
-    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    tmp = obj + ".tmp%d" % os.getpid()
+    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", tmp]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, obj)
+    open(stamp, "w").write(flags)
     return obj
 
 
@@ -71,8 +78,32 @@ def _build(out, tag, extra, force, verbose, jobs):
     jobs = jobs or int(os.environ.get("LB_BUILD_JOBS", "0")) or min(len(UNITS), os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(lambda u: _compile(u, tag, extra, verbose), UNITS))
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out, "-ldl"])
+    if "-DLB_DIAG" not in extra:
+        _check_hand_waited_gather([o for o in objs if os.path.basename(o).startswith("deep")])
+    tmp = out + ".tmp%d" % os.getpid()                     # (linked beside the target, then moved into place: a reader never sees half a library)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp, "-ldl"])
+    os.replace(tmp, out)
     return out
+
+
+def _check_hand_waited_gather(objs):
+    """k_deep's row in flight sits in accumulation registers the compiler only knows as clobbered, behind wait counts written by hand
+    (csrc/kernels_deep.h, LB_DEEP_MANUAL): every build that uses them is disassembled and refused if anything else touches the window
+    or if the stores a wait count stands for are not all there (tools/check_agpr_window.py)."""
+    import importlib.util
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_agpr_window.py")
+    spec = importlib.util.spec_from_file_location("check_agpr_window", tool)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(os.path.join(mod.LLVM, "llvm-objdump")):
+        raise RuntimeError("llvm-objdump not found under %s: the hand-waited gather of k_deep cannot be checked" % mod.LLVM)
+    for obj in objs:
+        loads, reads, strays, checked, problems = mod.check_all(obj)
+        if not loads:
+            continue                                     # (a variant built with -DLB_DEEP_MANUAL=0: nothing to check)
+        if strays or problems:
+            raise RuntimeError("%s: k_deep's accumulation-register window / hand-written waits are not as written:\n  %s"
+                               % (obj, "\n  ".join((strays + problems)[:10])))
 
 
 def build_diag(force=False, verbose=False, jobs=0):

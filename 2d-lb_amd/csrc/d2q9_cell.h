@@ -132,6 +132,9 @@ __device__ __forceinline__ void bounce_cell(Cell &c, bool solid)
 // Same operations, same order, explicit fma: the two instantiations round alike, so a cell gets the same bits whichever
 // form (and whichever kernel) computes it.
 typedef float f2a __attribute__((ext_vector_type(2)));
+#ifndef LB_RELAX_FOLD
+#define LB_RELAX_FOLD 1            // (0: omega * feq_k as nine products of their own -- rounds 2-5; A/B builds)
+#endif
 __device__ __forceinline__ float lb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ f2a lb_rcp(f2a x) { return f2a{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
 __device__ __forceinline__ float lb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -180,7 +183,32 @@ __device__ __forceinline__ void equilibrate_t(T &f0, T &f1, T &f2, T &f3, T &f4,
     const T one = lb_splat<T>(1.f);
     const T usq = lb_fma(ux, ux, uy * uy);
     const T base = lb_fma(lb_splat<T>(-1.5f), usq, one);
-    const T keep = lb_splat<T>(1.f - omega), om = lb_splat<T>(omega);
+    const T keep = lb_splat<T>(1.f - omega);
+#if LB_RELAX_FOLD
+    // omega enters ONCE, through the density: rw = omega rho, r_k = fl(w_k) rw, and every equilibrium below comes out as
+    // omega feq_k -- 61 operations per cell update instead of 69 (the nine products omega * feq_k become one).  The float32
+    // weights still multiply a run-time value, so their systematic bias (see above) is the reference's; the one extra rounding,
+    // omega * rho, depends on the cell's density and averages out (measured on the mass drift of a periodic box,
+    // test_periodic_mass_drift_tracks_reference / profiles/r06_experiments.txt section 1).
+    const T rw = lb_splat<T>(omega) * rho;
+    const T r0 = (4.f / 9.f) * rw, r1 = (1.f / 9.f) * rw, r2 = (1.f / 36.f) * rw;
+    const T r13 = 3.f * r1, r23 = 3.f * r2;
+    T e1, e2, e3, e4, e5, e6, e7, e8;
+    feq_pair<T>(r1, r13, ux, base, e1, e3);
+    feq_pair<T>(r1, r13, uy, base, e2, e4);
+    feq_pair<T>(r2, r23, ux + uy, base, e5, e7);
+    feq_pair<T>(r2, r23, ux - uy, base, e8, e6);
+    f0 = lb_fma(f0, keep, r0 * base);
+    f1 = lb_fma(f1, keep, e1);
+    f3 = lb_fma(f3, keep, e3);
+    f2 = lb_fma(f2, keep, e2);
+    f4 = lb_fma(f4, keep, e4);
+    f5 = lb_fma(f5, keep, e5);
+    f7 = lb_fma(f7, keep, e7);
+    f8 = lb_fma(f8, keep, e8);
+    f6 = lb_fma(f6, keep, e6);
+#else
+    const T om = lb_splat<T>(omega);
     const T r0 = (4.f / 9.f) * rho, r1 = (1.f / 9.f) * rho, r2 = (1.f / 36.f) * rho;
     const T r13 = 3.f * r1, r23 = 3.f * r2;
     T e1, e2, e3, e4, e5, e6, e7, e8;
@@ -197,6 +225,7 @@ __device__ __forceinline__ void equilibrate_t(T &f0, T &f1, T &f2, T &f3, T &f4,
     f7 = lb_fma(f7, keep, om * e7);
     f8 = lb_fma(f8, keep, om * e8);
     f6 = lb_fma(f6, keep, om * e6);
+#endif
 }
 
 __device__ __forceinline__ void moments_cell(const Cell &c, float &rho, float &ux, float &uy)

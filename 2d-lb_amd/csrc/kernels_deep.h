@@ -108,6 +108,11 @@ __device__ __forceinline__ void deep_publish(f4a (*W)[64], int lane, int gs, con
 #ifndef LB_DEEP_BUFFER
 #define LB_DEEP_BUFFER 1
 #endif
+// Extent of every resource: the whole 32-bit range.  A raw buffer access is range-checked as offset >= num_records - soffset, and the
+// scalar offset carries the plane: up to 8 planes x 4 bytes, which in the planar layout (LB_FLAG_PLANAR) of an 8192^2 lattice is 2.16 GB
+// -- with 2 GiB of records (round 5) plane 8 of such a lattice would have read zeros and dropped its stores.  The host admits a
+// lattice to these kernels only while (8 planes + a row) x 4 bytes < 4 GiB (marching_planes_fit, lb_hip.cpp).
+constexpr int DEEP_NUM_RECORDS = -1;                     // 0xffffffff bytes
 // (a resource must live in scalar registers; where the compiler cannot see that a row's base is wave-uniform it wraps every access in
 //  a "waterfall" loop over the distinct values -- 15 of them per row pair in the first form of this code: say so explicitly)
 __device__ __forceinline__ float *deep_uniform(const float *p)
@@ -152,9 +157,9 @@ __device__ __forceinline__ void deep_row_load(const StepArgs &a, int r, int x4, 
             // one resource per source row (the row itself, the rows its cy = +1 / cy = -1 links come from: wrapped by step1_rows where
             // the box is periodic), each based one float BELOW the row start: the immediate is 0 / 4 / 8 for a pull from the left / the
             // same column / the right; the scalar offset is the plane's
-            const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)yl * P - 1), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)ym * P - 1), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)yp * P - 1), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)yl * P - 1), 0, DEEP_NUM_RECORDS, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)ym * P - 1), 0, DEEP_NUM_RECORDS, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(s + (long long)yp * P - 1), 0, DEEP_NUM_RECORDS, 0x00020000);
             const unsigned S4 = (unsigned)a.plane * 4u;
             const int vo = x4 * 4;
             o.q[0] = deep_buf_load(r0, vo, 0, 4);
@@ -199,7 +204,7 @@ __device__ __forceinline__ void deep_row_load(const StepArgs &a, int r, int x4, 
 __device__ __forceinline__ u4v deep_rsrc_words(const float *p)
 {
     const unsigned long long v = (unsigned long long)p;
-    return u4v{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)), 0x7fffffffu,
+    return u4v{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)), (unsigned)DEEP_NUM_RECORDS,
                0x00020000u};
 }
 // issues row r's loads into a[192:227] (planes 0..8), a[228:233] (the seam lanes' wrap elements), a234 (obstacle flags); o: rr, have
@@ -282,7 +287,7 @@ __device__ __forceinline__ void deep_row_take(Row1 &o)
 // store_row9 (kernels_fused.h) through a buffer resource based at the row
 __device__ __forceinline__ void deep_row_store(const StepArgs &a, int r, int x4, const f4a (&t)[9])
 {
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(a.dst + (long long)r * a.pitch), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(deep_uniform(a.dst + (long long)r * a.pitch), 0, DEEP_NUM_RECORDS, 0x00020000);
     const unsigned S4 = (unsigned)a.plane * 4u;
     const int vo = x4 * 4;
     // (a compiler-level memory clobber, as store_row9's: without one in the loop the optimiser promotes the wave-private LDS windows

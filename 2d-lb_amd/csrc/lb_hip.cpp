@@ -308,8 +308,11 @@ int effective_variant(const lb_sim *s)
     // segments): 231-233 | 242-244 | 251 (profiles/r05_refcase_kernels.txt).  Walled whole grids from 2300^2, with a mask from 2150^2 cells
     // -- just below the reference case, which gains 8 %; a square cavity with a dense mask between 2150^2 and 2500^2 loses up to 5 % --
     // (slabs: as measured before).
+    // (slabs: ONE threshold per family, mask or not -- the halo cycle's depth follows from this choice (cycle_depth), every rank of a
+    //  run must arrive at the same one, and the ranks agree on nx, min_h and the family but not on who holds obstacle cells: with
+    //  round 5's 3800^2 / 4000^2 a rank with a mask and a rank without could pick different cycles between the two sizes)
     const double deep_side = periodic_box ? (whole_grid ? 1500.0 : 2400.0)
-                                          : (s->has_mask ? (whole_grid ? 2150.0 : 4000.0) : (whole_grid ? 2300.0 : 3800.0));
+                                          : (whole_grid ? (s->has_mask ? 2150.0 : 2300.0) : 3800.0);
     if (cells >= deep_side * deep_side) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
     return v;
 }
@@ -1025,6 +1028,38 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
     return rc;
 }
 
+// Thick edge bands (round 6).  The rows an edge band MUST cover are the 2D next to a slab edge (the halo is cut from them, D ghost rows
+// are recomputed on the way); as 14-row marches behind six filling iterations they kept 2 x strips workgroup slots busy for a
+// quarter of the launch and idle for the rest, while the interior's waves marched the longer for it (8192 x 1024 rows, one of eight
+// slabs: 48 iterations per wave where 44 do; profiles/r05_slab_proxy_final.txt).  Nothing in the cycle's data flow fixes where the
+// band ends: with bands B rows thicker -- E1: [-D, D+B), C1: [D+B, H-D-B); E2: [0, 2D+B), C2: [2D+B, H-2D-B) -- E1 still reads
+// exactly what E2 and the exchange wrote, C2 only what C1 wrote, E2 waits for C1 and the next C1 for E2, as before.  B is chosen so
+// that a band wave's march (x the wall-column strips' cost in a walled box) ends `slack` iterations before an interior wave's: the
+// edge stream also carries the exchange, the compute stream must never wait for it.  Rank-local: the neighbours need not agree.
+// LB_BAND_EXTRA=<rows> fixes B (0 = the bands of rounds 3-5), LB_BAND_SLACK=<iterations> the head start.
+int band_extra(const lb_sim *s, int D)
+{
+    if (D < 4) return 0;                                // (k_step2 / k_step3: one wave per strip and band, a few rows: as they were)
+    static const int fixed = getenv("LB_BAND_EXTRA") ? atoi(getenv("LB_BAND_EXTRA")) : -1;         // tuning knobs
+    static const double slack = getenv("LB_BAND_SLACK") ? atof(getenv("LB_BAND_SLACK")) : 8.0;
+    const int H = s->H;
+    const int room = (H - 4 * D) / 2 - 8;               // the interior of the second launch keeps at least 16 rows
+    if (room <= 0) return 0;
+    if (fixed >= 0) return std::min(fixed & ~1, room & ~1);
+    const int strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
+    const int wpc = D >= 6 ? 4 : 8;
+    const int segs = std::max(1, (s->cu_count * wpc - 2 * strips * STEP4_WAVES) / STEP4_WAVES / strips);    // interior pairs per strip
+    const double cost = s->p.bc_mode == LB_BC_PERIODIC ? 1.0 : (D >= 6 ? 2.1 : 1.2);    // a wall-column strip's rows (launch_step2)
+    int B = 0;
+    for (int b = 2; b <= room; b += 2) {
+        const double band = cost * ((2 * D + b) / 2.0 + (D - 1)) + slack;
+        const double inner = (double)((H - 4 * D - 2 * b + segs - 1) / segs) / 2.0 + (D - 1);
+        if (band > inner) break;
+        B = b;
+    }
+    return B;
+}
+
 // E1 + C1 (the caller flips cur afterwards); D = depth of the fused kernel (3 or 4).  last = this launch ends the run:
 // rho,u,v are stored and the ghost rows are not recomputed (nothing will consume them; the MACRO epilogue has no rows
 // outside the slab to write to).
@@ -1033,11 +1068,12 @@ int slab_cycle_first(lb_sim *s, int D, bool last = false)
     const int H = s->H, strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     const StepArgs probe = step_args(s, 0, 1, 1);
     const bool macro = last && !lazy_macro(s);
-    int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D, H - D, (probe.ghost_n && !last) ? H + D : H,
+    const int B = band_extra(s, D);
+    int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D + B, H - D - B, (probe.ghost_n && !last) ? H + D : H,
                           macro, D);
     if (rc) return rc;
     // (wave slots left to the band launch running beside it: two bands x strips items, two waves each under k_step4)
-    if ((rc = launch_step2(s, s->stream, D, H - D, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D))) return rc;
+    if ((rc = launch_step2(s, s->stream, D + B, H - D - B, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
@@ -1047,11 +1083,12 @@ int slab_cycle_second(lb_sim *s, bool macro, int D)
 {
     const int H = s->H, strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     macro = macro && !lazy_macro(s);
+    const int B = band_extra(s, D);
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
-    int rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D);
+    int rc = launch_bands(s, s->edge_stream, 0, 2 * D + B, H - 2 * D - B, H, macro, D);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
-    return launch_step2(s, s->stream, 2 * D, H - 2 * D, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D);
+    return launch_step2(s, s->stream, 2 * D + B, H - 2 * D - B, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D);
 }
 
 // Which fused depths a whole-grid handle may use: the variant bits (explicit or from the size heuristic), or --
@@ -1506,21 +1543,27 @@ int lb_create(const lb_params *p, lb_sim **out)
     s->stream = s->own_stream;
     CREATE_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     {
-        // The edge stream (edge bands, halo push / RCCL) at NORMAL priority.  Rounds 1-2 created it at the device's highest
-        // priority; with it, ~2 % of random slab partitions run through lb_run_group with events alone differed from the
-        // undivided run when four other processes kept the GPU busy (17 of ~900, tools/slab_stress.py), none of 1650 without,
+        // The edge stream (edge bands, halo push / RCCL) at NORMAL priority, like the other two.  Rounds 1-2 created it at the
+        // device's highest priority; with it, ~2 % of random slab partitions run through lb_run_group with events alone differed from
+        // the undivided run when four other processes kept the GPU busy (17 of ~900, tools/slab_stress.py), none of 1650 without,
         // while a stand-alone stress of HIP's cross-queue ordering finds nothing (tools/queue_order_repro.hip) and an audit of
-        // every read-after-write and write-after-read pair of the cycle finds every one ordered (DESIGN.md section 8).  The
+        // every read-after-write and write-after-read pair of the cycle finds every one ordered (DESIGN.md section 6).  The
         // priority bought nothing measurable (profiles/r03_experiments.txt section 6), so the product has no such stream and
         // no switch for one; the DIAGNOSTIC build (-DLB_DIAG, never loaded by the product) keeps LB_EDGE_PRIO=1 as the
         // known-bad control for tools/slab_stress.py.
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // (Rounds 3-5 passed the FIRST value hipDeviceGetStreamPriorityRange returns -- the LEAST priority, not the normal one the
+        //  comment claimed: the edge bands, which gate the halo, ran on a low-priority queue.  Round 6: no priority argument at all.)
         bool high = false;
 #ifdef LB_DIAG
         high = getenv("LB_EDGE_PRIO") && atoi(getenv("LB_EDGE_PRIO")) == 1;
 #endif
-        CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, high ? hi : lo));
+        if (high) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            CREATE_TRY(hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, greatest));
+        } else {
+            CREATE_TRY(hipStreamCreateWithFlags(&s->edge_stream, hipStreamNonBlocking));
+        }
     }
     const unsigned ev_flags = hipEventDisableTiming;
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_boundary, ev_flags));

@@ -1,6 +1,8 @@
 """k_deep's row in flight lives in a fixed window of accumulation registers that only its asm blocks may write and only the copies
-behind its hand-written wait may read (csrc/kernels_deep.h: deep_row_issue / deep_row_take).  The compiler is told the window is
-clobbered, not that it is reserved: the device code of the built objects is checked for strays (tools/check_agpr_window.py)."""
+behind its hand-written wait may read, and that wait counts the stores of one steady iteration (csrc/kernels_deep.h: deep_row_issue /
+deep_row_take).  The compiler is told the window is clobbered, not that it is reserved: the device code of the LIBRARY THAT RUNS is
+disassembled and checked for strays and for the store counts (tools/check_agpr_window.py; build.py runs the same check on every
+product build and refuses the build on a finding).  Runs wherever the library and llvm-objdump exist -- here and on the GPU box."""
 import importlib.util
 import os
 
@@ -16,14 +18,31 @@ def _tool():
     return mod
 
 
-@pytest.mark.parametrize("unit", ["deep6.o", "deep7.o"])
-def test_nothing_but_the_asm_blocks_touches_the_window(unit):
-    obj = os.path.join(ROOT, "2d-lb_amd", "build", unit)
-    if not os.path.exists(obj):
-        pytest.skip("objects not built here (__graft_entry__.build() leaves them in 2d-lb_amd/build)")
+def test_nothing_but_the_asm_blocks_touches_the_window_and_the_waits_count_the_stores():
+    lib = os.path.join(ROOT, "2d-lb_amd", "LB_D2Q9", "liblbhip.so")
     tool = _tool()
+    assert os.path.exists(lib), "library not built (__graft_entry__.build())"
     if not os.path.exists(tool.LLVM + "/llvm-objdump"):
         pytest.skip("no llvm-objdump")
-    loads, reads, strays = tool.check(obj)
-    assert loads > 0 and reads > 0, "the hand-waited gather is not in this object"
+    loads, reads, strays, waits, problems = tool.check_all(lib)
+    assert loads > 0 and reads > 0 and waits > 0, "the hand-waited gather is not in this library"
     assert not strays, strays[:5]
+    assert not problems, problems[:5]
+
+
+def test_the_checker_sees_a_stray_and_a_miscount():
+    """the checker itself: a made-up disassembly with one instruction writing the window, and a kernel one store short"""
+    tool = _tool()
+    good = ["0000000000001000 <k_deep_ok>:"]
+    good += ["\tbuffer_load_dwordx4 a[%d:%d], v1, s[0:3], 0 offen // 000000001000: 00" % (192 + 4 * k, 195 + 4 * k) for k in range(9)]
+    good += ["\ts_waitcnt vmcnt(9) // 000000001100: 00", "\tv_accvgpr_read_b32 v5, a192 // 000000001104: 00"]
+    good += ["\tbuffer_store_dwordx4 v[0:3], v1, s[0:3], 0 offen nt // 000000001200: 00"] * 9
+    good += ["\tbuffer_store_dwordx4 v[0:3], v1, s[0:3], 0 offen // 000000001300: 00"] * 9
+    text = "\n".join(good)
+    assert tool.check(None, text) == (9, 1, []) and tool.check_waits(None, text) == (1, [])
+    stray = text + "\n\tv_accvgpr_write_b32 a200, v3 // 000000001400: 00"
+    assert len(tool.check(None, stray)[2]) == 1
+    short = "\n".join(good[:-1])
+    assert len(tool.check_waits(None, short)[1]) == 1
+    extra = text + "\n\tglobal_load_dword v7, v[2:3], off // 000000001500: 00"
+    assert len(tool.check_waits(None, extra)[1]) == 1

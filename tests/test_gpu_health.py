@@ -87,8 +87,9 @@ def test_fields_on_demand_equal_stored_fields_within_rounding(lbhip, bc, kw, nx,
         s.close()
     lazy, eager = out
     assert np.array_equal(lazy["f"], eager["f"])                     # the populations do not know the difference
-    # rounding of nine relaxed populations (|f| <= 0.45: 3e-8 each) + the sum's own: a few ulp of 1
-    assert maxdiff(lazy["rho"], eager["rho"]) <= 3.6e-7
+    # rounding of nine relaxed populations (|f| <= 0.45: 3e-8 each) + the sum's own + (round 6) that of omega * rho, through which omega
+    # enters the nine equilibria at once: a few ulp of 1 -- the contract's single-step bound on rho, measured 4.2e-7
+    assert maxdiff(lazy["rho"], eager["rho"]) <= 5e-7
     assert maxdiff(lazy["u"], eager["u"]) <= 2.5e-7 and maxdiff(lazy["v"], eager["v"]) <= 2.5e-7
     assert maxdiff(lazy["feq"], eager["feq"]) <= 2.5e-7
 
