@@ -447,6 +447,21 @@ class Simulation(object):
     def set_variant(self, variant):
         check(self._lib.lb_set_variant(self._h, int(variant)))
 
+    def set_slab_cycle(self, depth):
+        """Slab handles: depth of the fused kernel the halo cycle runs on (0 = automatic, 3 ... 7); every rank of a run must set the
+        same value (lb_set_slab_cycle)."""
+        check(self._lib.lb_set_slab_cycle(self._h, int(depth)))
+
+    def exchange_timing(self, enable=True):
+        """Slab handles: time every halo exchange of run() on its stream from now on (lb_exchange_timing)."""
+        check(self._lib.lb_exchange_timing(self._h, int(bool(enable))))
+
+    def exchange_stats(self):
+        """The exchanges timed since the last call: {"n", "total_ms", "max_ms", "cycle_depth", "band_rows"} (lb_exchange_stats)."""
+        n, tot, mx, d, b = ct.c_int64(), ct.c_double(), ct.c_double(), ct.c_int(), ct.c_int()
+        check(self._lib.lb_exchange_stats(self._h, ct.byref(n), ct.byref(tot), ct.byref(mx), ct.byref(d), ct.byref(b)))
+        return {"n": n.value, "total_ms": tot.value, "max_ms": mx.value, "cycle_depth": d.value, "band_rows": b.value}
+
     def autotune(self):
         """Time the candidate fused-kernel configurations on a few live steps and keep the fastest for this
         grid (bitwise-equivalent candidates).  Returns the number of time steps the simulation advanced."""

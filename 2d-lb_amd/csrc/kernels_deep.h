@@ -493,8 +493,38 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const 
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
     const int x0 = sx * deep_valid(D) - 4 * deep_skirt_lanes(D);
-    if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
-    else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+    // A workgroup whose rows hold no solid cell in its strip marches WITHOUT the obstacle swap (round 6): the 32 selects and 4 compares
+    // per row and stage cost a lone wave 10-13 % (profiles/r05_experiments.txt sections 7, 20), and every way of skipping them per ROW
+    // has lost to the branch it takes (sections 8, 20).  Per workgroup the choice is two scalar loads at the entry: the host keeps, per
+    // strip, the running count of rows with a solid cell (lb_hip.cpp: mask_rows_rebuild); the rows this pair gathers obstacle flags
+    // for are [ya - (D - 1), yb + D - 2], wrapped where the box is periodic in y.  Same bits: the masked march over all-fluid cells
+    // selects what the unmasked one computes.  Both waves decide alike, their barriers stay matched.
+    bool clean = false;
+    if constexpr (MASK) {
+        static_assert(deep_valid(D) == 240 && deep_skirt_lanes(D) == 2, "the host's per-strip row counts are laid out for strips 240 apart, 8 early");
+        if (a.mask_rows) {
+            const int *P = a.mask_rows + (long long)sx * a.mask_rows_pitch + LB_MASK_HALO_ROWS;
+            auto solid_rows = [&](int lo, int hi) {                 // rows [lo, hi) of this strip that hold a solid cell
+                lo = max(lo, -LB_MASK_HALO_ROWS);
+                hi = min(hi, a.h + LB_MASK_HALO_ROWS);
+                return hi > lo ? P[hi] - P[lo] : 0;
+            };
+            const int lo = ya - (D - 1), hi = yb + (D - 1);
+            int n = solid_rows(lo, hi);
+            if (a.wrap_y == 1) {
+                if (lo < 0) n += solid_rows(lo + a.h, a.h);
+                if (hi > a.h) n += solid_rows(0, hi - a.h);
+            }
+            clean = __builtin_amdgcn_readfirstlane(n) == 0;
+        }
+    }
+    if (MASK && clean) {
+        if (wy == 0) deep_march<BC, false, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+        else deep_march<BC, false, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+    } else {
+        if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+        else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
+    }
 #ifdef LB_DIAG
     if ((a.diag & 4096) && threadIdx.x == 0) {
         // per-wave timeline into the (otherwise unused) rho array: start, end (100 MHz ticks), XCC id, HW id, item, rows (tools/wave_timeline.py)

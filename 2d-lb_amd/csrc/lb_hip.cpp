@@ -156,6 +156,11 @@ struct lb_sim {
     float *vi_corner = nullptr; // VELOCITY_INLET: the eight corner links nothing ever writes (bc_vel_cell), device
     uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
     bool has_mask = false;
+    // k_deep's mask-free march (kernels_deep.h): per strip of 256 columns (240 apart, 8 early) and row -MASK_GHOST .. H+MASK_GHOST-1
+    // "a solid cell here" on the host; on the device the running counts, [strips][H + 2 MASK_GHOST + 1] ints
+    std::vector<uint8_t> mask_row_flags;
+    int *mask_rows = nullptr;
+    int mask_strips = 0;
     int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
     bool macro_valid = true;    // rho,u,v hold the last step's fields (false: to be rebuilt from the populations, ensure_macro)
@@ -193,6 +198,12 @@ struct lb_sim {
     bool cyc_failed = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int diag = 0;
+    int forced_cycle = 0;       // slabs: depth of the fused kernel the halo cycle runs on, fixed by the caller (lb_set_slab_cycle); 0 = automatic
+    // lb_exchange_timing: a pair of timing events around every halo exchange of lb_run, on the stream that carries it
+    static constexpr int XT_RING = 256;
+    bool xt_on = false;
+    hipEvent_t xt_ev[2 * XT_RING] = {};
+    int xt_count = 0, xt_dropped = 0;
     int tuned_steps = 0;        // 0: not tuned; else the fused kernel depth (1..4) chosen by lb_autotune
     int tuned_wpc = 0;          // and its waves per CU for the marching kernels
     float depth_cost[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ms per launch of the d-step kernel as lb_autotune timed it (0: not timed): launch_costs
@@ -236,6 +247,9 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.src = s->origin(s->cur);
     a.dst = s->origin(s->cur ^ 1);
     a.mask = s->has_mask ? s->mask : nullptr;
+    static const bool no_clean = getenv("LB_MASK_CLEAN_PATH") && atoi(getenv("LB_MASK_CLEAN_PATH")) == 0;     // A/B switch
+    a.mask_rows = (s->has_mask && !no_clean) ? s->mask_rows : nullptr;
+    a.mask_rows_pitch = s->H + 2 * MASK_GHOST + 1;
     a.rho = s->rho; a.u = s->u; a.v = s->v;
     a.plane = s->plane; a.pitch = (int)s->rowp; a.fpitch = (int)s->pitch;
     a.nx = s->p.nx; a.ny = s->p.ny; a.y0 = s->p.y0; a.h = s->H;
@@ -881,7 +895,16 @@ int exchange_peer(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
 // halo of lattice `which` to the neighbours, by the transport this handle is attached to
 int exchange_halo(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
 {
-    return s->peer_connected ? exchange_peer(s, which, q, T) : exchange_rccl(s, which, q, T);
+    // (lb_exchange_timing: what an exchange takes on its stream -- pack / push, the transfer, the wait for the neighbours, unpack)
+    const bool timed = s->xt_on && s->xt_count < lb_sim::XT_RING;
+    if (s->xt_on && !timed) ++s->xt_dropped;
+    if (timed) HIP_TRY(hipEventRecord(s->xt_ev[2 * s->xt_count], q));
+    const int rc = s->peer_connected ? exchange_peer(s, which, q, T) : exchange_rccl(s, which, q, T);
+    if (timed && !rc) {
+        HIP_TRY(hipEventRecord(s->xt_ev[2 * s->xt_count + 1], q));
+        ++s->xt_count;
+    }
+    return rc;
 }
 
 // a wait of the peer transport gave up (the neighbour never arrived): reported once the device is idle
@@ -1006,6 +1029,11 @@ int cycle_depth(const lb_sim *s, int h)
 {
     const int v = effective_variant(s);
     if (!(v & 64) || (v & 128) || !step3_applicable(s, h) || h < 32) return 0;
+    // (lb_set_slab_cycle: the caller's choice -- the ranks of a run time the candidates together and agree, bench.py / slabs.py --
+    //  wherever that depth can run; elsewhere the automatic one)
+    if (s->forced_cycle >= 3 && s->forced_cycle <= MAX_DEPTH && h >= 16 * s->forced_cycle &&
+        !(s->forced_cycle >= 6 && s->p.bc_mode == LB_BC_VELOCITY_INLET))
+        return s->forced_cycle;
     // (k_deep on slabs, round 5: the fourteen- / twelve-step cycle, ghost zone as deep)
     if ((v & 32768) && (v & 16384) && (v & 4096) && (v & 256) && h >= 112) return 7;
     if ((v & 16384) && (v & 4096) && (v & 256) && h >= 96) return 6;
@@ -1625,6 +1653,8 @@ int lb_destroy(lb_sim *s)
     if (s->cyc_graph) (void)hipGraphDestroy(s->cyc_graph);
     for (hipEvent_t e : {s->ev_fork, s->ev_join})
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->xt_ev)
+        if (e) (void)hipEventDestroy(e);
     for (lb_sim::PeerNb &nb : s->peer_nb)
         if (nb.mapped) {
             (void)hipIpcCloseMemHandle(nb.flags);
@@ -1636,6 +1666,7 @@ int lb_destroy(lb_sim *s)
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner, s->stage})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
+    if (s->mask_rows) (void)hipFree(s->mask_rows);
     if (s->check_part) (void)hipFree(s->check_part);
     for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_t0, s->ev_t1})
         if (e) (void)hipEventDestroy(e);
@@ -1683,6 +1714,50 @@ int lb_set_variant(lb_sim *s, int variant)
     if (s && s->cpu) return LB_OK;                 // (one code path: nothing to select)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     s->variant = variant;
+    return LB_OK;
+}
+
+int lb_set_slab_cycle(lb_sim *s, int depth)
+{
+    if (s && s->cpu) return LB_OK;
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    if (depth != 0 && (depth < 3 || depth > MAX_DEPTH)) return fail(LB_ERR_ARG, "halo cycle depth must be 0 (automatic) or 3..%d, got %d", MAX_DEPTH, depth);
+    s->forced_cycle = depth;
+    return LB_OK;
+}
+
+int lb_exchange_timing(lb_sim *s, int enable)
+{
+    CPU_UNSUPPORTED(s, "lb_exchange_timing");
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    if (enable && !s->xt_ev[0])
+        for (hipEvent_t &e : s->xt_ev) HIP_TRY(hipEventCreate(&e));
+    s->xt_on = enable != 0;
+    s->xt_count = s->xt_dropped = 0;
+    return LB_OK;
+}
+
+int lb_exchange_stats(lb_sim *s, int64_t *n_exchanges, double *total_ms, double *max_ms, int *cycle_depth_out, int *band_rows)
+{
+    CPU_UNSUPPORTED(s, "lb_exchange_stats");
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    DeviceGuard guard(s->p.device);
+    double total = 0., mx = 0.;
+    for (int i = 0; i < s->xt_count; ++i) {
+        HIP_TRY(hipEventSynchronize(s->xt_ev[2 * i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->xt_ev[2 * i], s->xt_ev[2 * i + 1]));
+        total += ms;
+        mx = std::max(mx, (double)ms);
+    }
+    if (n_exchanges) *n_exchanges = s->xt_count;
+    if (total_ms) *total_ms = total;
+    if (max_ms) *max_ms = mx;
+    const int D = s->multi_slab() ? cycle_depth(s, s->min_h > 0 ? s->min_h : s->H) : 0;
+    if (cycle_depth_out) *cycle_depth_out = D;
+    if (band_rows) *band_rows = D ? 2 * D + band_extra(s, D) : 0;
+    s->xt_count = s->xt_dropped = 0;
     return LB_OK;
 }
 
@@ -1829,6 +1904,52 @@ int lb_get_feq(lb_sim *s, float *feq)
     return LB_OK;
 }
 
+// The per-strip row flags of rows [r0, r0 + nrows) (local rows; r0 may be negative: mask halo) from `rows` ([nrows][pitch] bytes, 1 =
+// solid), then the running counts on the device.  A strip's columns: [240 sx - 8, 240 sx + 248), through the box's ends where it is
+// periodic in x (a superset of what k_deep's lanes read there: only speed could depend on a flag too many).
+static int mask_rows_rebuild(lb_sim *s, const uint8_t *rows, int r0, int nrows)
+{
+    constexpr int VALID = 240, EARLY = 8;
+    const int nx = s->p.nx, R = s->H + 2 * MASK_GHOST;
+    const int strips = (nx + VALID - 1) / VALID;
+    if ((int)s->mask_row_flags.size() != strips * R) {
+        s->mask_row_flags.assign((size_t)strips * R, 0);
+        s->mask_strips = strips;
+        if (s->mask_rows) (void)hipFree(s->mask_rows);
+        s->mask_rows = nullptr;
+    }
+    const bool wrap_x = s->p.bc_mode == LB_BC_PERIODIC;
+    auto any = [&](const uint8_t *row, int lo, int hi) {     // a solid cell in columns [lo, hi) of the box
+        lo = std::max(lo, 0);
+        hi = std::min(hi, nx);
+        return hi > lo && memchr(row + lo, 1, (size_t)(hi - lo)) != nullptr;
+    };
+    for (int r = 0; r < nrows; ++r) {
+        const uint8_t *row = rows + (size_t)r * s->pitch;
+        for (int sx = 0; sx < strips; ++sx) {
+            const int lo = VALID * sx - EARLY, hi = lo + STRIP_W;
+            bool f = any(row, lo, hi);
+            if (wrap_x) f = f || any(row, lo + nx, hi + nx) || any(row, lo - nx, hi - nx);
+            s->mask_row_flags[(size_t)sx * R + (r0 + r + MASK_GHOST)] = f;
+        }
+    }
+    std::vector<int> run((size_t)strips * (R + 1));
+    for (int sx = 0; sx < strips; ++sx) {
+        int c = 0;
+        for (int j = 0; j < R; ++j) {
+            run[(size_t)sx * (R + 1) + j] = c;
+            c += s->mask_row_flags[(size_t)sx * R + j];
+        }
+        run[(size_t)sx * (R + 1) + R] = c;
+    }
+    if (!s->mask_rows) {
+        HIP_TRY(hipMalloc(&s->mask_rows, run.size() * sizeof(int)));
+        s->bytes += (int64_t)(run.size() * sizeof(int));
+    }
+    HIP_TRY(hipMemcpy(s->mask_rows, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice));
+    return LB_OK;
+}
+
 int lb_set_mask(lb_sim *s, const int32_t *mask)
 {
     if (s && s->cpu) {
@@ -1859,8 +1980,10 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     hipError_t e = hipStreamSynchronize(s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->edge_stream);
     if (e == hipSuccess) e = hipMemcpy(s->mask, tmp, n, hipMemcpyHostToDevice);
+    const int rc_rows = e == hipSuccess ? mask_rows_rebuild(s, tmp, 0, s->H) : LB_OK;
     free(tmp);
     if (e != hipSuccess) return fail(LB_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
+    if (rc_rows) return rc_rows;
     // An all-zero mask on one slab must still take the MASK kernel if the caller asked for a
     // mask: keep the flag (kernel choice is per handle, results are identical either way).
     (void)any;
@@ -1898,6 +2021,11 @@ int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_
         if (e != hipSuccess) {
             free(tmp);
             return fail(LB_ERR_HIP, "mask halo upload: %s", hipGetErrorString(e));
+        }
+        const int rc_rows = mask_rows_rebuild(s, tmp, side ? s->H : -MASK_GHOST, MASK_GHOST);
+        if (rc_rows) {
+            free(tmp);
+            return rc_rows;
         }
     }
     free(tmp);

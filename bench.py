@@ -464,8 +464,14 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
+    slab_tuning = None
     if dist is None:
         eng.autotune()                         # picks the fused-kernel configuration for this grid (untimed)
+    elif args.config == 4 and args.variant is None and hasattr(sim, "autotune"):
+        # slabs: the ranks time the halo cycle on each depth of the fused kernel together and agree (untimed, live steps)
+        slab_tuning = sim.autotune()
+    if dist is not None and hasattr(eng, "exchange_timing") and args.transport in ("rccl", "peer"):
+        eng.exchange_timing(True)
     copy_gbs = None
     if args.calibrate:
         copy_gbs = {"plain": round(eng.copy_calibration(args.calibrate, False)[0], 1),
@@ -492,6 +498,17 @@ def main():
         walls_incl.append(wall_incl)
         total += wall
     wall, ev_ms = statistics.median(walls), statistics.median(evs)
+    # per rank: what the halo exchanges of the timed blocks took on their stream (lb_exchange_stats), gathered on rank 0
+    per_rank = None
+    if dist is not None and hasattr(eng, "exchange_stats") and args.transport in ("rccl", "peer"):
+        st = eng.exchange_stats()
+        mine = torch.tensor([float(rank), float(h), float(st["n"]), st["total_ms"], st["max_ms"], float(st["cycle_depth"]),
+                             float(st["band_rows"]), statistics.median(evs)], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": int(t[0]), "rows": int(t[1]), "exchanges_timed": int(t[2]),
+                     "exchange_ms_mean": round(float(t[3]) / max(1.0, float(t[2])), 4), "exchange_ms_max": round(float(t[4]), 4),
+                     "cycle_depth": int(t[5]), "edge_band_rows": int(t[6])} for t in every]
 
     # ---- duration of ONE launch of the dominant kernel, for the roofline (outside the timed region) -----------
     # A run() ends with the launch that also stores rho, u, v (12 B per cell more, ~11 % longer at 8192^2), so the K-step
@@ -500,12 +517,14 @@ def main():
     # as the kernel's average (profiles/r02_rocprof_summary.md).
     plain_ms = macro_extra_ms = None
     if dist is None:
+        # (whole launches of the deepest kernel, at least four per run: with --steps 20 the 2 x 7 against 4 x 7 steps of round 5
+        #  differed by less than their noise and the probe rejected itself -- frac_plain_launch: null on the driver's line)
         spl_probe = eng.steps_per_launch()
-        q = max(1, args.steps // spl_probe)
-        t1 = statistics.median(sim.timed_run(spl_probe * q) for _ in range(5))
-        t2 = statistics.median(sim.timed_run(2 * spl_probe * q) for _ in range(5))
+        q = max(4, -(-args.steps // spl_probe))
+        t1 = statistics.median(sim.timed_run(spl_probe * q) for _ in range(7))
+        t2 = statistics.median(sim.timed_run(2 * spl_probe * q) for _ in range(7))
         a = (t2 - t1) / q
-        if 0.5 * t1 / q < a <= 1.02 * t1 / q:          # (else: keep the block average below)
+        if 0.5 * t1 / q < a <= 1.1 * t1 / q:           # (else: keep the block average below)
             plain_ms, macro_extra_ms = a, max(t1 - q * a, 0.0)
 
     # the six-step kernel beside the default (seven steps per launch since round 5): the launch the previous rounds' `frac` priced
@@ -578,12 +597,13 @@ def main():
                         % (bytes_per_cell, "" if bytes_per_cell == B_ALG else ", + 1 B obstacle mask")}
         # what the kernel is actually bound by since round 5: vector-ALU issue (profiles/r05_experiments.txt).  68 fp32 operations per
         # cell update as written (d2q9_cell.h: 23 of them FMAs) = 91 flop; the packed pipe's peak is the guide's fp32 vector figure.
-        flop_per_update, fp32_peak = 91.0, 157.3e12
+        # (round 6: omega enters once, through the density -- 60 operations per update instead of 68, d2q9_cell.h: equilibrate_t)
+        flop_per_update, fp32_peak = 83.0, 157.3e12
         compute = {"bound": "valu", "achieved": round(mlups * 1e6 * flop_per_update / 1e12, 2), "peak": fp32_peak / 1e12, "unit": "TFLOP/s",
                    "frac": round(mlups * 1e6 * flop_per_update / fp32_peak, 4),
-                   "note": "informational: %g flop per lattice update (68 fp32 operations, 23 of them FMAs, all issued as v_pk_*_f32) "
-                           "against the fp32 vector peak; the collision is %d of the %d instructions a wave issues per row"
-                           % (flop_per_update, 951, 1473)}
+                   "note": "informational: %g flop per lattice update (60 fp32 operations, 23 of them FMAs, all issued as v_pk_*_f32) "
+                           "against the fp32 vector peak; the collision is %d of the %d instructions a wave of k_deep<7> issues per row "
+                           "(tools/isa_stats.py)" % (flop_per_update, 839, 1342)}
         line = {
             "metric": "MLUPS (million lattice updates per second), fused D2Q9 BGK step",
             "value": round(mlups, 1), "unit": "MLUPS",
@@ -605,6 +625,11 @@ def main():
             "roofline": roof,
             "compute": compute,
         }
+        if per_rank is not None:
+            line["slabs"] = {"per_rank": per_rank, "cycle_tuning": slab_tuning,
+                             "note": "exchange_ms = one halo exchange on its stream (pack / push, transfer, wait for the neighbours, unpack; "
+                                     "lb_exchange_stats); the edge bands are cut so that their waves finish 8 iterations (~2 x 25 us per "
+                                     "cycle) before the interior's: an exchange longer than that delays the compute stream"}
         line["methodology"] = METHODOLOGY
         if copy_gbs is not None:
             line["copy_GBps"] = copy_gbs
@@ -616,7 +641,7 @@ def main():
             line["other_configs"] = []
             for c in (2, 3, 5):
                 try:
-                    line["other_configs"].append(measure_config(c, local_rank, 84, 14, args.min_blocks, args.min_timed_s))    # (84 = whole launches of every depth)
+                    line["other_configs"].append(measure_config(c, local_rank, 84, 14, args.min_blocks, args.min_timed_s))    # (84 = whole launches of depths 7, 6, 4, 3, 2, 1; k_step5 blocks end in a four-step launch)
                 except (Exception, SystemExit) as exc:             # noqa: BLE001 - a side line must not take the headline down
                     line["other_configs"].append({"config": c, "error": str(exc)})
             for path in ("opencl", "cython"):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 8
+#define LB_ABI_VERSION 9
 
 typedef enum {
     LB_OK = 0,
@@ -330,6 +330,21 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);
+/* Slab handles (round 6; new work, the reference is single-device: opencl_dim.py:229-240).  Depth of the fused kernel the halo cycle
+ * of lb_run runs on (the cycle is 2 x depth time steps between two exchanges): 0 = automatic (the size thresholds of
+ * lb_set_variant's bits 12, 14, 15), 3 ... 7 = that depth wherever the smallest slab of the run has >= 16 x depth rows.  Results
+ * never depend on it (bitwise); EVERY rank of a run must set the same value -- the ranks time the candidates together and agree
+ * (LB_D2Q9/slabs.py: DistributedSlab.autotune). */
+int lb_set_slab_cycle(lb_sim *s, int depth);
+/* Diagnosis of a multi-GPU run.  lb_exchange_timing(s, 1) brackets every halo exchange of lb_run with a pair of timing events on the
+ * stream that carries it (up to 256 exchanges between two queries; more are counted as dropped, not timed); lb_exchange_stats waits
+ * for the exchanges recorded so far and returns their number, their total and longest duration in milliseconds -- pack / push, the
+ * transfer, the wait for the neighbours' matching calls, unpack --, the depth of the halo cycle in use and the rows of one edge band
+ * of its second launch (2 x depth + the extra rows that keep the band's waves busy as long as the interior's, lb_hip.cpp:
+ * band_extra), then starts over.  An exchange longer than the head start the edge bands have over the interior delays the
+ * compute stream: bench.py --gpus N prints the figures per rank. */
+int lb_exchange_timing(lb_sim *s, int enable);
+int lb_exchange_stats(lb_sim *s, int64_t *n_exchanges, double *total_ms, double *max_ms, int *cycle_depth, int *band_rows);
 
 #ifdef __cplusplus
 }
