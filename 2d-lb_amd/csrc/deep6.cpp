@@ -10,8 +10,12 @@ template <int BC, bool MASK, bool MACRO>
 struct LD {
     static void go(const MarchLaunch &g, const StepArgs &a)
     {
-        hipLaunchKernelGGL((k_deep<BC, MASK, MACRO, 6, deep_rw(6), deep_pfd(6)>), g.grid, g.block, 0, g.stream, a, g.strips, g.seg_rows,
-                           g.nsegs, g.row_end);
+        // (LB_DEEP6_DEPTH: timing probes only -- another depth behind the six-step launcher; the host still counts six steps)
+#ifndef LB_DEEP6_DEPTH
+#define LB_DEEP6_DEPTH 6
+#endif
+        hipLaunchKernelGGL((k_deep<BC, MASK, MACRO, LB_DEEP6_DEPTH, deep_rw(LB_DEEP6_DEPTH), deep_pfd(LB_DEEP6_DEPTH)>), g.grid, g.block, 0,
+                           g.stream, a, g.strips, g.seg_rows, g.nsegs, g.row_end);
     }
 };
 

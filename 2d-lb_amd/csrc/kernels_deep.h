@@ -187,7 +187,10 @@ __device__ __forceinline__ void deep_row_load(const StepArgs &a, int r, int x4, 
 // between the two -- `s_waitcnt vmcnt(0..8)` where 9..18 would do: the wave drains what it has just issued and the gather "ahead"
 // hides nothing (SQ_WAIT_ANY 22 % of the wave cycles of k_deep<7>, profiles/r05_sq_deep7_8192.txt; a two-buffer loop of 30 lines
 // shows the same counts).  So the row in flight is hidden from the compiler altogether: its loads are issued by an asm block into a
-// FIXED window of accumulation registers, a[192:234], that the kernel uses for nothing else (tools/kernel_resources.py checks the
+// FIXED window of accumulation registers, a[0:42] (rounds 5: a[192:234] -- which made every wave ALLOCATE 235 accumulation registers
+// beside its ~230 vector registers: a SIMD's whole file, so that not even the 256-thread copy kernels of a halo exchange found a
+// place beside a marching wave; at the bottom of the file a wave takes ~280 of the 512, round 6), that the kernel uses for nothing else
+// -- it has no accumulation-register spills; the day it has, they start at a0 and the check below refuses the build -- (tools/check_agpr_window.py checks the
 // disassembly for strays), and taken out of it behind an `s_waitcnt vmcnt(N)` written here, N = the vector-memory instructions this
 // wave has issued since the row's last load -- the nine (MACRO: twelve) stores of the iteration in between, every steady iteration
 // issues them; none in the filling iterations --: vector-memory operations of a wave complete in issue order (loads and stores count
@@ -207,7 +210,7 @@ __device__ __forceinline__ u4v deep_rsrc_words(const float *p)
     return u4v{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)), (unsigned)DEEP_NUM_RECORDS,
                0x00020000u};
 }
-// issues row r's loads into a[192:227] (planes 0..8), a[228:233] (the seam lanes' wrap elements), a234 (obstacle flags); o: rr, have
+// issues row r's loads into a[0:35] (planes 0..8), a[36:41] (the seam lanes' wrap elements), a42 (obstacle flags); o: rr, have
 template <int BC, bool MASK>
 __device__ __forceinline__ void deep_row_issue(const StepArgs &a, int r, int x4, Row1 &o)
 {
@@ -224,34 +227,34 @@ __device__ __forceinline__ void deep_row_issue(const StepArgs &a, int r, int x4,
             const bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
             if (wrap_w) {
                 const float *e = s + a.nx - 1;
-                asm volatile("global_load_dword a228, %0, off\n\tglobal_load_dword a229, %1, off\n\tglobal_load_dword a230, %2, off"
+                asm volatile("global_load_dword a36, %0, off\n\tglobal_load_dword a37, %1, off\n\tglobal_load_dword a38, %2, off"
                              :: "v"(e + 1 * S + (long long)yl * P), "v"(e + 5 * S + (long long)ym * P), "v"(e + 8 * S + (long long)yp * P)
-                             : "memory", "a228", "a229", "a230");
+                             : "memory", "a36", "a37", "a38");
             }
             if (wrap_e) {
-                asm volatile("global_load_dword a231, %0, off\n\tglobal_load_dword a232, %1, off\n\tglobal_load_dword a233, %2, off"
+                asm volatile("global_load_dword a39, %0, off\n\tglobal_load_dword a40, %1, off\n\tglobal_load_dword a41, %2, off"
                              :: "v"(s + 3 * S + (long long)yl * P), "v"(s + 6 * S + (long long)ym * P), "v"(s + 7 * S + (long long)yp * P)
-                             : "memory", "a231", "a232", "a233");
+                             : "memory", "a39", "a40", "a41");
             }
         }
         const u4v r0 = deep_rsrc_words(s + (long long)yl * P - 1), rm = deep_rsrc_words(s + (long long)ym * P - 1),
                   rp = deep_rsrc_words(s + (long long)yp * P - 1);
         const unsigned S4 = (unsigned)a.plane * 4u;
-        asm volatile("buffer_load_dwordx4 a[192:195], %0, %1, 0 offen offset:4\n\t"
-                     "buffer_load_dwordx4 a[196:199], %0, %1, %4 offen\n\t"
-                     "buffer_load_dwordx4 a[200:203], %0, %2, %5 offen offset:4\n\t"
-                     "buffer_load_dwordx4 a[204:207], %0, %1, %6 offen offset:8\n\t"
-                     "buffer_load_dwordx4 a[208:211], %0, %3, %7 offen offset:4\n\t"
-                     "buffer_load_dwordx4 a[212:215], %0, %2, %8 offen\n\t"
-                     "buffer_load_dwordx4 a[216:219], %0, %2, %9 offen offset:8\n\t"
-                     "buffer_load_dwordx4 a[220:223], %0, %3, %10 offen offset:8\n\t"
-                     "buffer_load_dwordx4 a[224:227], %0, %3, %11 offen"
+        asm volatile("buffer_load_dwordx4 a[0:3], %0, %1, 0 offen offset:4\n\t"
+                     "buffer_load_dwordx4 a[4:7], %0, %1, %4 offen\n\t"
+                     "buffer_load_dwordx4 a[8:11], %0, %2, %5 offen offset:4\n\t"
+                     "buffer_load_dwordx4 a[12:15], %0, %1, %6 offen offset:8\n\t"
+                     "buffer_load_dwordx4 a[16:19], %0, %3, %7 offen offset:4\n\t"
+                     "buffer_load_dwordx4 a[20:23], %0, %2, %8 offen\n\t"
+                     "buffer_load_dwordx4 a[24:27], %0, %2, %9 offen offset:8\n\t"
+                     "buffer_load_dwordx4 a[28:31], %0, %3, %10 offen offset:8\n\t"
+                     "buffer_load_dwordx4 a[32:35], %0, %3, %11 offen"
                      :: "v"(x4 * 4), "s"(r0), "s"(rm), "s"(rp), "s"(S4), "s"(2u * S4), "s"(3u * S4), "s"(4u * S4), "s"(5u * S4), "s"(6u * S4),
                         "s"(7u * S4), "s"(8u * S4)
-                     : "memory", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205",
-                       "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220",
-                       "a221", "a222", "a223", "a224", "a225", "a226", "a227");
-        if (MASK) asm volatile("global_load_dword a234, %0, off" :: "v"(lane_ptr(a.mask + (long long)yl * a.fpitch, x4)) : "memory", "a234");
+                     : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13",
+                       "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28",
+                       "a29", "a30", "a31", "a32", "a33", "a34", "a35");
+        if (MASK) asm volatile("global_load_dword a42, %0, off" :: "v"(lane_ptr(a.mask + (long long)yl * a.fpitch, x4)) : "memory", "a42");
     }
 }
 // the row issued last: waits until all but the wave's N youngest vector-memory operations are done, then takes it out of the window
@@ -259,8 +262,8 @@ template <int BC, bool MASK, int N>
 __device__ __forceinline__ void deep_row_take(Row1 &o)
 {
     static_assert(N == 0 || N == 9 || N == 12, "the stores of one steady iteration, or nothing");
-#define LB_DEEP_TAKE_OUTS "={a[192:195]}"(o.q[0]), "={a[196:199]}"(o.q[1]), "={a[200:203]}"(o.q[2]), "={a[204:207]}"(o.q[3]), \
-                          "={a[208:211]}"(o.q[4]), "={a[212:215]}"(o.q[5]), "={a[216:219]}"(o.q[6]), "={a[220:223]}"(o.q[7]), "={a[224:227]}"(o.q[8])
+#define LB_DEEP_TAKE_OUTS "={a[0:3]}"(o.q[0]), "={a[4:7]}"(o.q[1]), "={a[8:11]}"(o.q[2]), "={a[12:15]}"(o.q[3]), \
+                          "={a[16:19]}"(o.q[4]), "={a[20:23]}"(o.q[5]), "={a[24:27]}"(o.q[6]), "={a[28:31]}"(o.q[7]), "={a[32:35]}"(o.q[8])
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" : LB_DEEP_TAKE_OUTS :: "memory");
 #ifdef LB_DEEP_TIMING_NO_WAIT                        // timing only, wrong results: what the wait itself costs
     else if (N == 9) asm volatile("s_waitcnt vmcnt(63)" : LB_DEEP_TAKE_OUTS :: "memory");
@@ -270,11 +273,11 @@ __device__ __forceinline__ void deep_row_take(Row1 &o)
 #undef LB_DEEP_TAKE_OUTS
     o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (BC == LB_BC_PERIODIC)
-        asm volatile("" : "={a228}"(o.wp.p1), "={a229}"(o.wp.p5), "={a230}"(o.wp.p8), "={a231}"(o.wp.w3), "={a232}"(o.wp.w6), "={a233}"(o.wp.w7));
+        asm volatile("" : "={a36}"(o.wp.p1), "={a37}"(o.wp.p5), "={a38}"(o.wp.p8), "={a39}"(o.wp.w3), "={a40}"(o.wp.w6), "={a41}"(o.wp.w7));
     o.mk = uc4{0, 0, 0, 0};
     if (MASK) {
         unsigned m;
-        asm volatile("" : "={a234}"(m));
+        asm volatile("" : "={a42}"(m));
         o.mk = __builtin_bit_cast(uc4, m);
     }
     if (!o.have) {                                      // (a row outside a walled box: nothing was issued)
@@ -467,8 +470,13 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
 
 // Launch geometry as k_step5 / k_step6: one workgroup = one segment pair of one strip (two waves), XCD-transposed order, shorter
 // segments for the two wall-column strips.  LDS: (D - 1 - RW) x 8 KiB per wave.
+// (LB_DEEP_OCC2: timing probes only -- two workgroups per SIMD pair where the depth's registers and LDS allow it, e.g. D = 4:
+//  tools/r06/occ2_probe.sh, profiles/r06_experiments.txt section 5)
+#ifndef LB_DEEP_OCC2
+#define LB_DEEP_OCC2 0
+#endif
 template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD>
-__global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+__global__ __launch_bounds__(64 * STEP4_WAVES, ((PFD && !LB_DEEP_OCC2) ? 1 : 2)) void k_deep(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     __shared__ f4a lds_win[STEP4_WAVES][(D - 1 - RW) * DEEP_WSLOTS][64];
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -493,38 +501,14 @@ __global__ __launch_bounds__(64 * STEP4_WAVES, (PFD ? 1 : 2)) void k_deep(const 
     const int yb = min(ya + seg_rows, row_end);
     const int ym = ya + (yb - ya) / 2;                  // the pair's middle line: wave 0 marches down from it, wave 1 up
     const int x0 = sx * deep_valid(D) - 4 * deep_skirt_lanes(D);
-    // A workgroup whose rows hold no solid cell in its strip marches WITHOUT the obstacle swap (round 6): the 32 selects and 4 compares
-    // per row and stage cost a lone wave 10-13 % (profiles/r05_experiments.txt sections 7, 20), and every way of skipping them per ROW
-    // has lost to the branch it takes (sections 8, 20).  Per workgroup the choice is two scalar loads at the entry: the host keeps, per
-    // strip, the running count of rows with a solid cell (lb_hip.cpp: mask_rows_rebuild); the rows this pair gathers obstacle flags
-    // for are [ya - (D - 1), yb + D - 2], wrapped where the box is periodic in y.  Same bits: the masked march over all-fluid cells
-    // selects what the unmasked one computes.  Both waves decide alike, their barriers stay matched.
-    bool clean = false;
-    if constexpr (MASK) {
-        static_assert(deep_valid(D) == 240 && deep_skirt_lanes(D) == 2, "the host's per-strip row counts are laid out for strips 240 apart, 8 early");
-        if (a.mask_rows) {
-            const int *P = a.mask_rows + (long long)sx * a.mask_rows_pitch + LB_MASK_HALO_ROWS;
-            auto solid_rows = [&](int lo, int hi) {                 // rows [lo, hi) of this strip that hold a solid cell
-                lo = max(lo, -LB_MASK_HALO_ROWS);
-                hi = min(hi, a.h + LB_MASK_HALO_ROWS);
-                return hi > lo ? P[hi] - P[lo] : 0;
-            };
-            const int lo = ya - (D - 1), hi = yb + (D - 1);
-            int n = solid_rows(lo, hi);
-            if (a.wrap_y == 1) {
-                if (lo < 0) n += solid_rows(lo + a.h, a.h);
-                if (hi > a.h) n += solid_rows(0, hi - a.h);
-            }
-            clean = __builtin_amdgcn_readfirstlane(n) == 0;
-        }
-    }
-    if (MASK && clean) {
-        if (wy == 0) deep_march<BC, false, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
-        else deep_march<BC, false, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
-    } else {
-        if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
-        else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
-    }
+    // (Round 6 let a workgroup whose rows hold no solid cell in its strip -- two scalar loads of per-strip running counts kept by the
+    //  host -- take the march WITHOUT the obstacle swap, inside the same kernel: its loop is 235 instructions per row shorter (2381
+    //  against 2616 in a walled kernel), and it bought nothing: the reference's 3751 x 1251 pipe + disc 256 against 259 k MLUPS, pipe +
+    //  disc 4096^2 331 / 329, config 5's image 331 / 329, cavity + disc 6144^2 382 against 397 k (-4 %), periodic + random mask (no clean
+    //  workgroup) 423 / 423 -- the kernel grows from 26 to 46 thousand instructions, and two CUs whose four workgroups are not all of one
+    //  kind run 80 KB of steady loops through a 64 KB instruction cache.  profiles/r06_experiments.txt section 4; commit 64f91cf has the code.)
+    if (wy == 0) deep_march<BC, MASK, MACRO, D, RW, PFD, true>(a, x0, ym, ym - ya, lds_win[0], lds_win[1]);
+    else deep_march<BC, MASK, MACRO, D, RW, PFD, false>(a, x0, ym, yb - ym, lds_win[1], lds_win[0]);
 #ifdef LB_DIAG
     if ((a.diag & 4096) && threadIdx.x == 0) {
         // per-wave timeline into the (otherwise unused) rho array: start, end (100 MHz ticks), XCC id, HW id, item, rows (tools/wave_timeline.py)

@@ -32,8 +32,6 @@ struct StepArgs {
     float omega, rho_in, rho_out, lid_u, rho0;
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)
-    const int *mask_rows;  // k_deep with a mask: per strip of 256 columns (240 apart, 8 early) the number of rows BELOW row r that hold a
-    int mask_rows_pitch;   //   solid cell there, r = -LB_MASK_HALO_ROWS .. h + LB_MASK_HALO_ROWS (one int each, + 1): lb_hip.cpp, mask_rows_rebuild
 };
 
 // several lattices of one geometry advanced by one launch (k_step_batch)

@@ -156,18 +156,13 @@ struct lb_sim {
     float *vi_corner = nullptr; // VELOCITY_INLET: the eight corner links nothing ever writes (bc_vel_cell), device
     uint8_t *mask_raw = nullptr, *mask = nullptr;   // [H+2*MASK_GHOST][pitch] + guards; mask -> row 0
     bool has_mask = false;
-    // k_deep's mask-free march (kernels_deep.h): per strip of 256 columns (240 apart, 8 early) and row -MASK_GHOST .. H+MASK_GHOST-1
-    // "a solid cell here" on the host; on the device the running counts, [strips][H + 2 MASK_GHOST + 1] ints
-    std::vector<uint8_t> mask_row_flags;
-    int *mask_rows = nullptr;
-    int mask_strips = 0;
     int cu_count = 256;
     bool feq_valid = false;     // feq buffer consistent with rho,u,v
     bool macro_valid = true;    // rho,u,v hold the last step's fields (false: to be rebuilt from the populations, ensure_macro)
     CheckPartial *check_part = nullptr;   // one partial per workgroup of k_macro_check (+ the folded result behind them)
     long long check_cap = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, comm_stream = nullptr, edge_stream = nullptr;
-    hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_packed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_interior = nullptr, ev_halo = nullptr, ev_packed = nullptr, ev_edge = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     int min_h = 0;              // smallest slab height over the ranks (every rank must pick the same schedule)
@@ -247,9 +242,6 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.src = s->origin(s->cur);
     a.dst = s->origin(s->cur ^ 1);
     a.mask = s->has_mask ? s->mask : nullptr;
-    static const bool no_clean = getenv("LB_MASK_CLEAN_PATH") && atoi(getenv("LB_MASK_CLEAN_PATH")) == 0;     // A/B switch
-    a.mask_rows = (s->has_mask && !no_clean) ? s->mask_rows : nullptr;
-    a.mask_rows_pitch = s->H + 2 * MASK_GHOST + 1;
     a.rho = s->rho; a.u = s->u; a.v = s->v;
     a.plane = s->plane; a.pitch = (int)s->rowp; a.fpitch = (int)s->pitch;
     a.nx = s->p.nx; a.ny = s->p.ny; a.y0 = s->p.y0; a.h = s->H;
@@ -1062,14 +1054,33 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
 // slabs: 48 iterations per wave where 44 do; profiles/r05_slab_proxy_final.txt).  Nothing in the cycle's data flow fixes where the
 // band ends: with bands B rows thicker -- E1: [-D, D+B), C1: [D+B, H-D-B); E2: [0, 2D+B), C2: [2D+B, H-2D-B) -- E1 still reads
 // exactly what E2 and the exchange wrote, C2 only what C1 wrote, E2 waits for C1 and the next C1 for E2, as before.  B is chosen so
-// that a band wave's march (x the wall-column strips' cost in a walled box) ends `slack` iterations before an interior wave's: the
-// edge stream also carries the exchange, the compute stream must never wait for it.  Rank-local: the neighbours need not agree.
-// LB_BAND_EXTRA=<rows> fixes B (0 = the bands of rounds 3-5), LB_BAND_SLACK=<iterations> the head start.
-int band_extra(const lb_sim *s, int D)
+// that a band wave's march (x the wall-column strips' cost in a walled box) ends `slack` iterations before an interior wave's.
+// Rank-local: the neighbours need not agree.
+//
+// Split bands (the default in lb_run).  With thick bands the exchange -- on the edge stream between E2 and the next E1 -- had only that
+// head start to complete in: enough for the peer transport's one push kernel (one box, k MLUPS per GPU, bands of round 5 | thick:
+// 8192 x 1024 rows 378 | 393, x 2048 419 | 453, x 4096 442 | 476 = the plain grid's rate), not for RCCL's pack, send / receive and unpack
+// (371 | 315, 416 | 372, 442 | 339: profiles/r06_slab_proxy_bands.txt).  But only the OUTER 2D rows of a band have to do with the exchange:
+//   E2a  rows [0, 2D)        the rows the halo is cut from        -> ev_edge -> the exchange, on the communication stream
+//   E2b  rows [2D, 2D+B)     meanwhile, on the edge stream
+//   E1b  rows [D, D+B)       of the next cycle: reads rows [0, 2D+B) only, no ghost row -- does not wait for the exchange
+//   E1a  rows [-D, D)        the one launch that reads the ghost rows: waits for ev_halo
+// so the exchange has from the end of E2a to the start of E1a, more than a whole launch, and every workgroup slot stays busy.
+// LB_BAND_EXTRA=<rows> fixes B (0 = the bands of rounds 3-5), LB_BAND_SLACK=<iterations> the head start, LB_SPLIT_BANDS=0 keeps
+// each band one launch (lb_run_group and the captured cycles always do).
+bool split_bands()
+{
+    static const bool on = !(getenv("LB_SPLIT_BANDS") && atoi(getenv("LB_SPLIT_BANDS")) == 0);
+    return on;
+}
+
+int band_extra(const lb_sim *s, int D, bool split = false)
 {
     if (D < 4) return 0;                                // (k_step2 / k_step3: one wave per strip and band, a few rows: as they were)
     static const int fixed = getenv("LB_BAND_EXTRA") ? atoi(getenv("LB_BAND_EXTRA")) : -1;         // tuning knobs
-    static const double slack = getenv("LB_BAND_SLACK") ? atof(getenv("LB_BAND_SLACK")) : 8.0;
+    static const double slack_env = getenv("LB_BAND_SLACK") ? atof(getenv("LB_BAND_SLACK")) : -1.0;
+    // (one launch per band: the exchange must fit into the head start; split: only the launch gaps of the two parts do)
+    const double slack = slack_env >= 0.0 ? slack_env : (split ? 3.0 : 8.0);
     const int H = s->H;
     const int room = (H - 4 * D) / 2 - 8;               // the interior of the second launch keeps at least 16 rows
     if (room <= 0) return 0;
@@ -1080,7 +1091,8 @@ int band_extra(const lb_sim *s, int D)
     const double cost = s->p.bc_mode == LB_BC_PERIODIC ? 1.0 : (D >= 6 ? 2.1 : 1.2);    // a wall-column strip's rows (launch_step2)
     int B = 0;
     for (int b = 2; b <= room; b += 2) {
-        const double band = cost * ((2 * D + b) / 2.0 + (D - 1)) + slack;
+        // a band wave's iterations: the band as one march of (2D + b) / 2 rows per wave, or -- split -- two marches, D and b / 2 rows
+        const double band = cost * (split ? (D + (D - 1)) + (b / 2.0 + (D - 1)) : (2 * D + b) / 2.0 + (D - 1)) + slack;
         const double inner = (double)((H - 4 * D - 2 * b + segs - 1) / segs) / 2.0 + (D - 1);
         if (band > inner) break;
         B = b;
@@ -1090,31 +1102,47 @@ int band_extra(const lb_sim *s, int D)
 
 // E1 + C1 (the caller flips cur afterwards); D = depth of the fused kernel (3 or 4).  last = this launch ends the run:
 // rho,u,v are stored and the ghost rows are not recomputed (nothing will consume them; the MACRO epilogue has no rows
-// outside the slab to write to).
-int slab_cycle_first(lb_sim *s, int D, bool last = false)
+// outside the slab to write to).  split: the bands in two launches, the outer one behind the exchange on the communication
+// stream (ev_halo); else the caller has put the exchange on the edge stream itself.
+int slab_cycle_first(lb_sim *s, int D, bool last = false, bool split = false)
 {
     const int H = s->H, strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     const StepArgs probe = step_args(s, 0, 1, 1);
     const bool macro = last && !lazy_macro(s);
-    const int B = band_extra(s, D);
-    int rc = launch_bands(s, s->edge_stream, (probe.ghost_s && !last) ? -D : 0, D + B, H - D - B, (probe.ghost_n && !last) ? H + D : H,
-                          macro, D);
-    if (rc) return rc;
+    const int B = band_extra(s, D, split);
+    const int lo = (probe.ghost_s && !last) ? -D : 0, hi = (probe.ghost_n && !last) ? H + D : H;
+    int rc;
+    if (split && B > 0) {
+        if ((rc = launch_bands(s, s->edge_stream, D, D + B, H - D - B, H - D, macro, D))) return rc;      // E1b
+        HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
+        if ((rc = launch_bands(s, s->edge_stream, lo, D, H - D, hi, macro, D))) return rc;                 // E1a
+    } else {
+        if (split) HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
+        if ((rc = launch_bands(s, s->edge_stream, lo, D + B, H - D - B, hi, macro, D))) return rc;
+    }
     // (wave slots left to the band launch running beside it: two bands x strips items, two waves each under k_step4)
     if ((rc = launch_step2(s, s->stream, D + B, H - D - B, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D))) return rc;
     HIP_TRY(hipEventRecord(s->ev_interior, s->stream));
     return LB_OK;
 }
 
-// E2 + C2 (the caller flips cur afterwards); ev_boundary = the 2D edge rows of the new lattice are complete
-int slab_cycle_second(lb_sim *s, bool macro, int D)
+// E2 + C2 (the caller flips cur afterwards); ev_edge = the 2D edge rows of the new lattice are complete (the exchange may start),
+// ev_boundary = all of the bands' rows are (the next C1 may)
+int slab_cycle_second(lb_sim *s, bool macro, int D, bool split = false)
 {
     const int H = s->H, strips = D >= 6 ? deep_strips(s->p.nx, D) : (D == 5 ? step5_strips(s->p.nx) : (s->p.nx + STRIP_W - 1) / STRIP_W);
     macro = macro && !lazy_macro(s);
-    const int B = band_extra(s, D);
+    const int B = band_extra(s, D, split);
     HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
-    int rc = launch_bands(s, s->edge_stream, 0, 2 * D + B, H - 2 * D - B, H, macro, D);
-    if (rc) return rc;
+    int rc;
+    if (split && B > 0) {
+        if ((rc = launch_bands(s, s->edge_stream, 0, 2 * D, H - 2 * D, H, macro, D))) return rc;                              // E2a
+        HIP_TRY(hipEventRecord(s->ev_edge, s->edge_stream));
+        if ((rc = launch_bands(s, s->edge_stream, 2 * D, 2 * D + B, H - 2 * D - B, H - 2 * D, macro, D))) return rc;          // E2b
+    } else {
+        if ((rc = launch_bands(s, s->edge_stream, 0, 2 * D + B, H - 2 * D - B, H, macro, D))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_edge, s->edge_stream));
+    }
     HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));
     return launch_step2(s, s->stream, 2 * D + B, H - 2 * D - B, macro, 0, 0, 0, 2 * strips * (D >= 4 ? STEP4_WAVES : 1), D);
 }
@@ -1598,6 +1626,7 @@ int lb_create(const lb_params *p, lb_sim **out)
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_halo, ev_flags));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_interior, ev_flags));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_packed, ev_flags));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_edge, ev_flags));
     CREATE_TRY(hipEventCreate(&s->ev_t0));
     CREATE_TRY(hipEventCreate(&s->ev_t1));
     const size_t lat_bytes = sizeof(float) * s->lat_floats;
@@ -1666,9 +1695,8 @@ int lb_destroy(lb_sim *s)
     for (float *p : {s->lat[0], s->lat[1], s->feq, s->rho, s->u, s->v, s->halo_buf, s->vi_corner, s->stage})
         if (p) (void)hipFree(p);
     if (s->mask_raw) (void)hipFree(s->mask_raw);
-    if (s->mask_rows) (void)hipFree(s->mask_rows);
     if (s->check_part) (void)hipFree(s->check_part);
-    for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_t0, s->ev_t1})
+    for (hipEvent_t e : {s->ev_boundary, s->ev_interior, s->ev_halo, s->ev_packed, s->ev_edge, s->ev_t0, s->ev_t1})
         if (e) (void)hipEventDestroy(e);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
@@ -1756,7 +1784,7 @@ int lb_exchange_stats(lb_sim *s, int64_t *n_exchanges, double *total_ms, double 
     if (max_ms) *max_ms = mx;
     const int D = s->multi_slab() ? cycle_depth(s, s->min_h > 0 ? s->min_h : s->H) : 0;
     if (cycle_depth_out) *cycle_depth_out = D;
-    if (band_rows) *band_rows = D ? 2 * D + band_extra(s, D) : 0;
+    if (band_rows) *band_rows = D ? 2 * D + band_extra(s, D, split_bands()) : 0;
     s->xt_count = s->xt_dropped = 0;
     return LB_OK;
 }
@@ -1904,52 +1932,6 @@ int lb_get_feq(lb_sim *s, float *feq)
     return LB_OK;
 }
 
-// The per-strip row flags of rows [r0, r0 + nrows) (local rows; r0 may be negative: mask halo) from `rows` ([nrows][pitch] bytes, 1 =
-// solid), then the running counts on the device.  A strip's columns: [240 sx - 8, 240 sx + 248), through the box's ends where it is
-// periodic in x (a superset of what k_deep's lanes read there: only speed could depend on a flag too many).
-static int mask_rows_rebuild(lb_sim *s, const uint8_t *rows, int r0, int nrows)
-{
-    constexpr int VALID = 240, EARLY = 8;
-    const int nx = s->p.nx, R = s->H + 2 * MASK_GHOST;
-    const int strips = (nx + VALID - 1) / VALID;
-    if ((int)s->mask_row_flags.size() != strips * R) {
-        s->mask_row_flags.assign((size_t)strips * R, 0);
-        s->mask_strips = strips;
-        if (s->mask_rows) (void)hipFree(s->mask_rows);
-        s->mask_rows = nullptr;
-    }
-    const bool wrap_x = s->p.bc_mode == LB_BC_PERIODIC;
-    auto any = [&](const uint8_t *row, int lo, int hi) {     // a solid cell in columns [lo, hi) of the box
-        lo = std::max(lo, 0);
-        hi = std::min(hi, nx);
-        return hi > lo && memchr(row + lo, 1, (size_t)(hi - lo)) != nullptr;
-    };
-    for (int r = 0; r < nrows; ++r) {
-        const uint8_t *row = rows + (size_t)r * s->pitch;
-        for (int sx = 0; sx < strips; ++sx) {
-            const int lo = VALID * sx - EARLY, hi = lo + STRIP_W;
-            bool f = any(row, lo, hi);
-            if (wrap_x) f = f || any(row, lo + nx, hi + nx) || any(row, lo - nx, hi - nx);
-            s->mask_row_flags[(size_t)sx * R + (r0 + r + MASK_GHOST)] = f;
-        }
-    }
-    std::vector<int> run((size_t)strips * (R + 1));
-    for (int sx = 0; sx < strips; ++sx) {
-        int c = 0;
-        for (int j = 0; j < R; ++j) {
-            run[(size_t)sx * (R + 1) + j] = c;
-            c += s->mask_row_flags[(size_t)sx * R + j];
-        }
-        run[(size_t)sx * (R + 1) + R] = c;
-    }
-    if (!s->mask_rows) {
-        HIP_TRY(hipMalloc(&s->mask_rows, run.size() * sizeof(int)));
-        s->bytes += (int64_t)(run.size() * sizeof(int));
-    }
-    HIP_TRY(hipMemcpy(s->mask_rows, run.data(), run.size() * sizeof(int), hipMemcpyHostToDevice));
-    return LB_OK;
-}
-
 int lb_set_mask(lb_sim *s, const int32_t *mask)
 {
     if (s && s->cpu) {
@@ -1980,10 +1962,8 @@ int lb_set_mask(lb_sim *s, const int32_t *mask)
     hipError_t e = hipStreamSynchronize(s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->edge_stream);
     if (e == hipSuccess) e = hipMemcpy(s->mask, tmp, n, hipMemcpyHostToDevice);
-    const int rc_rows = e == hipSuccess ? mask_rows_rebuild(s, tmp, 0, s->H) : LB_OK;
     free(tmp);
     if (e != hipSuccess) return fail(LB_ERR_HIP, "mask upload: %s", hipGetErrorString(e));
-    if (rc_rows) return rc_rows;
     // An all-zero mask on one slab must still take the MASK kernel if the caller asked for a
     // mask: keep the flag (kernel choice is per handle, results are identical either way).
     (void)any;
@@ -2021,11 +2001,6 @@ int lb_set_mask_halo(lb_sim *s, const int32_t *south_rows, const int32_t *north_
         if (e != hipSuccess) {
             free(tmp);
             return fail(LB_ERR_HIP, "mask halo upload: %s", hipGetErrorString(e));
-        }
-        const int rc_rows = mask_rows_rebuild(s, tmp, side ? s->H : -MASK_GHOST, MASK_GHOST);
-        if (rc_rows) {
-            free(tmp);
-            return rc_rows;
         }
     }
     free(tmp);
@@ -2250,15 +2225,22 @@ int lb_halo_floats(lb_sim *s)
 namespace {
 constexpr int CYCLE_GRAPH_CYCLES = 4;
 
-// one halo cycle: E1 + C1, E2 + C2, exchange of the 2D edge rows (see slab_cycle_first)
-int slab_cycle_one(lb_sim *s, int D, bool last_of_run, const HaloTables &T)
+// one halo cycle: E1 + C1, E2 + C2, exchange of the 2D edge rows (see slab_cycle_first).  split: the exchange on the communication
+// stream, behind the outer part of E2 (ev_edge) and in front of the outer part of the next E1 (ev_halo).
+int slab_cycle_one(lb_sim *s, int D, bool last_of_run, const HaloTables &T, bool split)
 {
     int rc;
-    if ((rc = slab_cycle_first(s, D))) return rc;
+    if ((rc = slab_cycle_first(s, D, false, split))) return rc;
     s->cur ^= 1;
-    if ((rc = slab_cycle_second(s, last_of_run, D))) return rc;
+    if ((rc = slab_cycle_second(s, last_of_run, D, split))) return rc;
     s->cur ^= 1;
-    if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
+    if (split) {
+        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_edge, 0));
+        if ((rc = exchange_halo(s, s->cur, s->comm_stream, T))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
+    } else {
+        if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
+    }
     HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
     return LB_OK;
 }
@@ -2295,7 +2277,7 @@ int slab_cycle_graph(lb_sim *s, int D, const HaloTables &T)
         const int cur0 = s->cur;
         hipError_t e = hipEventRecord(s->ev_fork, s->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(s->edge_stream, s->ev_fork, 0);
-        for (int c = 0; c < CYCLE_GRAPH_CYCLES && !rc && e == hipSuccess; ++c) rc = slab_cycle_one(s, D, false, T);
+        for (int c = 0; c < CYCLE_GRAPH_CYCLES && !rc && e == hipSuccess; ++c) rc = slab_cycle_one(s, D, false, T, false);
         if (e == hipSuccess) e = hipEventRecord(s->ev_join, s->edge_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev_join, 0);
         s->cur = cur0;
@@ -2424,13 +2406,20 @@ int lb_run(lb_sim *s, int n_steps)
             left -= 2 * D * CYCLE_GRAPH_CYCLES;
             s->ghost_depth = 2 * D;
         }
+        // (the exchanges of the cycles below run on the communication stream, each behind the outer edge rows of its cycle and in front
+        //  of the next cycle's; whatever the edge stream has done so far -- the exchange above -- precedes the first of them)
+        const bool split = split_bands();
+        if (split) {
+            HIP_TRY(hipEventRecord(s->ev_halo, s->edge_stream));
+            HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_halo, 0));
+        }
         for (; left >= 2 * D; left -= 2 * D) {
-            if ((rc = slab_cycle_one(s, D, left == 2 * D, T))) return rc;
+            if ((rc = slab_cycle_one(s, D, left == 2 * D, T, split))) return rc;
             s->ghost_depth = 2 * D;
         }
         if (left >= D) {
             const bool last = (left == D);
-            if ((rc = slab_cycle_first(s, D, last))) return rc;
+            if ((rc = slab_cycle_first(s, D, last, split))) return rc;
             HIP_TRY(hipEventRecord(s->ev_boundary, s->edge_stream));      // the edge bands of the new lattice are complete
             s->cur ^= 1;
             left -= D;
@@ -2438,6 +2427,8 @@ int lb_run(lb_sim *s, int n_steps)
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_boundary, 0));
             HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_interior, 0));
         }
+        // (whatever follows on the edge stream follows the last exchange of the cycles)
+        if (split) HIP_TRY(hipStreamWaitEvent(s->edge_stream, s->ev_halo, 0));
     }
     if (left > 0 && s->ghost_depth < 3) {
         // ghost rows of the current lattice: exchange once before the first step

@@ -34,13 +34,13 @@ def test_the_checker_sees_a_stray_and_a_miscount():
     """the checker itself: a made-up disassembly with one instruction writing the window, and a kernel one store short"""
     tool = _tool()
     good = ["0000000000001000 <k_deep_ok>:"]
-    good += ["\tbuffer_load_dwordx4 a[%d:%d], v1, s[0:3], 0 offen // 000000001000: 00" % (192 + 4 * k, 195 + 4 * k) for k in range(9)]
-    good += ["\ts_waitcnt vmcnt(9) // 000000001100: 00", "\tv_accvgpr_read_b32 v5, a192 // 000000001104: 00"]
+    good += ["\tbuffer_load_dwordx4 a[%d:%d], v1, s[0:3], 0 offen // 000000001000: 00" % (tool.LO + 4 * k, tool.LO + 3 + 4 * k) for k in range(9)]
+    good += ["\ts_waitcnt vmcnt(9) // 000000001100: 00", "\tv_accvgpr_read_b32 v5, a%d // 000000001104: 00" % tool.LO]
     good += ["\tbuffer_store_dwordx4 v[0:3], v1, s[0:3], 0 offen nt // 000000001200: 00"] * 9
     good += ["\tbuffer_store_dwordx4 v[0:3], v1, s[0:3], 0 offen // 000000001300: 00"] * 9
     text = "\n".join(good)
     assert tool.check(None, text) == (9, 1, []) and tool.check_waits(None, text) == (1, [])
-    stray = text + "\n\tv_accvgpr_write_b32 a200, v3 // 000000001400: 00"
+    stray = text + "\n\tv_accvgpr_write_b32 a%d, v3" % (tool.LO + 8) + "  // 000000001400: 00"
     assert len(tool.check(None, stray)[2]) == 1
     short = "\n".join(good[:-1])
     assert len(tool.check_waits(None, short)[1]) == 1

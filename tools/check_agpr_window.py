@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_deep keeps the row it gathers ahead in a FIXED window of accumulation registers, a[192:234], loaded by an asm block and taken
+"""k_deep keeps the row it gathers ahead in a FIXED window of accumulation registers, a[0:42], loaded by an asm block and taken
 out behind a hand-written s_waitcnt (csrc/kernels_deep.h: deep_row_issue / deep_row_take).  The compiler is told that the asm
 blocks clobber the window, not that it is reserved: this script disassembles the device code of the built objects and reports any
 instruction that touches the window other than the asm blocks' loads (buffer_load_dwordx4 / global_load_dword INTO it) and the
@@ -16,7 +16,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-LO, HI = 192, 234
+LO, HI = 0, 42
 
 
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
