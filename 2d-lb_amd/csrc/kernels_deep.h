@@ -39,7 +39,10 @@ constexpr int deep_skirt_lanes(int D) { return (D - 1 + 3) / 4; }
 constexpr int deep_valid(int D) { return STRIP_W - 8 * deep_skirt_lanes(D); }           // cells stored per strip and row (D = 6..9: 240)
 constexpr int deep_strips(int nx, int D) { return (nx + deep_valid(D) - 1) / deep_valid(D); }
 // Where a wave's state lives, per depth (see the header comment): windows in registers, rows gathered ahead
-constexpr int deep_rw(int D) { return 1; }
+#ifndef LB_DEEP_RW
+#define LB_DEEP_RW 1                    // (2: the form of round 5's first D = 7 kernel, for tools/r06/rw2_check.sh)
+#endif
+constexpr int deep_rw(int D) { return LB_DEEP_RW; }
 constexpr int DEEP_WSLOTS = 8;          // LDS slots of a stage window
 constexpr int deep_pfd(int D) { return 1; }
 // Code footprint (two CUs share a 64 KB instruction cache; a lone wave has nobody to cover its fetch misses; 8192^2, k MLUPS,

@@ -28,7 +28,6 @@ struct StepArgs {
     int nts;               // marching kernels: non-temporal stores (a run-time flag there: halves their instantiations and takes a
                            // minute off the library's build)
     int tile_launch_order; // k_tile4: 1 = tile = blockIdx (A/B switch; default: one band of tile rows per XCD)
-    int rule_last;         // k1_step5 (Cython path): the pass's last step is followed by the next step's boundary rule, too
     float omega, rho_in, rho_out, lid_u, rho0;
     float u_w, u_e;        // VELOCITY_INLET: imposed speeds
     const float *corner;   // VELOCITY_INLET: the eight never-written corner links (bc_vel_cell)

@@ -82,9 +82,6 @@ int fail(int code, const char *fmt, ...)
 #include "kernels_deep.h"
 #include "kernels_tile.h"
 #include "kernels_phases.h"
-#ifdef LB_DIAG
-#include "kernels_step5c.h"     // k1_step5, the Cython path's marching form: diagnostic build only since round 5
-#endif
 #include "launchers.h"          // the fused kernels are instantiated in their own translation units
 
 namespace {
@@ -254,7 +251,6 @@ StepArgs step_args(const lb_sim *s, int row_begin, int row_step, int row_count)
     a.seg_stride = 0;
     a.edge_seg_rows = 0;
     a.tile_launch_order = (s->variant >= 0 && (s->variant & 8192)) ? 1 : 0;    // (A/B switch: explicit variants only)
-    a.rule_last = 0;
     a.diag = s->diag;
     a.prio_turns = 0;      // (set by launch_step2 from the variant)
     a.nts = 0;
@@ -503,23 +499,6 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
     a.nts = nts ? 1 : 0;                       // (the marching kernels take it at run time)
-#ifdef LB_DIAG
-    if (s->p.semantics == LB_SEM_CYTHON) {
-        // the Cython path's five-step march (k1_step5; diagnostic build only): `macro` = this is the run's last launch -- it
-        // stores rho, u, v and is not followed by the next step's boundary rule
-        a.rule_last = macro ? 0 : 1;
-        const dim3 block(64, STEP4_WAVES), grid(items);
-        if (s->has_mask) {
-            if (macro) hipLaunchKernelGGL((k1_step5<true, true>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
-            else hipLaunchKernelGGL((k1_step5<true, false>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
-        } else {
-            if (macro) hipLaunchKernelGGL((k1_step5<false, true>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
-            else hipLaunchKernelGGL((k1_step5<false, false>), grid, block, 0, st, a, strips, seg_rows, segs, row_end);
-        }
-        HIP_TRY(hipGetLastError());
-        return LB_OK;
-    }
-#endif
     launch_march(s, st, a, items, strips, seg_rows, segs, row_end, macro, depth);
     HIP_TRY(hipGetLastError());
     return LB_OK;
@@ -1068,10 +1047,15 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
 // so the exchange has from the end of E2a to the start of E1a, more than a whole launch, and every workgroup slot stays busy.
 // LB_BAND_EXTRA=<rows> fixes B (0 = the bands of rounds 3-5), LB_BAND_SLACK=<iterations> the head start, LB_SPLIT_BANDS=0 keeps
 // each band one launch (lb_run_group and the captured cycles always do).
-bool split_bands()
+// (Which transport: one box, k MLUPS per GPU of a strong-scaled 8192^2, 8 | 4 | 2 slabs, profiles/r06_slab_proxy_split.txt -- peer: one
+//  launch per band 370-386 | 437-443 | 461-468, split 372-383 | 424-426 | 460; RCCL: one launch 331-341 | 356-357 | 363-380, split 353-388 |
+//  372-386 | 420-445.  The peer transport's exchange is one push kernel, ~16 us: it fits the bands' head start and the second fill of a split
+//  band is all the split costs; RCCL's pack, send / receive, unpack take 30-160 us.  Hence: split under RCCL, one launch per band under the
+//  peer transport; LB_SPLIT_BANDS=0 / 1 forces either.)
+bool split_bands(const lb_sim *s)
 {
-    static const bool on = !(getenv("LB_SPLIT_BANDS") && atoi(getenv("LB_SPLIT_BANDS")) == 0);
-    return on;
+    static const int forced = getenv("LB_SPLIT_BANDS") ? (atoi(getenv("LB_SPLIT_BANDS")) != 0) : -1;
+    return forced >= 0 ? forced != 0 : !s->peer_connected;
 }
 
 int band_extra(const lb_sim *s, int D, bool split = false)
@@ -1383,17 +1367,6 @@ int autotune_quick_cost(const lb_sim *s) { return 11 * 2 * (small_grid(s) ? 36 :
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)
 bool cython_tiles(const lb_sim *s) { return s->p.nx >= 64 && s->H >= 64 && (s->variant < 0 || (s->variant & 512)); }
-// ... and five through the marching kernel on overlapping strips (k1_step5) when an explicit variant with bit 12 asks for it: the
-// kernel is bitwise right and faster than the tiles from ~6000^2 cells only (3751 x 1251 with the cylinder: 136 k against 174 k
-// MLUPS, 8192^2: 205 against 193 k; profiles/r04_experiments.txt section 11) -- not the default
-bool cython_march(const lb_sim *s)
-{
-#ifndef LB_DIAG
-    return false;       // (round 5: k1_step5 left the product -- slower than the tiles at the reference's sizes; the diagnostic build keeps it)
-#endif
-    if (s->p.nx < 512 || s->H < 128 || !marching_planes_fit(s)) return false;
-    return s->variant >= 0 && (s->variant & 4096) != 0;
-}
 
 // ---- what lb_autotune found, remembered across handles and processes (opt-in: LB_TUNE_CACHE) ------------------------------------
 // The kernel choice of a handle that was never tuned is a table of size thresholds measured on a pool of boxes that differ by +-5 %,
@@ -1784,7 +1757,7 @@ int lb_exchange_stats(lb_sim *s, int64_t *n_exchanges, double *total_ms, double 
     if (max_ms) *max_ms = mx;
     const int D = s->multi_slab() ? cycle_depth(s, s->min_h > 0 ? s->min_h : s->H) : 0;
     if (cycle_depth_out) *cycle_depth_out = D;
-    if (band_rows) *band_rows = D ? 2 * D + band_extra(s, D, split_bands()) : 0;
+    if (band_rows) *band_rows = D ? 2 * D + band_extra(s, D, split_bands(s)) : 0;
     s->xt_count = s->xt_dropped = 0;
     return LB_OK;
 }
@@ -2331,15 +2304,13 @@ int lb_run(lb_sim *s, int n_steps)
         // ceiling of a pass that moves 72 B per cell), then a launches of four steps each through LDS tiles (k1_tile4);
         // grids too small for tiles, or LB_VARIANT / lb_set_variant bit 9 clear with an explicit variant: single steps only
         const dim3 blk(64, 4), grd((unsigned)((s->pitch / 4 + 63) / 64), (unsigned)((s->H + 3) / 4));
-        // (k1_step5, where it applies: n = 5a + rem, the remainder first -- four steps through the tiles, or step by step)
-        const bool tiles = cython_tiles(s), march = cython_march(s);
+        // (rounds 4-5 also had a five-step marching form, k1_step5: bitwise right, slower than the tiles at the reference's sizes --
+        //  3751 x 1251 with the cylinder 136 against 174 k MLUPS --, diagnostic build only in round 5, removed in round 6)
+        const bool tiles = cython_tiles(s);
         int left = n_steps;
         while (left > 0) {
             const PhaseArgs a = phase_args(s);
-            if (march && left % 5 == 0) {
-                if ((rc = launch_step2(s, s->stream, 0, s->H, left == 5, 0, 0, 0, 0, 5))) return rc;
-                left -= 5;
-            } else if (tiles && (march ? left % 5 == TILE_T : left % TILE_T == 0)) {
+            if (tiles && left % TILE_T == 0) {
                 const int tiles_x = (s->p.nx + 31) / 32, tiles_y = (s->H + 15) / 16, n_tiles = tiles_x * tiles_y;
                 const dim3 tg((n_tiles + 7) / 8 * 8), tb(TileShape<32, 16, 2>::THREADS);    // (eight equal shares: xcd_band_tile)
                 const bool lastp = (left == TILE_T);
@@ -2408,7 +2379,7 @@ int lb_run(lb_sim *s, int n_steps)
         }
         // (the exchanges of the cycles below run on the communication stream, each behind the outer edge rows of its cycle and in front
         //  of the next cycle's; whatever the edge stream has done so far -- the exchange above -- precedes the first of them)
-        const bool split = split_bands();
+        const bool split = split_bands(s);
         if (split) {
             HIP_TRY(hipEventRecord(s->ev_halo, s->edge_stream));
             HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_halo, 0));
@@ -2958,7 +2929,7 @@ int lb_steps_per_launch(lb_sim *s)
     if (s && s->cpu) return 1;
     if (!s) return fail(LB_ERR_ARG, "null handle");
     int n = 1;
-    if (s->p.semantics == LB_SEM_CYTHON) return cython_march(s) ? 5 : (cython_tiles(s) ? TILE_T : 1);
+    if (s->p.semantics == LB_SEM_CYTHON) return cython_tiles(s) ? TILE_T : 1;
     if (!s->multi_slab()) {
         const int depths = whole_grid_depths(s);
         for (int d = 2; d <= MAX_DEPTH; ++d)
@@ -3005,8 +2976,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     static const char *const bc_names[] = {"PIPE", "PERIODIC", "CAVITY", "VELOCITY_INLET", "PIPE, D2Q9i"};
     const char *kernel = "k_step";
     if (s->p.semantics == LB_SEM_CYTHON)
-        kernel = cython_march(s) ? "k1_step5 (Cython path, marching strips, five steps per pass)"
-                                 : (cython_tiles(s) ? "k1_tile4 (Cython path, LDS tiles)" : "k1_fstep (Cython path)");
+        kernel = cython_tiles(s) ? "k1_tile4 (Cython path, LDS tiles)" : "k1_fstep (Cython path)";
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";

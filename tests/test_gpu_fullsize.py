@@ -167,6 +167,35 @@ def test_config4_shear_layer_8192_default_and_four_step_kernel_equal_single_step
             assert chk["n_nonfinite"] == 0 and abs(chk["sum_rho"] / (n * n) - 1.0) < 1e-4
 
 
+def test_planar_layout_8192_deep_kernels_equal_single_step_kernel_bitwise(lbhip):
+    """LB_FLAG_PLANAR at 8192^2: each plane contiguous, 8220 rows x 8192 floats = 269 MB, so k_deep's scalar plane offsets reach
+    8 x 269 MB = 2.16 GB -- beyond the 2 GiB its buffer resources spanned until round 6 (a raw buffer access is range-checked as
+    offset >= num_records - soffset: plane 8 would have read zeros and dropped its stores, silently).  k_deep<7> and
+    k_deep<6> against the single-step kernel, bit for bit, on the bench's initial state."""
+    from LB_D2Q9.simulation import Simulation
+    import bench
+    n = 8192
+    ref = None
+    for variant in (9, -1, 20833):
+        sim = Simulation(n, n, 1.7, bc="periodic", planar=True)
+        lay = sim.layout()
+        assert lay["planar"] and 8 * lay["plane_stride"] * 4 > 2 ** 31
+        sim.set_variant(variant)
+        assert sim.steps_per_launch() == {9: 1, -1: 7, 20833: 6}[variant]
+        sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
+        sim.run(14)
+        f = sim.get_fields(("f",))["f"]
+        chk = sim.check()
+        sim.close()
+        if ref is None:
+            assert np.all(np.isfinite(f[:, :, 8])) and f[:, :, 8].std() > 0
+            ref = (f, chk)
+        else:
+            for k in range(9):
+                assert np.array_equal(f[:, :, k], ref[0][:, :, k]), (variant, "plane", k)
+            assert chk == ref[1]
+
+
 @pytest.mark.parametrize("bc,masked", [("pipe", True), ("cavity", False), ("periodic", True)])
 def test_full_size_families_default_and_four_step_kernel_equal_single_step_kernel_bitwise(lbhip, bc, masked):
     """8192 x 8192 in the other boundary families, with and without an obstacle mask (the instantiations of k_step5 and k_step4

@@ -551,6 +551,47 @@ def test_rccl_self_exchange_single_rank(lbhip):
     assert np.array_equal(one.get_fields(("f",))["f"], two.get_fields(("f",))["f"])
 
 
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_slab_cycle_depth_set_by_the_caller_and_exchange_timing(lbhip, transport):
+    """lb_set_slab_cycle (ABI 9): the halo cycle of lb_run on the depth the caller fixes -- what DistributedSlab.autotune does after
+    the ranks have timed the candidates together -- gives the plain run's bits at every depth, over both transports (thick edge bands;
+    under RCCL split in two launches with the exchange on the communication stream: lb_hip.cpp, slab_cycle_first), with an obstacle
+    mask; lb_exchange_timing / lb_exchange_stats count the exchanges and report the cycle in use."""
+    from LB_D2Q9.simulation import Simulation, comm_unique_id
+    from LB_D2Q9.slabs import _SlabSet
+    nx, ny = 1024, 480
+    rng = np.random.default_rng(77)
+    f0 = _random_state(rng, nx, ny)
+    mask = rng.random((nx, ny)) < 0.02
+    one = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask)
+    one.set_variant(0)
+    one.set_f(f0)
+    one.run(3 * 28 + 9)
+    want = one.get_fields(("f",))["f"]
+    one.close()
+    for depth in (7, 6, 5, 4, 3):
+        s = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask, halo=True)
+        s.set_obstacle_mask_halo(*_SlabSet._mask_halo_rows(mask, 0, ny, ny, True))
+        s.set_variant(97 | 256 | 4096 | 16384 | 32768)        # every marching kernel allowed; the cycle's depth is the caller's
+        if transport == "rccl":
+            s.comm_init(comm_unique_id(), 0, 1)
+        else:
+            d = s.peer_export()
+            s.peer_connect(0, 1, d, d, ny)
+        s.set_slab_cycle(depth)
+        s.exchange_timing(True)
+        s.set_f(f0)
+        for n in (28, 28, 28, 9):
+            s.run(n)
+        st = s.exchange_stats()
+        assert st["cycle_depth"] == depth and st["n"] >= 3 and st["total_ms"] > 0 and st["max_ms"] <= st["total_ms"]
+        assert st["band_rows"] >= 2 * depth
+        assert s.exchange_stats()["n"] == 0                    # (the query starts over)
+        got = s.get_fields(("f",))["f"]
+        assert np.array_equal(got, want), (transport, depth)
+        s.close()
+
+
 # ---- the drop-in classes ---------------------------------------------------------------------------
 def test_pipe_flow_class_poiseuille_kat(lbhip):
     """The reference's own known-answer test (docs/opencl_dimensionless_verification.ipynb:632-696):

@@ -148,3 +148,62 @@ def test_multirank_checkpoint_written_by_two_ranks_resumes_on_three(oracle, tmp_
     want = ref.get_fields()
     for k in ("f", "rho", "u", "v"):
         assert np.array_equal(got[k], want[k]), (bc, k)
+
+
+# ---- DistributedSlab.autotune: the ranks time the halo cycle's candidate depths TOGETHER and agree --------------------------------
+class _TimedStubEngine(object):
+    """An engine that only knows how long a run 'takes' on this rank at each depth of the halo cycle: enough for the collective
+    choice (the kernels' own equivalence at every depth is the GPU suite's: tests/test_gpu_parity.py)."""
+    MS_PER_STEP = {0: {7: 0.10, 6: 0.12, 5: 0.15}, 1: {7: 0.30, 6: 0.13, 5: 0.14}}       # rank 1 is slow at depth 7
+
+    def __init__(self, **kw):
+        self.rank_of = None
+        self.depth = 0
+        self.steps = 0
+        self._n = 0
+
+    def set_slab_cycle(self, depth):
+        self.depth = depth
+
+    def sync(self):
+        pass
+
+    def timer_start(self):
+        self._n = 0
+
+    def run(self, n, wait=True):
+        self._n += n
+        self.steps += n
+
+    def timer_stop(self):
+        return self.MS_PER_STEP[self.rank_of][self.depth] * self._n
+
+
+def _tune_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "2d-lb_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from LB_D2Q9.slabs import DistributedSlab
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        slab = DistributedSlab(64, 400, 1.4, bc="periodic", transport="torch", engine_factory=_TimedStubEngine)
+        slab.engine.rank_of = rank
+        slab.transport = "peer"             # (what autotune asks: the schedule runs inside the engine)
+        got = slab.autotune()
+        np.savez(os.path.join(out_dir, "tune_%d.npz" % rank), depth=got["depth"], steps=got["steps"], engine_depth=slab.engine.depth,
+                 engine_steps=slab.engine.steps, t7=got["ms_per_step"][7], t6=got["ms_per_step"][6], t5=got["ms_per_step"][5])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_slab_autotune_agrees_on_the_slowest_ranks_best_depth(tmp_path):
+    """Two ranks, 200 rows each (>= 16 x 7: every candidate applies): rank 0 alone would pick depth 7, rank 1 is three times
+    slower there -- the MAX over ranks decides, both set depth 6 and both have advanced the same number of live steps."""
+    import torch.multiprocessing as mp
+    mp.spawn(_tune_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "tune_%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        assert int(r[k]["depth"]) == 6 and int(r[k]["engine_depth"]) == 6
+        assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["t6"]) - 0.13) < 1e-9 and abs(float(r[k]["t5"]) - 0.15) < 1e-9
+        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 3 * 3 * 2 * (7 + 6 + 5)

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--parts", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--variants", default="-1,9")
+    ap.add_argument("--reps", type=int, default=3, help="timed runs per configuration; the best counts")
     ap.add_argument("--transports", default="rccl", help="comma list of rccl, peer (the slab path as a 1-rank ring over that transport)")
     args = ap.parse_args()
     from LB_D2Q9.simulation import Simulation, comm_unique_id
@@ -39,9 +40,11 @@ def main():
                     sim.peer_connect(0, 1, d, d, ny)
                 sim.init_equilibrium(*shear_layer(args.nx, ny, 0, ny))
                 sim.run(10)
+                if mode != "plain":
+                    sim.exchange_timing(True)
                 best = 0.0
                 host = 1e9
-                for _ in range(3):
+                for _ in range(args.reps):
                     import time
                     t0 = time.perf_counter()
                     sim.run(args.steps, wait=False)      # host enqueue time only
@@ -52,12 +55,16 @@ def main():
                     best = max(best, args.nx * ny * args.steps / (ms * 1e-3) / 1e6)
                 res[mode] = best
                 res[mode + "_host_us"] = host
+                if mode != "plain":
+                    st = sim.exchange_stats()
+                    res[mode + "_xchg"] = "halo cycle on depth %d, edge bands of %d rows, exchange %.0f us mean / %.0f us max" % (
+                        st["cycle_depth"], st["band_rows"], 1e3 * st["total_ms"] / max(1, st["n"]), 1e3 * st["max_ms"])
                 sim.close()
             for mode in modes[1:]:
                 print("grid %5d x %5d (1/%d of %d^2) variant %3d: plain %9.1f MLUPS, slab path (%s) %9.1f MLUPS "
-                      "(%.1f us/step GPU, %.0f us/step host enqueue) -> x%d = %9.1f"
+                      "(%.1f us/step GPU, %.0f us/step host enqueue; %s) -> x%d = %9.1f"
                       % (args.nx, ny, parts, args.nx, variant, res["plain"], mode[5:], res[mode],
-                         args.nx * ny / res[mode], res[mode + "_host_us"], parts, parts * res[mode]), flush=True)
+                         args.nx * ny / res[mode], res[mode + "_host_us"], res[mode + "_xchg"], parts, parts * res[mode]), flush=True)
 
 
 if __name__ == "__main__":
