@@ -478,8 +478,11 @@ __device__ __forceinline__ void deep_march(const StepArgs &a, const int x0, cons
 #ifndef LB_DEEP_OCC2
 #define LB_DEEP_OCC2 0
 #endif
+#ifndef LB_DEEP_KATTR
+#define LB_DEEP_KATTR
+#endif
 template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD>
-__global__ __launch_bounds__(64 * STEP4_WAVES, ((PFD && !LB_DEEP_OCC2) ? 1 : 2)) void k_deep(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
+__global__ __launch_bounds__(64 * STEP4_WAVES, ((PFD && !LB_DEEP_OCC2) ? 1 : 2)) LB_DEEP_KATTR void k_deep(const StepArgs a, int strips, int seg_rows, int nsegs, int row_end)
 {
     __shared__ f4a lds_win[STEP4_WAVES][(D - 1 - RW) * DEEP_WSLOTS][64];
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
