@@ -20,11 +20,16 @@ HDR = os.path.join(os.path.dirname(HERE), "include", "lb_hip.h")
 OUT = os.path.join(HERE, "LB_D2Q9", "liblbhip.so")
 OBJ = os.path.join(HERE, "build")
 # (largest first: the pool starts them in this order)
-UNITS = ["deep7.cpp", "deep6.cpp", "march5.cpp", "march4.cpp", "lb_hip.cpp", "march23.cpp", "tile.cpp", "step1.cpp"]
+UNITS = ["deep7.cpp", "deep2.cpp", "deep6.cpp", "march5.cpp", "march4.cpp", "lb_hip.cpp", "march23.cpp", "tile.cpp", "step1.cpp"]
+# Units whose DEVICE code is compiled through LLVM IR so that a function attribute clang cannot spell can be added to their kernels
+# (_compile_patched): k_deep2 runs two waves per SIMD and keeps a row in flight in accumulation registers a[0:42]; the compiler's default
+# for such a kernel is 128 vector + 128 accumulation registers, "amdgpu-agpr-alloc"="44" makes it 212 + 44 (kernels_deep2.h).
+IR_ATTRS = {}      # (round 6 built k_deep2 that way until its gather ahead moved into LDS: kernels_deep.h, deep_row_issue_lds)
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 # -ffp-contract=on: a*b+c fuses to an FMA only inside one source expression, so every kernel instantiation (single step,
 # multi-step, slab edge rows) -- in whichever translation unit -- rounds identically: results are bitwise independent of the
 # kernel variant and of the slab partition.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-constant-logical-operand"]
 
 
 def hipcc():
@@ -57,14 +62,47 @@ def _compile(unit, tag, extra, verbose):
             os.path.exists(stamp) and open(stamp).read() == flags):
         return obj
     tmp = obj + ".tmp%d" % os.getpid()
-    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", tmp]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    if unit in IR_ATTRS:
+        _compile_patched(src, tmp, FLAGS + extra, IR_ATTRS[unit], verbose)
+    else:
+        cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", tmp]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     os.replace(tmp, obj)
     open(stamp, "w").write(flags)
     return obj
+
+
+def _compile_patched(src, out, flags, attr, verbose):
+    """hipcc's own steps for one translation unit, with a stop in the middle: device code to optimised LLVM IR; `attr` added to the
+    attribute group of every kernel (amdgpu_kernel functions); IR to a code object (llc, lld); code object bundled
+    (clang-offload-bundler) and embedded into the host object (-fcuda-include-gpubinary), as `hipcc -c` does (`hipcc -###`)."""
+    import re
+    base = out + ".ir"
+    ll, ll2, dev, hsaco, fb = base + ".ll", base + ".patched.ll", base + ".dev.o", base + ".hsaco", base + ".hipfb"
+    run = (lambda c: (print(" ".join(c), flush=True), subprocess.check_call(c))) if verbose else subprocess.check_call
+    run([hipcc()] + flags + ["--cuda-device-only", "-emit-llvm", "-S", src, "-o", ll])
+    text = open(ll).read()
+    groups = set(re.findall(r"^define [^\n]*\bamdgpu_kernel\b[^\n]*#(\d+)", text, re.M))
+    if not groups:
+        raise RuntimeError("%s: no amdgpu_kernel function found in the device IR" % src)
+    for g in groups:
+        text, n = re.subn(r"^(attributes #%s = \{ )" % g, r"\1%s " % attr.replace("\\", "\\\\"), text, flags=re.M)
+        if n != 1:
+            raise RuntimeError("%s: attribute group #%s not found" % (src, g))
+    open(ll2, "w").write(text)
+    llc = [os.path.join(LLVM_BIN, "llc"), "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-O3", "-filetype=obj", "-relocation-model=pic", ll2, "-o", dev]
+    if verbose:
+        llc.insert(1, "-pass-remarks-analysis=kernel-resource-usage")
+    run(llc)
+    run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", hsaco, dev])
+    run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + hsaco, "-output=" + fb])
+    run([hipcc()] + flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-c", src, "-o", out])
+    for f in (ll, ll2, dev, hsaco, fb):
+        os.remove(f)
 
 
 def _build(out, tag, extra, force, verbose, jobs):

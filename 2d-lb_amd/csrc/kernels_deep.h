@@ -71,7 +71,13 @@ struct DeepCtx {
     int lane, x4, ym, n_iter;
     bool store_lane;
     f4a (*mine)[64], (*other)[64];      // my LDS windows RW+1..D-1 (DEEP_WSLOTS slots each, in that order), the other wave's
+    f4a (*ho)[64];                      // k_deep2: the slot a front wave hands its rows to its back wave through (9 links + the obstacle flags)
+    f4a (*dma)[64];                     // k_deep2, front waves: the slot the row gathered ahead is loaded INTO (buffer_load ... lds), and
+    unsigned dma_off;                   //   its byte offset inside the workgroup's LDS (what M0 takes)
 };
+// k_deep2 (below): a strip's march split between two waves -- the front wave runs stages 1..F, the back wave stages F+1..D
+constexpr int DEEP_WHOLE = 0, DEEP_FRONT = 1, DEEP_BACK = 2;
+constexpr int DEEP_HO_SLOTS = 10;
 
 // An LDS window: slot 0, 1 = links 1, 3 of the newest row; slots 2..4 / 5..7 = links A, B, C (pulled from behind) of the newest two
 // rows, a ring: the iteration's parity picks the OLDER row, which is read, then overwritten
@@ -290,6 +296,97 @@ __device__ __forceinline__ void deep_row_take(Row1 &o)
     }
 }
 
+// ---- the row gathered ahead, straight into LDS (k_deep2's front waves; round 6) ---------------------------------------------------
+// A front wave shares its SIMD with another wave: 256 registers.  The accumulation-register window above does not survive that -- a
+// kernel that names accumulation registers at two waves per SIMD is given 128 vector + 128 accumulation registers (LLVM's default
+// split; "amdgpu-agpr-alloc"="44" mends it to 212 + 44, but then the compiler's own spills land in a0..a43, i.e. in the window) --,
+// and the same window in vector registers does not either (the compiler copies the values "in" it around branches: data that has
+// not arrived yet).  So the row in flight is in no register at all: `buffer_load_dwordx4 ... lds` writes a lane's 16 bytes to LDS at
+// M0 + 16 x lane -- measured, tools/lds_dma_probe.hip / profiles/r06_lds_dma_probe.txt: M0 may lie beyond 64 KB; an instruction offset
+// moves the LDS address as well as the global one (hence none here: the 0 / 4 / 8-byte displacement of the pulled planes sits in three
+// lane-offset registers); lanes masked out of exec write nothing --, one 1-KiB slot per plane, a tenth for the row's obstacle flags and
+// the seam lanes' wrap elements.  The loads are issued by asm blocks (the compiler must not count them: kernels_deep.h above), taken
+// behind `s_waitcnt vmcnt(0)` -- a front wave has nothing else in flight: it stores nothing -- by nine ds_read_b128 where the
+// accumulation registers took 42 v_accvgpr_read.
+template <int BC, bool MASK>
+__device__ __forceinline__ void deep_row_issue_lds(const StepArgs &a, int r, int x4, unsigned slot, Row1 &o)
+{
+    int ym, yp;
+    o.have = step1_rows(a, r, o.rr, ym, yp);
+    o.hsolid = false;
+    o.hxc = -1;
+    if (o.have) {
+        const long long P = a.pitch, S = a.plane;
+        const float *s = a.src;
+        const int yl = o.rr;
+        // (whatever still reads the slot -- the previous row's take -- has its data first)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (BC == LB_BC_PERIODIC) {
+            const int c = a.nx - 1 - x4;
+            const bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
+            if (wrap_w) {
+                const float *e = s + a.nx - 1;
+                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, off"
+                             :: "v"(e + 1 * S + (long long)yl * P), "v"(e + 5 * S + (long long)ym * P), "v"(e + 8 * S + (long long)yp * P),
+                                "s"(slot + 9 * 1024 + 256)
+                             : "memory", "m0", "scc");
+            }
+            if (wrap_e) {
+                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, off"
+                             :: "v"(s + 3 * S + (long long)yl * P), "v"(s + 6 * S + (long long)ym * P), "v"(s + 7 * S + (long long)yp * P),
+                                "s"(slot + 9 * 1024 + 256)
+                             : "memory", "m0", "scc");
+            }
+        }
+        const u4v r0 = deep_rsrc_words(s + (long long)yl * P - 1), rm = deep_rsrc_words(s + (long long)ym * P - 1),
+                  rp = deep_rsrc_words(s + (long long)yp * P - 1);
+        const unsigned S4 = (unsigned)a.plane * 4u;
+        const int v0 = x4 * 4, v4 = v0 + 4, v8 = v0 + 8;       // pulled from the left / the same column / from the right
+        asm volatile("s_mov_b32 m0, %14\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %6 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %8 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %9 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %4, %10 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %11 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %12 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %13 offen lds"
+                     :: "v"(v0), "v"(v4), "v"(v8), "s"(r0), "s"(rm), "s"(rp), "s"(S4), "s"(2u * S4), "s"(3u * S4), "s"(4u * S4), "s"(5u * S4),
+                        "s"(6u * S4), "s"(7u * S4), "s"(8u * S4), "s"(slot)
+                     : "memory", "m0", "scc");
+        if (MASK)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                         :: "v"(lane_ptr(a.mask + (long long)yl * a.fpitch, x4)), "s"(slot + 9 * 1024) : "memory", "m0");
+    }
+}
+// the row issued last: everything this wave has in flight is that row
+template <int BC, bool MASK>
+__device__ __forceinline__ void deep_row_take_lds(const f4a (*S)[64], int lane, Row1 &o)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (o.have) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.q[k] = S[k][lane];
+        const unsigned *X = reinterpret_cast<const unsigned *>(S[9]);
+        o.mk = MASK ? __builtin_bit_cast(uc4, X[lane]) : uc4{0, 0, 0, 0};
+        o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (BC == LB_BC_PERIODIC) {                     // (the lane at x = 0 and the lane at x = nx - 4 share the three sub-slots)
+            const float e1 = __builtin_bit_cast(float, X[64 + lane]), e2 = __builtin_bit_cast(float, X[128 + lane]),
+                        e3 = __builtin_bit_cast(float, X[192 + lane]);
+            o.wp = WrapPatch{e1, e2, e3, e1, e2, e3};
+        }
+    } else {                                            // (a row outside a walled box: nothing was issued)
+        o.wp = WrapPatch{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.q[k] = f4a{0.f, 0.f, 0.f, 0.f};
+        o.mk = uc4{0, 0, 0, 0};
+    }
+}
+
 // store_row9 (kernels_fused.h) through a buffer resource based at the row
 __device__ __forceinline__ void deep_row_store(const StepArgs &a, int r, int x4, const f4a (&t)[9])
 {
@@ -310,7 +407,7 @@ __device__ __forceinline__ void deep_row_store(const StepArgs &a, int r, int x4,
 }
 
 // Stages S..D of one iteration, S >= 2.  qin = the row stage S - 1 produced in this iteration (position i - (S - 2)).
-template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S>
+template <int BC, bool MASK, bool MACRO, int D, int RW, bool DOWN, int NST, int S, int ROLE = DEEP_WHOLE>
 __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx, const int i, const int it,
                                            DeepState<RW, D - 1 - RW> &st, f4a (&qin)[9], f4a &r4, f4a &u4, f4a &v4)
 {
@@ -334,7 +431,12 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                 deep_window_push<DOWN>(W, lane, it, st.d0[L], qin);
             }
             LB_DEEP_NOCOLLIDE collide_row<BC, MASK, true>(a, x4, a.y0 + r, t, mask_bits(st.mhist, K), r4, u4, v4);
-            if constexpr (S == D) {
+            if constexpr (S == D && ROLE == DEEP_FRONT) {
+                // k_deep2: the row goes to my back wave (every lane's: its skirt shifts need the skirt lanes' cells), with its obstacle flags
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cx.ho[k][lane] = t[k];
+                if (MASK) reinterpret_cast<unsigned *>(cx.ho[9])[lane] = __builtin_bit_cast(unsigned, mask_bits(st.mhist, K));
+            } else if constexpr (S == D) {
 #ifdef LB_DIAG
                 if (!(a.diag & (1 << 22)))
 #endif
@@ -357,7 +459,7 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
                     if constexpr (S <= RW) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, S == 1 ? 5 : 2, t);
                     else deep_publish<DOWN>(cx.other + (S - RW - 1) * DEEP_WSLOTS, lane, 2 + 3 * (S & 1), t);
                 }
-                deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, S + 1>(a, cx, i, it, st, t, r4, u4, v4);
+                deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, S + 1, ROLE>(a, cx, i, it, st, t, r4, u4, v4);
             }
         } else if constexpr (NST == S - 1) {
             // position 0 after step K enters window K (its d slots and the ring row of this parity; the other wave fills the other one)
@@ -371,11 +473,15 @@ __device__ __forceinline__ void deep_stage(const StepArgs &a, const DeepCtx &cx,
 // that have a row: 1..D-1 in iterations 0..D-2 (code of their own, i a constant: the pipeline fills, the two waves of the pair hand
 // over), D in the loop.  PFD = 1: `cur` holds position i on entry and position i + 1 is gathered into `nxt` first; the caller swaps
 // the two from one iteration to the next.  PAR >= 0: the parity of i as a constant (the LDS ring slots become immediate offsets).
-template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST, int PAR = -1>
+// ROLE (k_deep2): a FRONT wave is a march of depth D whose last stage hands its row to the back wave instead of storing it; a BACK wave
+// is a march of depth D whose "step 1" is that row, already in `cur` (D, NST, i: the wave's own).  Neither has barriers of its own.
+template <int BC, bool MASK, bool MACRO, int D, int RW, int PFD, bool DOWN, int NST, int PAR = -1, int ROLE = DEEP_WHOLE>
 __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, const int i_, DeepState<RW, D - 1 - RW> &st, Row1 &cur,
                                           Row1 &nxt)
 {
-    static_assert(RW >= 0 && RW <= 2 && D - 1 - RW >= 1 && D - 2 > RW, "register windows hand over through the last LDS window while it is idle");
+    // (the mailbox -- the last LDS window -- is read at the top of iteration K <= RW and takes its own first row later in iteration D - 2)
+    static_assert(RW >= 0 && RW <= 2 && D - 1 - RW >= 1 && (ROLE == DEEP_WHOLE ? D - 2 > RW : D - 2 >= RW),
+                  "register windows hand over through the last LDS window while it is idle");
     static_assert((D - 1 - RW) * DEEP_WSLOTS <= 40, "a wave has 40 KB of LDS at four waves per CU");
     const int lane = cx.lane, x4 = cx.x4;
     const int i = NST < D ? NST - 1 : i_;
@@ -390,8 +496,11 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
 #ifdef LB_DIAG
     if (!((a.diag & (1 << 23)) && i > 0))
 #endif
-    {
-        if (PFD && LB_DEEP_MANUAL) {
+    if constexpr (ROLE != DEEP_BACK) {
+        if (ROLE == DEEP_FRONT) {
+            deep_row_take_lds<BC, MASK>(cx.dma, lane, cur);
+            deep_row_issue_lds<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, cx.dma_off, nxt);
+        } else if (PFD && LB_DEEP_MANUAL) {
             deep_row_take<BC, MASK, (NST < D ? 0 : (MACRO ? 12 : 9))>(cur);
             deep_row_issue<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, nxt);
         } else if (PFD) deep_row_load<BC, MASK>(a, row_at(min(i + 1, cx.n_iter - 1)), x4, nxt);
@@ -400,7 +509,7 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
     f4a (&q1)[9] = cur.q;
     f4a r4, u4, v4;
     const uc4 mk = cur.mk;
-    if (cur.have) {
+    if (ROLE != DEEP_BACK && cur.have) {
         gather_merge<BC, true>(a, x4, q1, cur.wp);
         LB_DEEP_NOCOLLIDE collide_row<BC, MASK, true>(a, x4, a.y0 + cur.rr, q1, mk, r4, u4, v4);
     }
@@ -408,9 +517,9 @@ __device__ __forceinline__ void deep_iter(const StepArgs &a, const DeepCtx &cx, 
         if constexpr (RW >= 1) deep_publish<DOWN>(cx.other + (D - 2 - RW) * DEEP_WSLOTS, lane, 5, q1);      // (mailbox)
         else deep_publish<DOWN>(cx.other, lane, 2 + 3 * 1, q1);
     }
-    deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, 2>(a, cx, i, it, st, q1, r4, u4, v4);
+    deep_stage<BC, MASK, MACRO, D, RW, DOWN, NST, 2, ROLE>(a, cx, i, it, st, q1, r4, u4, v4);
     if (MASK) st.mhist = ((st.mhist | mask_word(mk)) << 1) & (0x01010101u * (unsigned)(((1 << D) - 2) & 0xff));
-    if (NST < D) __syncthreads();                   // what was published in this iteration is consumed in the next
+    if (ROLE == DEEP_WHOLE && NST < D) __syncthreads();     // what was published in this iteration is consumed in the next
 }
 
 // the filling iterations 0..D-2, one after the other (NST = 1..D-1); PFD = 1: the two row buffers swap roles every iteration

@@ -25,6 +25,7 @@ void lbk_launch_march4(int bc, bool mask, bool macro, bool prefetch, const March
 void lbk_launch_march5(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                   // march5.cpp
 void lbk_launch_deep6(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep6.cpp (not VELOCITY_INLET)
 void lbk_launch_deep7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep7.cpp (not VELOCITY_INLET)
+void lbk_launch_deep2_7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                  // deep2.cpp: k_deep2, four waves per workgroup (not VELOCITY_INLET)
 // k_tile4 over a whole grid of nx x h cells; shape 0: 32 x 16 tiles, two cells per thread; 1: 32 x 16, one; 2: 16 x 16, one
 void lbk_launch_tile4(int bc, bool mask, bool macro, int shape, int nx, int h, hipStream_t st, const StepArgs &a);                // tile.cpp (not VELOCITY_INLET)
 void lbk_launch_vel_band(bool mask, bool macro, int d, dim3 grid, dim3 block, hipStream_t st, const StepArgs &a);                 // tile.cpp (d = 3, 4, 5)

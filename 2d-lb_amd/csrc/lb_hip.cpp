@@ -351,7 +351,8 @@ void launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items,
     g.stream = st;
     g.strips = strips; g.seg_rows = seg_rows; g.nsegs = nsegs; g.row_end = row_end;
     const int bc = kernel_bc(s);
-    if (depth == 7) lbk_launch_deep7(bc, s->has_mask, macro, g, a);
+    if (depth == 7 && (effective_variant(s) & 65536)) lbk_launch_deep2_7(bc, s->has_mask, macro, g, a);    // k_deep2: four waves per workgroup
+    else if (depth == 7) lbk_launch_deep7(bc, s->has_mask, macro, g, a);
     else if (depth == 6) lbk_launch_deep6(bc, s->has_mask, macro, g, a);
     else if (depth == 5) lbk_launch_march5(bc, s->has_mask, macro, g, a);
     else if (depth == 4) lbk_launch_march4(bc, s->has_mask, macro, !(effective_variant(s) & 1024), g, a);
@@ -2980,6 +2981,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";
+        else if (spl == 7 && (effective_variant(s) & 65536)) kernel = "k_deep2<7> (marching strips, seven steps per pass, two waves per strip and direction -- stages 1-4 / 5-7 --, two waves per SIMD)";
         else if (spl == 7) kernel = "k_deep<7> (marching strips, seven steps per pass, one wave per SIMD, stage windows in registers + LDS, gather one row ahead)";
         else if (spl == 6) kernel = "k_deep<6> (marching strips, six steps per pass, one wave per SIMD, stage windows in registers + LDS, gather one row ahead)";
         else if (spl == 5) kernel = "k_step5 (marching strips, five steps per pass: two stage windows in registers, two in wave-private LDS)";

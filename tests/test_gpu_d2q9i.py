@@ -83,12 +83,12 @@ def test_d2q9i_every_fused_kernel_bitwise_and_vs_oracle(lbhip, oracle, nx, ny, m
         mask[0, :] = mask[-1, :] = False
         mask[:, 0] = mask[:, -1] = False
     outs = []
-    variants = (0, 33, 97, 353, 864, 353 | 4096, 353 | 4096 | 16384, 353 | 4096 | 16384 | 32768) if nx >= 512 else (0, -1, 512)
+    variants = (0, 33, 97, 353, 864, 353 | 4096, 353 | 4096 | 16384, 353 | 4096 | 16384 | 32768, 353 | 4096 | 16384 | 32768 | 65536) if nx >= 512 else (0, -1, 512)
     for variant in variants:
         s = Simulation(nx, ny, 1.0, bc="pipe", inlet_rho=1.0002, obstacle_mask=mask, semantics="d2q9i")
         s.set_variant(variant)
         if nx >= 512:
-            assert s.steps_per_launch() == {0: 1, 33: 2, 97: 3, 353: 4, 864: 4, 4449: 5, 20833: 6, 53601: 7}[variant]
+            assert s.steps_per_launch() == {0: 1, 33: 2, 97: 3, 353: 4, 864: 4, 4449: 5, 20833: 6, 53601: 7, 119137: 7}[variant]
         assert "D2Q9i" in s.hot_kernel()
         s.set_f(f0)
         s.run(5); s.run(3)

@@ -141,10 +141,10 @@ def test_config4_shear_layer_8192_default_and_four_step_kernel_equal_single_step
     import bench
     n = 8192
     ref = None
-    for variant in (9, -1, 20833, 4449, 353):
+    for variant in (9, -1, 20833, 4449, 353, 119137):
         sim = Simulation(n, n, 1.7, bc="periodic")
         sim.set_variant(variant)
-        assert sim.steps_per_launch() == {9: 1, -1: 7, 20833: 6, 4449: 5, 353: 4}[variant]
+        assert sim.steps_per_launch() == {9: 1, -1: 7, 20833: 6, 4449: 5, 353: 4, 119137: 7}[variant]
         sim.init_equilibrium(*bench.shear_layer(n, n, 0, n))
         f0 = sim.get_fields(("f",))["f"] if ref is None else None
         sim.run(8)
@@ -241,7 +241,7 @@ def test_wall_column_strips_with_shorter_segments_bitwise(lbhip, bc, nx, ny, mas
     u = (0.02 + 1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
     v = (1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
     out = []
-    for variant in (353, 9, 353 | 4096, 353 | 4096 | 16384, 353 | 4096 | 16384 | 32768):
+    for variant in (353, 9, 353 | 4096, 353 | 4096 | 16384, 353 | 4096 | 16384 | 32768, 353 | 4096 | 16384 | 32768 | 65536):
         sim = Simulation(nx, ny, 1.5, bc=bc, inlet_rho=1.0005, lid_u=0.05, inlet_u=0.02, obstacle_mask=mask)
         sim.set_variant(variant)
         if variant & 4096:

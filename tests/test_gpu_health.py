@@ -50,7 +50,7 @@ def test_deep_kernels_store_the_single_step_kernels_fields_when_eager(lbhip, bc,
             mask[0, :] = mask[-1, :] = False
             mask[:, 0] = mask[:, -1] = False
     out = []
-    for variant in (0, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768):
+    for variant in (0, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384 | 32768 | 65536):
         s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, eager_macro=True, inlet_rho=1.002, lid_u=0.04)
         s.set_variant(variant)
         if variant:

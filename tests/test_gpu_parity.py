@@ -218,10 +218,11 @@ def test_two_step_kernel_equals_single_step_kernel(lbhip, oracle, bc, nx, ny, ma
     sims = []
     # single step / two-step / + NT stores / three-step (+ two-step remainder) / four-step (+ remainders) /
     # four steps through LDS tiles (+ single-step remainders) / five-step on overlapping strips (+ remainders)
-    for variant in (0, 32, 33, 97, 97 | 256, 512, 97 | 256 | 4096, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768):
+    for variant in (0, 32, 33, 97, 97 | 256, 512, 97 | 256 | 4096, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768,
+                    97 | 256 | 4096 | 16384 | 32768 | 65536):                     # (the last one: k_deep2)
         s = Simulation(nx, ny, 1.6, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
-        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4, 4449: 5, 20833: 6, 53601: 7}[variant]
+        assert s.steps_per_launch() == {0: 1, 32: 2, 33: 2, 97: 3, 353: 4, 512: 4, 4449: 5, 20833: 6, 53601: 7, 119137: 7}[variant]
         s.set_f(f0)
         s.run(7)                      # 7 = 1+2+2+2 (two-step) = 1+3+3 (three-step) = 3+4 (four-step) = 2+5 (five-step) = 1+6 = 7
         s.run(4)                      # 4 = 2+2 = 1+3 = 4
@@ -353,12 +354,12 @@ def test_five_and_six_step_kernel_strip_boundaries(lbhip, bc, nx):
         mask[0, :] = mask[-1, :] = False
         mask[:, 0] = mask[:, -1] = False
     out = []
-    for variant in (0, 97 | 256 | 4096, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768):
+    for variant in (0, 97 | 256 | 4096, 97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384 | 32768 | 65536):
         s = Simulation(nx, ny, 1.55, bc=bc, obstacle_mask=mask, inlet_rho=1.003, lid_u=0.05)
         s.set_variant(variant)
         if variant:
             spl = 7 if variant & 32768 else (6 if variant & 16384 else 5)
-            assert s.steps_per_launch() == spl and ("k_step5" if spl == 5 else "k_deep<%d>" % spl) in s.hot_kernel()
+            assert s.steps_per_launch() == spl and ("k_step5" if spl == 5 else ("k_deep2<7>" if variant & 65536 else "k_deep<%d>" % spl)) in s.hot_kernel()
         s.set_f(f0)
         s.run(12)
         s.run(7)
@@ -515,7 +516,7 @@ def test_slab_schedule_inside_lb_run_wall_families_single_rank(lbhip, bc):
     one.set_f(f0)
     one.run(20 + 7 + 4 + 9)
     want = one.get_fields(("f", "rho", "u", "v"))
-    for variant in (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256, 97, 33):
+    for variant in (97 | 256 | 4096 | 16384 | 32768 | 65536, 97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256, 97, 33):
         s = Simulation(nx, ny, 1.4, bc=bc, obstacle_mask=mask, halo=True, **kw)
         s.set_variant(variant)
         s.comm_init(comm_unique_id(), 0, 1)

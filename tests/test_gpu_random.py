@@ -11,7 +11,8 @@ from test_gpu_parity import assert_fields_close, _random_state
 pytestmark = pytest.mark.gpu
 
 # NT / tile shapes / XCD order / two-, three-, four-step marching kernels / LDS-tile kernel / the automatic choice
-VARIANTS = (1, 9, 16, 24, 33, 41, 97, 105, 97 | 256, 105 | 256, 97 | 256 | 4096, 105 | 256 | 4096, 97 | 256 | 4096 | 16384, 105 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768, 105 | 256 | 4096 | 16384 | 32768, 512, 512 | 1, -1)
+VARIANTS = (1, 9, 16, 24, 33, 41, 97, 105, 97 | 256, 105 | 256, 97 | 256 | 4096, 105 | 256 | 4096, 97 | 256 | 4096 | 16384, 105 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768, 105 | 256 | 4096 | 16384 | 32768,
+            97 | 256 | 4096 | 16384 | 32768 | 65536, 105 | 256 | 4096 | 16384 | 32768 | 65536, 512, 512 | 1, -1)
 WIDTHS = (2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 600, 768, 1021, 1024, 1028, 1280)
 
 

@@ -131,6 +131,11 @@ def check_waits(obj, text=None):
             continue
         w = c["w9"] + c["w12"]
         checked += w
+        if "k_deep2" in name:
+            # a front wave of k_deep2 stores nothing: its wait is vmcnt(0), whatever else (the back waves' stores, spills) is the compiler's
+            if w:
+                problems.append("%s: %d waits vmcnt(9 / 12) in a kernel whose front waves store nothing" % (name, w))
+            continue
         if (c["w9"] and c["w12"]) or not w:
             problems.append("%s: %d waits vmcnt(9), %d waits vmcnt(12) beside %d window loads" % (name, c["w9"], c["w12"], c["win"]))
             continue

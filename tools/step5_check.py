@@ -15,7 +15,9 @@ from LB_D2Q9.simulation import Simulation  # noqa: E402
 W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
 SIX = "--six" in sys.argv                       # k_deep<6> (variant bit 14) instead of k_step5 (bit 12)
 SEVEN = "--seven" in sys.argv                   # k_deep<7> (variant bit 15)
-DEEP = 97 | 256 | 4096 | (16384 if SIX or SEVEN else 0) | (32768 if SEVEN else 0)
+DEEP2 = "--deep2" in sys.argv                   # k_deep2 (variant bit 16: the seven-step launches by two waves per strip and direction)
+SEVEN = SEVEN or DEEP2
+DEEP = 97 | 256 | 4096 | (16384 if SIX or SEVEN else 0) | (32768 if SEVEN else 0) | (65536 if DEEP2 else 0)
 DEEP_SPL = 7 if SEVEN else (6 if SIX else 5)
 
 
@@ -45,6 +47,7 @@ def bitwise():
             s.set_variant(variant)
             if variant:
                 assert s.steps_per_launch() == DEEP_SPL, s.steps_per_launch()
+                assert ("k_deep2" in s.hot_kernel()) == DEEP2, s.hot_kernel()
             s.set_f(f0)
             s.run(7)
             s.run(13)
@@ -64,7 +67,8 @@ def bitwise():
 def timing(sizes):
     for n in sizes:
         for bc in ("periodic", "pipe"):
-            for name, variant in (("k_step5", 353 | 4096), ("k_deep<6>", 353 | 4096 | 16384), ("k_deep<7>", 353 | 4096 | 16384 | 32768), ("k_step5", 353 | 4096), ("k_deep<6>", 353 | 4096 | 16384), ("k_deep<7>", 353 | 4096 | 16384 | 32768)):
+            for name, variant in (("k_deep<6>", 353 | 4096 | 16384), ("k_deep<7>", 353 | 4096 | 16384 | 32768), ("k_deep2<7>", 353 | 4096 | 16384 | 32768 | 65536),
+                                  ("k_deep<6>", 353 | 4096 | 16384), ("k_deep<7>", 353 | 4096 | 16384 | 32768), ("k_deep2<7>", 353 | 4096 | 16384 | 32768 | 65536)):
                 s = Simulation(n, n, 1.7, bc=bc, inlet_rho=1.003)
                 s.set_variant(variant)
                 spl = s.steps_per_launch()
