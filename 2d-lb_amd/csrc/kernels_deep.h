@@ -319,6 +319,7 @@ __device__ __forceinline__ void deep_row_issue_lds(const StepArgs &a, int r, int
         const long long P = a.pitch, S = a.plane;
         const float *s = a.src;
         const int yl = o.rr;
+        unsigned m0_kept;                               // (M0 is the compiler's: every block puts back what it found there)
         // (whatever still reads the slot -- the previous row's take -- has its data first)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (BC == LB_BC_PERIODIC) {
@@ -326,41 +327,44 @@ __device__ __forceinline__ void deep_row_issue_lds(const StepArgs &a, int r, int
             const bool wrap_w = x4 == 0, wrap_e = c >= 0 && c < 4;
             if (wrap_w) {
                 const float *e = s + a.nx - 1;
-                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\t"
-                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
-                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, off"
-                             :: "v"(e + 1 * S + (long long)yl * P), "v"(e + 5 * S + (long long)ym * P), "v"(e + 8 * S + (long long)yp * P),
-                                "s"(slot + 9 * 1024 + 256)
-                             : "memory", "m0", "scc");
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_kept)
+                             : "v"(e + 1 * S + (long long)yl * P), "v"(e + 5 * S + (long long)ym * P), "v"(e + 8 * S + (long long)yp * P),
+                               "s"(slot + 9 * 1024 + 256)
+                             : "memory", "scc");
             }
             if (wrap_e) {
-                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\t"
-                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
-                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, off"
-                             :: "v"(s + 3 * S + (long long)yl * P), "v"(s + 6 * S + (long long)ym * P), "v"(s + 7 * S + (long long)yp * P),
-                                "s"(slot + 9 * 1024 + 256)
-                             : "memory", "m0", "scc");
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
+                             "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_kept)
+                             : "v"(s + 3 * S + (long long)yl * P), "v"(s + 6 * S + (long long)ym * P), "v"(s + 7 * S + (long long)yp * P),
+                               "s"(slot + 9 * 1024 + 256)
+                             : "memory", "scc");
             }
         }
         const u4v r0 = deep_rsrc_words(s + (long long)yl * P - 1), rm = deep_rsrc_words(s + (long long)ym * P - 1),
                   rp = deep_rsrc_words(s + (long long)yp * P - 1);
         const unsigned S4 = (unsigned)a.plane * 4u;
         const int v0 = x4 * 4, v4 = v0 + 4, v8 = v0 + 8;       // pulled from the left / the same column / from the right
-        asm volatile("s_mov_b32 m0, %14\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %3, %6 offen lds\n\t"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %15\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
                      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %7 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %8 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %9 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %4, %10 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %11 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %12 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %5, %13 offen lds"
-                     :: "v"(v0), "v"(v4), "v"(v8), "s"(r0), "s"(rm), "s"(rp), "s"(S4), "s"(2u * S4), "s"(3u * S4), "s"(4u * S4), "s"(5u * S4),
-                        "s"(6u * S4), "s"(7u * S4), "s"(8u * S4), "s"(slot)
-                     : "memory", "m0", "scc");
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %8 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %9 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, %10 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %11 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %12 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, %13 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, %14 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_kept)
+                     : "v"(v0), "v"(v4), "v"(v8), "s"(r0), "s"(rm), "s"(rp), "s"(S4), "s"(2u * S4), "s"(3u * S4), "s"(4u * S4), "s"(5u * S4),
+                       "s"(6u * S4), "s"(7u * S4), "s"(8u * S4), "s"(slot)
+                     : "memory", "scc");
         if (MASK)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                         :: "v"(lane_ptr(a.mask + (long long)yl * a.fpitch, x4)), "s"(slot + 9 * 1024) : "memory", "m0");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_kept) : "v"(lane_ptr(a.mask + (long long)yl * a.fpitch, x4)), "s"(slot + 9 * 1024) : "memory");
     }
 }
 // the row issued last: everything this wave has in flight is that row
