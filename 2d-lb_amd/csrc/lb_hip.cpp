@@ -1305,6 +1305,38 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     }
     for (int c = 0; c < NC; ++c)
         if (usable[c] && (best < 0 || ms_min[c] < best_ms)) { best = c; best_ms = ms_min[c]; }
+    // A runner-up within 5 % (round 5: k_step5 and k_deep<7> on config 5, 19.7 against 19.1 steps per ms -- the choice flipped from run to
+    // run, the rocprofv3 profile and the driver's line named different kernels): the two once more over samples four times as long, three
+    // rounds alternating, minimum of each.
+    if (best >= 0 && !small_grid(s)) {
+        int second = -1;
+        for (int c = 0; c < NC; ++c)
+            if (usable[c] && c != best && cands[c].steps != cands[best].steps && (second < 0 || ms_min[c] < ms_min[second])) second = c;
+        if (second >= 0 && ms_min[second] < 1.05f * best_ms) {
+            float again[2] = {1e30f, 1e30f};
+            const int pair[2] = {best, second};
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 2; ++k) {
+                    const Cand &cd = cands[pair[k]];
+                    s->tuned_steps = cd.steps;
+                    s->tuned_wpc = cd.wpc;
+                    const int per = 4 * per_of(cd);
+                    TUNE_TRY(hipEventRecord(e0, s->stream));
+                    int rc = run_whole_grid(s, per, false);
+                    if (rc) return bail(rc);
+                    TUNE_TRY(hipEventRecord(e1, s->stream));
+                    TUNE_TRY(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    TUNE_TRY(hipEventElapsedTime(&ms, e0, e1));
+                    used += per;
+                    again[k] = std::min(again[k], ms / (float)per);
+                }
+            ms_min[best] = again[0];
+            ms_min[second] = again[1];
+            if (again[1] < again[0]) best = second;
+            best_ms = ms_min[best];
+        }
+    }
 #undef TUNE_TRY
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -2951,6 +2983,9 @@ int lb_autotune(lb_sim *s)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune inside a split step");
     if (!autotune_applies(s)) return 0;                // nothing to choose between
+    // (LB_TUNE_CACHE holds a result for this shape: taken over, as lb_autotune_quick and lb_run do -- a profiled run then names the
+    //  kernel the un-profiled run before it chose: tools/gpu_profile.sh)
+    if (!s->tune_cache_checked && s->variant < 0 && !s->tuned_steps && tune_cache_apply(s)) return 0;
     DeviceGuard guard(s->p.device);
     return autotune_whole_grid(s, 6);
 }
