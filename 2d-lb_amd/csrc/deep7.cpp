@@ -17,7 +17,7 @@ struct LD {
 
 }  // namespace
 
-void lbk_launch_deep7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a)
+bool lbk_launch_deep7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a)
 {
-    lbk_dispatch<LD, false>(bc, mask, macro, g, a);
+    return lbk_dispatch<LD, false>(bc, mask, macro, g, a);
 }

@@ -23,16 +23,17 @@ void lbk_launch_step_batch(bool mask, bool macro, dim3 grid, dim3 block, hipStre
 void lbk_launch_march23(int depth, int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                       // march23.cpp
 void lbk_launch_march4(int bc, bool mask, bool macro, bool prefetch, const MarchLaunch &g, const StepArgs &a);                    // march4.cpp
 void lbk_launch_march5(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                   // march5.cpp
-void lbk_launch_deep6(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep6.cpp (not VELOCITY_INLET)
-void lbk_launch_deep7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep7.cpp (not VELOCITY_INLET)
-void lbk_launch_deep2_7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                  // deep2.cpp: k_deep2, four waves per workgroup (not VELOCITY_INLET)
+bool lbk_launch_deep6(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep6.cpp (not VELOCITY_INLET)
+bool lbk_launch_deep7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                    // deep7.cpp (not VELOCITY_INLET)
+bool lbk_launch_deep2_7(int bc, bool mask, bool macro, const MarchLaunch &g, const StepArgs &a);                                  // deep2.cpp: k_deep2, four waves per workgroup (not VELOCITY_INLET)
 // k_tile4 over a whole grid of nx x h cells; shape 0: 32 x 16 tiles, two cells per thread; 1: 32 x 16, one; 2: 16 x 16, one
-void lbk_launch_tile4(int bc, bool mask, bool macro, int shape, int nx, int h, hipStream_t st, const StepArgs &a);                // tile.cpp (not VELOCITY_INLET)
+bool lbk_launch_tile4(int bc, bool mask, bool macro, int shape, int nx, int h, hipStream_t st, const StepArgs &a);                // tile.cpp (not VELOCITY_INLET)
 void lbk_launch_vel_band(bool mask, bool macro, int d, dim3 grid, dim3 block, hipStream_t st, const StepArgs &a);                 // tile.cpp (d = 3, 4, 5)
 
-// Run-time (bc, mask, macro) -> L<BC, MASK, MACRO>::go(args...).  VEL: the family list includes LB_BC_VELOCITY_INLET.
+// Run-time (bc, mask, macro) -> L<BC, MASK, MACRO>::go(args...).  VEL: the family list includes LB_BC_VELOCITY_INLET.  Returns false --
+// and launches nothing -- for a family the unit does not instantiate: the caller reports it (a silent no-op would skip time steps).
 template <template <int, bool, bool> class L, bool VEL, typename... A>
-inline void lbk_dispatch(int bc, bool mask, bool macro, const A &...args)
+inline bool lbk_dispatch(int bc, bool mask, bool macro, const A &...args)
 {
 #define LBK_MM(BC)                                                            \
     do {                                                                      \
@@ -45,8 +46,10 @@ inline void lbk_dispatch(int bc, bool mask, bool macro, const A &...args)
     case LB_BC_PERIODIC: LBK_MM(LB_BC_PERIODIC); break;
     case LB_BC_VELOCITY_INLET:
         if constexpr (VEL) { LBK_MM(LB_BC_VELOCITY_INLET); }
+        else return false;
         break;
     default: LBK_MM(LB_BC_CAVITY); break;
     }
 #undef LBK_MM
+    return true;
 }

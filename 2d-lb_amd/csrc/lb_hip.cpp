@@ -315,7 +315,8 @@ int effective_variant(const lb_sim *s)
     //  round 5's 3800^2 / 4000^2 a rank with a mask and a rank without could pick different cycles between the two sizes)
     const double deep_side = periodic_box ? (whole_grid ? 1500.0 : 2400.0)
                                           : (whole_grid ? (s->has_mask ? 2150.0 : 2300.0) : 3800.0);
-    if (cells >= deep_side * deep_side) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
+    // (not the velocity-inlet family: its wall-row bands stop at five steps and k_deep has no instantiation for it)
+    if (cells >= deep_side * deep_side && s->p.bc_mode != LB_BC_VELOCITY_INLET) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
     return v;
 }
 
@@ -340,7 +341,7 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 // A marching launch of `depth` time steps per pass (k_step2 ... k_step5, k_deep), by the translation unit that instantiates that depth.
 // k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
 // instantiation without an obstacle mask but the D2Q9i fork's); variant bit 10 switches it off (A/B runs).
-void launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs, int row_end,
+bool launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs, int row_end,
                   bool macro, int depth)
 {
     const int waves = (depth >= 4) ? STEP4_WAVES : 4;      // waves per workgroup: k_step4 ... k_step6: the two directions of ONE item
@@ -351,12 +352,14 @@ void launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items,
     g.stream = st;
     g.strips = strips; g.seg_rows = seg_rows; g.nsegs = nsegs; g.row_end = row_end;
     const int bc = kernel_bc(s);
-    if (depth == 7 && (effective_variant(s) & 65536)) lbk_launch_deep2_7(bc, s->has_mask, macro, g, a);    // k_deep2: four waves per workgroup
-    else if (depth == 7) lbk_launch_deep7(bc, s->has_mask, macro, g, a);
-    else if (depth == 6) lbk_launch_deep6(bc, s->has_mask, macro, g, a);
-    else if (depth == 5) lbk_launch_march5(bc, s->has_mask, macro, g, a);
+    // (false: the unit has no instantiation for this boundary family -- k_deep / k_deep2 and the velocity-inlet family)
+    if (depth == 7 && (effective_variant(s) & 65536)) return lbk_launch_deep2_7(bc, s->has_mask, macro, g, a);    // k_deep2: four waves per workgroup
+    if (depth == 7) return lbk_launch_deep7(bc, s->has_mask, macro, g, a);
+    if (depth == 6) return lbk_launch_deep6(bc, s->has_mask, macro, g, a);
+    if (depth == 5) lbk_launch_march5(bc, s->has_mask, macro, g, a);
     else if (depth == 4) lbk_launch_march4(bc, s->has_mask, macro, !(effective_variant(s) & 1024), g, a);
     else lbk_launch_march23(depth, bc, s->has_mask, macro, g, a);
+    return true;
 }
 
 // The marching kernels address the nine planes of a row through ONE scalar base and a 32-bit byte offset per lane that carries the
@@ -500,7 +503,8 @@ int launch_step2(lb_sim *s, hipStream_t st, int row_begin, int row_end, bool mac
     static const int turn_bit = getenv("LB_PRIO_TURN_BIT") ? atoi(getenv("LB_PRIO_TURN_BIT")) : 13;    // tuning knob
     a.prio_turns = (variant & 2048) ? 0 : turn_bit;
     a.nts = nts ? 1 : 0;                       // (the marching kernels take it at run time)
-    launch_march(s, st, a, items, strips, seg_rows, segs, row_end, macro, depth);
+    if (!launch_march(s, st, a, items, strips, seg_rows, segs, row_end, macro, depth))
+        return fail(LB_ERR_STATE, "no %d-step kernel for this boundary family (the caller's schedule must not ask for one)", depth);
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }
@@ -528,7 +532,8 @@ int launch_tile4(lb_sim *s, bool macro)
 {
     macro = macro && !lazy_macro(s);
     const StepArgs a = step_args(s, 0, 1, s->H);
-    lbk_launch_tile4(kernel_bc(s), s->has_mask, macro, tile_shape_of(s), s->p.nx, s->H, s->stream, a);
+    if (!lbk_launch_tile4(kernel_bc(s), s->has_mask, macro, tile_shape_of(s), s->p.nx, s->H, s->stream, a))
+        return fail(LB_ERR_STATE, "no LDS-tile kernel for this boundary family");
     HIP_TRY(hipGetLastError());
     return LB_OK;
 }

@@ -33,9 +33,9 @@ void vel_band(int d, dim3 grid, dim3 block, hipStream_t st, const StepArgs &a)
 
 }  // namespace
 
-void lbk_launch_tile4(int bc, bool mask, bool macro, int shape, int nx, int h, hipStream_t st, const StepArgs &a)
+bool lbk_launch_tile4(int bc, bool mask, bool macro, int shape, int nx, int h, hipStream_t st, const StepArgs &a)
 {
-    lbk_dispatch<LT, false>(bc, mask, macro, shape, nx, h, st, a);
+    return lbk_dispatch<LT, false>(bc, mask, macro, shape, nx, h, st, a);
 }
 
 void lbk_launch_vel_band(bool mask, bool macro, int d, dim3 grid, dim3 block, hipStream_t st, const StepArgs &a)
