@@ -15,7 +15,7 @@ def case(bc, nx, ny, steps, masked, **kw):
     u = (0.02 + 1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
     v = (1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
     out = []
-    for variant in (-1, 9):
+    for variant in (int(os.environ.get("LB_SOAK_VARIANT", "-1")), 9):       # (LB_SOAK_VARIANT=119137: k_deep2 for the seven-step launches)
         s = Simulation(nx, ny, 1.2, bc=bc, obstacle_mask=mask, **kw)
         s.set_variant(variant)
         s.init_equilibrium(rho, u, v)

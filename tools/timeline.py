@@ -24,7 +24,7 @@ def main():
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = (s - last_end[q]) / 1e3 if q in last_end else float("nan")
         last_end[q] = e
-        name = r["Kernel_Name"].split("(")[0][:60]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
         print("q%-3s start %9.1f  dur %8.1f  gap_same_q %7.1f  grid %-8s %s"
               % (q, (s - t0) / 1e3, (e - s) / 1e3, gap, r.get("Grid_Size", ""), name))
 
