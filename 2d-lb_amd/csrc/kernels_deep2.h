@@ -80,11 +80,17 @@ __device__ __forceinline__ void deep2_front(const StepArgs &a, const int x0, con
     deep2_front_fill<BC, MASK, F, RW, DOWN, 1>(a, cx, st, ra, rb, trip);
     if ((F - 1) & 1) ra = rb;                           // (position F - 1 is in ra or rb by its parity)
     for (; trip < trips; ++trip) {
+#ifdef LB_DIAG
+        if (!(a.diag & (1 << 24)))                      // timing only: no barriers in the steady state (races: wrong results)
+#endif
         deep2_barrier();
         if (trip < cx.n_iter) {
             deep_iter<BC, MASK, false, F, RW, 1, DOWN, F, -1, DEEP_FRONT>(a, cx, trip, st, ra, rb);
             ra = rb;
         }
+#ifdef LB_DIAG
+        if (!(a.diag & (1 << 24)))
+#endif
         deep2_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the row gathered behind the last position)
@@ -141,8 +147,14 @@ __device__ __forceinline__ void deep2_back(const StepArgs &a, const int x0, cons
     deep2_back_fill<BC, MASK, MACRO, DB, RW, DOWN, 1>(a, cx, st, cur, j);
     for (; j + F < trips; ++j) {
         if (j < cx.n_iter) deep2_take<MASK>(cx, cur);
+#ifdef LB_DIAG
+        if (!(a.diag & (1 << 24)))
+#endif
         deep2_barrier();
         if (j < cx.n_iter) deep_iter<BC, MASK, MACRO, DB, RW, 0, DOWN, DB, -1, DEEP_BACK>(a, cx, j, st, cur, cur);
+#ifdef LB_DIAG
+        if (!(a.diag & (1 << 24)))
+#endif
         deep2_barrier();
     }
 }
