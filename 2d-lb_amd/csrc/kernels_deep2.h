@@ -4,8 +4,9 @@
 // wave issues one instruction per ~5 cycles whatever the instruction: the vector ALU is busy 65 % of the time, the launch is bound
 // by instruction issue.  Round 5 priced a second wave per SIMD at "nothing" from two DIFFERENT kernels;
 // round 6 ran the SAME kernel both ways (k_deep<4>, 213 registers, 16 KB: profiles/r06_occ2_probe.txt, 8192^2, arithmetic only, no
-// global memory): four waves per CU 767 us per launch, eight waves per CU 415 us -- 1.85 x.  A SIMD fed by two waves issues their
-// scalar, LDS and memory instructions beside the other's vector instructions and covers their dependency stalls.
+// global memory): four waves per CU 767 us per launch, eight waves per CU 415 us -- of which ~1.4 x is the second wave's doing (a
+// quarter of the four-waves build's waves had doubled up on SIMDs and set its launch time: profiles/r06_occ2_placement.txt).  A SIMD fed
+// by two waves issues their scalar, LDS and memory instructions beside the other's vector instructions and covers their stalls.
 //
 // How.  A wave's state must halve.  So the D stages of a strip's march are split between two waves that share the strip: the FRONT
 // wave gathers the rows from memory (one row ahead, in a register window it waits for by hand: kernels_deep.h) and runs stages

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
-os.environ["LB_LIB"] = os.path.join(ROOT, "2d-lb_amd", "LB_D2Q9", "liblbhip_diag.so")
+os.environ["LB_LIB"] = os.environ.get("LB_TIMELINE_LIB") or os.path.join(ROOT, "2d-lb_amd", "LB_D2Q9", "liblbhip_diag.so")
 os.environ["LB_DIAG"] = os.environ.get("LB_DIAG", "4096")
 if len(sys.argv) > 2:
     os.environ["LB_STEP2_WAVES_PER_CU"] = sys.argv[2]
