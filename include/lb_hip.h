@@ -297,7 +297,8 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 /* Pick the fastest configuration of the fused kernels for THIS grid by timing each candidate on a few
  * live time steps (all candidates give bitwise identical results, so this simply advances the
  * simulation): returns the number of steps advanced (0 when there is nothing to choose), <0 on error.
- * Blocks the host (it reads HIP event times).  lb_run never tunes by itself. */
+ * Blocks the host (it reads HIP event times).  lb_run never tunes by itself.  A runner-up within 5 % of the winner is timed against it
+ * once more over longer samples.  With LB_TUNE_CACHE set (below) a result remembered for this shape is taken over instead (returns 0). */
 int lb_autotune(lb_sim *s);
 /* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
  * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
