@@ -873,7 +873,10 @@ int exchange_peer(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
 int exchange_halo(lb_sim *s, int which, hipStream_t q, const HaloTables &T)
 {
     // (lb_exchange_timing: what an exchange takes on its stream -- pack / push, the transfer, the wait for the neighbours, unpack)
-    const bool timed = s->xt_on && s->xt_count < lb_sim::XT_RING;
+    // (not inside a stream capture -- LB_CYCLE_GRAPH=1 --: timing events cannot be recorded into a graph)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s->xt_on) (void)hipStreamIsCapturing(q, &cap);
+    const bool timed = s->xt_on && cap == hipStreamCaptureStatusNone && s->xt_count < lb_sim::XT_RING;
     if (s->xt_on && !timed) ++s->xt_dropped;
     if (timed) HIP_TRY(hipEventRecord(s->xt_ev[2 * s->xt_count], q));
     const int rc = s->peer_connected ? exchange_peer(s, which, q, T) : exchange_rccl(s, which, q, T);
