@@ -1056,15 +1056,20 @@ int launch_bands(lb_sim *s, hipStream_t st, int lo_s, int hi_s, int lo_n, int hi
 // so the exchange has from the end of E2a to the start of E1a, more than a whole launch, and every workgroup slot stays busy.
 // LB_BAND_EXTRA=<rows> fixes B (0 = the bands of rounds 3-5), LB_BAND_SLACK=<iterations> the head start, LB_SPLIT_BANDS=0 keeps
 // each band one launch (lb_run_group and the captured cycles always do).
-// (Which transport: one box, k MLUPS per GPU of a strong-scaled 8192^2, 8 | 4 | 2 slabs, profiles/r06_slab_proxy_split.txt -- peer: one
-//  launch per band 370-386 | 437-443 | 461-468, split 372-383 | 424-426 | 460; RCCL: one launch 331-341 | 356-357 | 363-380, split 353-388 |
-//  372-386 | 420-445.  The peer transport's exchange is one push kernel, ~16 us: it fits the bands' head start and the second fill of a split
-//  band is all the split costs; RCCL's pack, send / receive, unpack take 30-160 us.  Hence: split under RCCL, one launch per band under the
-//  peer transport; LB_SPLIT_BANDS=0 / 1 forces either.)
-bool split_bands(const lb_sim *s)
+// (Which transport.  RCCL's pack, send / receive, unpack take 30-160 us and never fitted a thick band's head start: one launch per band
+//  331-341 | 356-357 | 363-380 k MLUPS per GPU at 8 | 4 | 2 slabs of a strong-scaled 8192^2, split 353-388 | 372-386 | 420-445
+//  (profiles/r06_slab_proxy_split.txt).  The peer transport's exchange is one push kernel, ~16 us, and on that box one launch per band
+//  did as well or 3 % better (370-386 | 437-443 | 461-468 against 372-383 | 424-426 | 460) -- but on two later boxes it lost 8-15 %
+//  wherever the bands are long: three alternating repetitions, 8 | 4 | 2 | 1 slabs, one launch 398-403 | 384-408 | 417-436 | 432-456,
+//  split 397-399 | 449-453 | 470-474 | 484 = 0.92 | 0.97 | 0.98 | 0.99 of the plain grids of those sizes
+//  (profiles/r06_slab_proxy_peer_split_ab.txt; bench.py --force-slab-path: 415 k one launch, 467 k split).  With one launch per band
+//  the next E1 queues behind E2 AND the exchange on one stream, and whether that chain keeps up with the interior depends on the box's
+//  issue rate; split, nothing of a band but its outer 2D rows waits for anything.  Hence split for both transports; LB_SPLIT_BANDS=0
+//  keeps each band one launch.)
+bool split_bands(const lb_sim *)
 {
     static const int forced = getenv("LB_SPLIT_BANDS") ? (atoi(getenv("LB_SPLIT_BANDS")) != 0) : -1;
-    return forced >= 0 ? forced != 0 : !s->peer_connected;
+    return forced != 0;
 }
 
 int band_extra(const lb_sim *s, int D, bool split = false)
@@ -2754,6 +2759,14 @@ int lb_comm_init(lb_sim *s, const void *unique_id_128, int rank, int nranks)
         HIP_TRY(hipMalloc(&s->halo_buf, sizeof(float) * 4 * HALO_SEGS_DEEP * s->p.nx));
         s->bytes += sizeof(float) * 4 * HALO_SEGS_DEEP * s->p.nx;
     }
+    // (RCCL's channel count.  Left alone, RCCL spreads the two sends and receives of an exchange -- 14 rows x 3 populations per direction,
+    //  ~1.4 MB at 8192 columns -- over 59 workgroups of 256 threads with 20-37 KB of LDS each; k_deep's workgroups hold a CU's whole LDS
+    //  in pairs, so those 59 trickle in as slots come free, sit on the SIMDs of an issue-bound kernel for most of a launch and take slots
+    //  from the band launch behind them: one slab of four of an 8192^2 lattice 381 k MLUPS, with NCCL_MAX_NCHANNELS=2..16 438-450 k
+    //  (profiles/r06c_slab_proxy_channels.txt, timeline profiles/r06c_slab_timeline_rccl_4.txt).  The per-communicator form of that cap,
+    //  ncclConfig_t::maxCTAs through ncclCommInitRankConfig, is accepted and IGNORED by RCCL 2.26 / 2.27 (59 workgroups still:
+    //  profiles/r06c_slab_timeline_rccl_4_cap8.txt), and the environment variable is read once per process at the first communicator's
+    //  creation -- usually the caller's.  So it is the caller's to set before anything touches RCCL: bench.py does, INTEGRATION.md says so.)
     NCCL_TRY(g_rccl.CommInitRank(&s->comm, nranks, id, rank));
     s->rank = rank;
     s->nranks = nranks;

@@ -229,7 +229,7 @@ def measure_config(config, local_rank, steps, warmup, min_blocks, min_timed_s, s
             total += walls[-1]
         wall, ev_ms = statistics.median(walls), statistics.median(evs)
         health = sim.check()
-        mean_rho = health["sum_rho"] / (float(n) * n)
+        mean_rho = health["sum_rho"] / (float(n) * ny_all)
         if health["n_nonfinite"] or abs(mean_rho - 1.0) > 1e-3 or not health["max_mach"] < 0.3:
             raise SystemExit("bench: non-physical state after config %d (%r)" % (config, health))
         spl = sim.steps_per_launch()
@@ -365,6 +365,9 @@ def main():
     ap.add_argument("--force-slab-path", action="store_true",
                     help="run through DistributedSlab / the RCCL halo path even with one rank (a 1-rank periodic "
                          "ring exchanging with itself): exercises the multi-GPU code on a single GPU")
+    ap.add_argument("--slab-rows", type=int, default=0,
+                    help="diagnostic, with --force-slab-path: the lattice is SIZE columns x this many rows -- the slab one of N ranks "
+                         "of a strong-scaled SIZE^2 lattice would hold, in this process's structure (torch.distributed, RCCL's streams)")
     ap.add_argument("--calibrate", type=int, default=3,
                     help="launch N plain float4 copies of known size before the timed region (the device's own "
                          "streaming rate, `copy_GBps`; also the FETCH_SIZE calibration of rocprofv3 --pmc runs); 0 = skip")
@@ -416,6 +419,7 @@ def main():
     from LB_D2Q9.slabs import DistributedSlab
 
     n = args.size
+    ny_all = args.slab_rows if (args.slab_rows and args.force_slab_path and args.config == 4) else n     # rows of the whole lattice
     bytes_per_cell, what = B_ALG, None
     if args.config != 4:
         sim, what, bytes_per_cell = workload(args.config, n, args.omega, local_rank, eager_macro=args.eager_macro)
@@ -433,7 +437,7 @@ def main():
         for transport in chain:
             failed = 0
             try:
-                slab = DistributedSlab(n, n, args.omega, bc="periodic", transport=transport, device=local_rank,
+                slab = DistributedSlab(n, ny_all, args.omega, bc="periodic", transport=transport, device=local_rank,
                                        eager_macro=args.eager_macro)
             except Exception as exc:                                   # noqa: BLE001 - reported below
                 failed = 1
@@ -452,7 +456,7 @@ def main():
     if args.variant is not None:
         eng.set_variant(args.variant)
     if args.config == 4:
-        rho, u, v = shear_layer(n, n, y0, h)
+        rho, u, v = shear_layer(n, ny_all, y0, h)
         eng.init_equilibrium(rho, u, v)        # feq and f = feq are built on the device
         del rho, u, v
 
@@ -542,12 +546,12 @@ def main():
     # sanity: the run must have produced finite, physical numbers (guards against timing a broken kernel) -- one
     # device pass and 24 bytes to the host (lb_check) instead of downloading a 268 MB plane
     health = sim.check() if dist is not None else eng.check()
-    mean_rho = health["sum_rho"] / (float(n) * n)
+    mean_rho = health["sum_rho"] / (float(n) * ny_all)
     if health["n_nonfinite"] or abs(mean_rho - 1.0) > 1e-3 or not health["max_mach"] < 0.3:
         raise SystemExit("bench: non-physical state after the run (%r)" % (health,))
 
     if rank == 0:
-        cells = float(n) * n
+        cells = float(n) * ny_all
         mlups = cells * args.steps / wall / 1e6
         # dominant kernel = the fused step over this rank's rows; rank 0's slab is representative.
         # One launch advances spl time steps: it performs spl x n x h lattice updates, but what it MUST move is
@@ -618,9 +622,9 @@ def main():
                        "ms_per_step_with_closing_barrier": round(statistics.median(walls_incl) * 1e3 / args.steps, 4),
                        "timed_s": round(total, 3)},
             "config": {"workload": what or "%dx%d periodic double shear layer, D2Q9 BGK fp32, omega=%g, "
-                                           "%d row slab(s) of %d rows%s" % (n, n, args.omega, world, h,
+                                           "%d row slab(s) of %d rows%s" % (n, ny_all, args.omega, world, h,
                                                                             "" if dist is None else ", halo via " + args.transport),
-                       "baseline_config": args.config, "grid": [n, n], "bytes_per_lattice_update": B_ALG},
+                       "baseline_config": args.config, "grid": [n, ny_all], "bytes_per_lattice_update": B_ALG},
             "health": health,
             "roofline": roof,
             "compute": compute,

@@ -1,0 +1,31 @@
+#!/bin/bash
+# round 6, GPU run 29: bench.py itself on the slab one of 8 | 4 | 2 ranks would hold (--force-slab-path --slab-rows), hardware queues 4 | 8,
+# both transports; and the timeline of the 1024-row case at 4 queues
+set -u
+cd $GRAFT_REPO_ROOT
+P=gpurun_out/r06g_bench_slab_rows.txt
+: > $P
+for rep in 1 2; do
+for hq in default 8; do
+  if [ $hq = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$hq; fi
+  for rows in 1024 2048 4096; do
+    for t in rccl peer; do
+      timeout 200 python3 bench.py --force-slab-path --slab-rows $rows --transport $t --steps 56 --warmup 14 --no-cpu-baseline --no-other-configs > gpurun_out/x.json 2> gpurun_out/x.err
+      python3 - $hq $rows $t >> $P <<'PY'
+import json, sys
+try:
+    d = json.loads(open("gpurun_out/x.json").read().strip().splitlines()[-1])
+    print("hw queues %-7s rows %5s %-4s: %9.1f MLUPS, exchange %.1f us mean" % (sys.argv[1], sys.argv[2], sys.argv[3], d["value"], 1e3 * d["slabs"]["per_rank"][0]["exchange_ms_mean"]))
+except Exception as e:
+    print("hw queues %s rows %s %s: no line (%s)" % (sys.argv[1], sys.argv[2], sys.argv[3], e)); print(open("gpurun_out/x.err").read()[-800:])
+PY
+    done
+  done
+done
+done
+unset GPU_MAX_HW_QUEUES
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/tl_bench -- python3 $GRAFT_REPO_ROOT/bench.py --force-slab-path --slab-rows 1024 --transport rccl --steps 56 --warmup 14 --no-cpu-baseline --no-other-configs --min-blocks 3 > $GRAFT_REPO_ROOT/gpurun_out/tl_bench.log 2>&1)
+python3 tools/timeline.py gpurun_out/tl_bench 30 GenericKernel > gpurun_out/r06g_bench_timeline_rccl_1024.txt 2>&1
+rm -rf gpurun_out/tl_bench gpurun_out/x.json gpurun_out/x.err
+cat $P
+cut -c1-150 gpurun_out/r06g_bench_timeline_rccl_1024.txt

@@ -21,7 +21,19 @@ def main():
     ap.add_argument("--variants", default="-1,9")
     ap.add_argument("--reps", type=int, default=3, help="timed runs per configuration; the best counts")
     ap.add_argument("--transports", default="rccl", help="comma list of rccl, peer (the slab path as a 1-rank ring over that transport)")
+    ap.add_argument("--torch-dist", action="store_true",
+                    help="first join a one-rank torch.distributed group over RCCL, as bench.py does: torch's and RCCL's own streams then exist "
+                         "before the handles' and compete for the process's hardware queues (GPU_MAX_HW_QUEUES)")
     args = ap.parse_args()
+    if args.torch_dist:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dist.barrier()
     from LB_D2Q9.simulation import Simulation, comm_unique_id
     from bench import shear_layer
     for parts in [int(p) for p in args.parts.split(",")]:
