@@ -1616,6 +1616,11 @@ int lb_create(const lb_params *p, lb_sim **out)
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
+    // (Three streams that must not share a hardware queue -- interior, edge bands, halo exchange.  HIP maps a process's streams onto
+    //  GPU_MAX_HW_QUEUES queues, four by default, per priority, and not once and for all: a probe at creation saw three queues in a
+    //  process whose timeline later shows the exchange on the interior's queue.  The process decides -- bench.py sets 8 --; a
+    //  communication stream at the highest priority, a queue pool of its own, pushed the EDGE stream onto the interior's queue in
+    //  bench.py's process structure, 370 -> 230 k MLUPS: profiles/r06_experiments.txt section 10c, r06h_bench_comm_prio.txt.)
     CREATE_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     {
         // The edge stream (edge bands, halo push / RCCL) at NORMAL priority, like the other two.  Rounds 1-2 created it at the

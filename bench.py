@@ -55,6 +55,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "2d-lb_amd"), ROOT]
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (four by default), and streams that share one run in submission
+# order.  A slab handle needs three that do not (interior, edge bands, halo exchange); under torch.distributed -- torch's own and RCCL's
+# streams come first -- the exchange has been seen on the interior's queue, ~45 us per halo cycle that nothing hides, and with a
+# priority stream in the mix the edge bands on it (-35 %): profiles/r06_experiments.txt section 10c.  The HIP runtime reads the variable
+# when it is loaded, i.e. at `import torch` below; the caller's own value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 B_ALG = 72.0              # algorithmic bytes per lattice update: 9 fp32 read + 9 fp32 written
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling quoted by the same guide
