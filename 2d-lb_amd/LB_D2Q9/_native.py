@@ -19,7 +19,7 @@ LB_SEM_OPENCL, LB_SEM_CYTHON, LB_SEM_OPENCL_D2Q9I = 0, 1, 2
 BC_NAMES = {"pipe": LB_BC_PIPE, "periodic": LB_BC_PERIODIC, "cavity": LB_BC_CAVITY,
             "velocity_inlet": LB_BC_VELOCITY_INLET}
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # every symbol include/lb_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -32,6 +32,7 @@ EXPORTS = (
     "lb_comm_available", "lb_comm_unique_id", "lb_comm_init", "lb_timer_start", "lb_timer_stop", "lb_layout", "lb_set_variant", "lb_copy_calibration", "lb_steps_per_launch", "lb_plan_launches", "lb_autotune",
     "lb_autotune_quick", "lb_hot_kernel", "lb_get_corner_state", "lb_set_corner_state", "lb_check", "lb_set_debug_sync",
     "lb_peer_export", "lb_peer_connect", "lb_set_params_f64", "lb_set_slab_cycle", "lb_exchange_timing", "lb_exchange_stats",
+    "lb_set_exchange_inline",
 )
 
 
@@ -95,6 +96,8 @@ def lib():
         L.lb_exchange_timing.argtypes = [h, I]
         L.lb_exchange_stats.argtypes = [h, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                         ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
+    if L.lb_abi_version() >= 10:
+        L.lb_set_exchange_inline.argtypes = [h, I]
     L.lb_comm_init.argtypes = [h, vp, I, I]
     L.lb_timer_stop.argtypes = [h, fp]
     L.lb_layout.argtypes = [h, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64)]

@@ -452,6 +452,11 @@ class Simulation(object):
         same value (lb_set_slab_cycle)."""
         check(self._lib.lb_set_slab_cycle(self._h, int(depth)))
 
+    def set_exchange_inline(self, on):
+        """Slab handles: the halo exchange of a cycle on the compute stream, between the interior launches (True), instead of beside
+        them on the communication stream (False, the default); every rank of a run must set the same value (lb_set_exchange_inline)."""
+        check(self._lib.lb_set_exchange_inline(self._h, int(bool(on))))
+
     def exchange_timing(self, enable=True):
         """Slab handles: time every halo exchange of run() on its stream from now on (lb_exchange_timing)."""
         check(self._lib.lb_exchange_timing(self._h, int(bool(enable))))

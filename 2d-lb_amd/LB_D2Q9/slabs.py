@@ -363,24 +363,29 @@ class DistributedSlab(_SlabSet):
         self.run(n, wait=False)
         return self.engine.timer_stop()
 
-    def autotune(self, depths=(7, 6, 5), cycles=3, rounds=2):
-        """Collective: the ranks time the halo cycle on each candidate depth of the fused kernel TOGETHER -- `cycles` cycles of
-        2 x depth live time steps each (every candidate gives the same bits: tuning advances the simulation), the slowest rank's
-        time counts, the best of `rounds` --, and all set the depth that is fastest per time step (lb_set_slab_cycle).  A whole-grid
-        handle tunes itself (Simulation.autotune); slabs cannot: every rank must run the same schedule.  Returns
-        {"depth": chosen, "ms_per_step": {depth: slowest rank's}, "steps": time steps advanced}; nothing to choose on the
-        python-driven transport."""
+    def autotune(self, depths=(7, 6, 5), cycles=3, rounds=2, placements=(False, True)):
+        """Collective: the ranks time the halo cycle on each candidate TOGETHER -- a depth of the fused kernel x where the exchange
+        runs (beside the interior launches on its own stream, or between them on the compute stream: lb_set_exchange_inline) --,
+        `cycles` cycles of 2 x depth live time steps each (every candidate gives the same bits: tuning advances the simulation), the
+        slowest rank's time counts, the best of `rounds`, and all set the candidate that is fastest per time step (lb_set_slab_cycle,
+        lb_set_exchange_inline).  A whole-grid handle tunes itself (Simulation.autotune); slabs cannot: every rank must run the
+        same schedule.  Returns {"depth": chosen, "exchange_inline": chosen, "ms_per_step": {depth: slowest rank's, the better
+        placement}, "ms_per_step_inline": {depth: ...}, "steps": time steps advanced}; nothing to choose on the python-driven
+        transport."""
         if self.transport not in ("rccl", "peer") or not hasattr(self.engine, "set_slab_cycle"):
-            return {"depth": 0, "ms_per_step": {}, "steps": 0}
+            return {"depth": 0, "exchange_inline": False, "ms_per_step": {}, "steps": 0}
         import torch
         dist = self._dist
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         hmin = min(h for _, h in self.parts)
-        cands = [d for d in depths if hmin >= 16 * d]
+        can_place = hasattr(self.engine, "set_exchange_inline")
+        cands = [(d, bool(pl)) for d in depths if hmin >= 16 * d for pl in (placements if can_place else (False,))]
         times, steps = {}, 0
         for r in range(rounds + 1):                      # (round 0 warms every candidate up)
-            for d in cands:
+            for d, pl in cands:
                 self.engine.set_slab_cycle(d)
+                if can_place:
+                    self.engine.set_exchange_inline(pl)
                 n = 2 * d * cycles
                 self.engine.sync()
                 dist.barrier(self.group)
@@ -389,10 +394,14 @@ class DistributedSlab(_SlabSet):
                 t = torch.tensor([ms / n], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 if r:
-                    times[d] = min(times.get(d, 1e30), float(t[0]))
-        best = min(times, key=times.get) if times else 0
-        self.engine.set_slab_cycle(best)
-        return {"depth": best, "ms_per_step": {d: round(v, 5) for d, v in times.items()}, "steps": steps}
+                    times[(d, pl)] = min(times.get((d, pl), 1e30), float(t[0]))
+        best = min(times, key=times.get) if times else (0, False)
+        self.engine.set_slab_cycle(best[0])
+        if can_place:
+            self.engine.set_exchange_inline(best[1])
+        return {"depth": best[0], "exchange_inline": best[1],
+                "ms_per_step": {d: round(v, 5) for (d, pl), v in times.items() if not pl},
+                "ms_per_step_inline": {d: round(v, 5) for (d, pl), v in times.items() if pl}, "steps": steps}
 
     def get_local_fields(self, which=("f", "feq", "u", "v", "rho")):
         return self.engine.get_fields(which)

@@ -190,6 +190,7 @@ struct lb_sim {
     bool cyc_failed = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int diag = 0;
+    bool xchg_inline = false;   // slabs, split bands: the exchange on the COMPUTE stream, between the interior launches (lb_set_exchange_inline)
     int forced_cycle = 0;       // slabs: depth of the fused kernel the halo cycle runs on, fixed by the caller (lb_set_slab_cycle); 0 = automatic
     // lb_exchange_timing: a pair of timing events around every halo exchange of lb_run, on the stream that carries it
     static constexpr int XT_RING = 256;
@@ -1778,6 +1779,14 @@ int lb_set_slab_cycle(lb_sim *s, int depth)
     return LB_OK;
 }
 
+int lb_set_exchange_inline(lb_sim *s, int on)
+{
+    if (s && s->cpu) return LB_OK;
+    if (!s) return fail(LB_ERR_ARG, "null handle");
+    s->xchg_inline = on != 0;
+    return LB_OK;
+}
+
 int lb_exchange_timing(lb_sim *s, int enable)
 {
     CPU_UNSUPPORTED(s, "lb_exchange_timing");
@@ -2259,9 +2268,11 @@ int slab_cycle_one(lb_sim *s, int D, bool last_of_run, const HaloTables &T, bool
     if ((rc = slab_cycle_second(s, last_of_run, D, split))) return rc;
     s->cur ^= 1;
     if (split) {
-        HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_edge, 0));
-        if ((rc = exchange_halo(s, s->cur, s->comm_stream, T))) return rc;
-        HIP_TRY(hipEventRecord(s->ev_halo, s->comm_stream));
+        // (xchg_inline: on the compute stream, i.e. behind C2 and in front of the next C1 -- beside the tail of E2b at most)
+        hipStream_t xq = s->xchg_inline ? s->stream : s->comm_stream;
+        HIP_TRY(hipStreamWaitEvent(xq, s->ev_edge, 0));
+        if ((rc = exchange_halo(s, s->cur, xq, T))) return rc;
+        HIP_TRY(hipEventRecord(s->ev_halo, xq));
     } else {
         if ((rc = exchange_halo(s, s->cur, s->edge_stream, T))) return rc;
     }
@@ -2433,7 +2444,7 @@ int lb_run(lb_sim *s, int n_steps)
         const bool split = split_bands(s);
         if (split) {
             HIP_TRY(hipEventRecord(s->ev_halo, s->edge_stream));
-            HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_halo, 0));
+            HIP_TRY(hipStreamWaitEvent(s->xchg_inline ? s->stream : s->comm_stream, s->ev_halo, 0));
         }
         for (; left >= 2 * D; left -= 2 * D) {
             if ((rc = slab_cycle_one(s, D, left == 2 * D, T, split))) return rc;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LB_ABI_VERSION 9
+#define LB_ABI_VERSION 10
 
 typedef enum {
     LB_OK = 0,
@@ -338,13 +338,23 @@ int lb_set_variant(lb_sim *s, int variant);
  * never depend on it (bitwise); EVERY rank of a run must set the same value -- the ranks time the candidates together and agree
  * (LB_D2Q9/slabs.py: DistributedSlab.autotune). */
 int lb_set_slab_cycle(lb_sim *s, int depth);
+/* Where the halo exchange of a cycle runs (slabs; ABI 10).  0, the default: on the handle's communication stream, beside the second
+ * interior launch and the inner part of the edge bands -- hidden, if its kernels find room beside kernels that fill the chip.  1: on the
+ * COMPUTE stream, behind the second interior launch and in front of the next first one -- exposed (pack + transfer + unpack, ~45 us of a
+ * self-exchange) but beside nothing.  RCCL's send / receive kernel (59 workgroups with 20 KB of LDS each) takes 15 us alone and up to a
+ * whole launch beside k_deep, which it slows by 5-30 %; which placement wins depends on the slab's height and on the link, so the ranks
+ * time both together and agree (DistributedSlab.autotune).  Results never depend on it (bitwise); every rank sets the same value.
+ * Whole-grid handles and the CPU backend ignore it. */
+int lb_set_exchange_inline(lb_sim *s, int on);
 /* Diagnosis of a multi-GPU run.  lb_exchange_timing(s, 1) brackets every halo exchange of lb_run with a pair of timing events on the
  * stream that carries it (up to 256 exchanges between two queries; more are counted as dropped, not timed); lb_exchange_stats waits
  * for the exchanges recorded so far and returns their number, their total and longest duration in milliseconds -- pack / push, the
  * transfer, the wait for the neighbours' matching calls, unpack --, the depth of the halo cycle in use and the rows of one edge band
  * of its second launch (2 x depth + the extra rows that keep the band's waves busy as long as the interior's, lb_hip.cpp:
- * band_extra), then starts over.  An exchange longer than the head start the edge bands have over the interior delays the
- * compute stream: bench.py --gpus N prints the figures per rank. */
+ * band_extra), then starts over.  The bands are split -- only their outer 2 x depth rows wait for the exchange, which runs on a stream
+ * of its own beside the rest --, so an exchange delays the compute stream once it takes longer than about a whole launch; bench.py
+ * --gpus N prints the figures per rank.  (The three streams of a slab handle must not share a hardware queue: a process that creates
+ * many streams wants GPU_MAX_HW_QUEUES=8 set before the HIP runtime loads -- INTEGRATION.md.) */
 int lb_exchange_timing(lb_sim *s, int enable);
 int lb_exchange_stats(lb_sim *s, int64_t *n_exchanges, double *total_ms, double *max_ms, int *cycle_depth, int *band_rows);
 

@@ -554,7 +554,7 @@ def test_rccl_self_exchange_single_rank(lbhip):
 
 @pytest.mark.parametrize("transport", ["rccl", "peer"])
 def test_slab_cycle_depth_set_by_the_caller_and_exchange_timing(lbhip, transport):
-    """lb_set_slab_cycle (ABI 9): the halo cycle of lb_run on the depth the caller fixes -- what DistributedSlab.autotune does after
+    """lb_set_slab_cycle (ABI 9), lb_set_exchange_inline (ABI 10): the halo cycle of lb_run on the depth the caller fixes -- what DistributedSlab.autotune does after
     the ranks have timed the candidates together -- gives the plain run's bits at every depth, over both transports (thick edge bands;
     under RCCL split in two launches with the exchange on the communication stream: lb_hip.cpp, slab_cycle_first), with an obstacle
     mask; lb_exchange_timing / lb_exchange_stats count the exchanges and report the cycle in use."""
@@ -570,7 +570,8 @@ def test_slab_cycle_depth_set_by_the_caller_and_exchange_timing(lbhip, transport
     one.run(3 * 28 + 9)
     want = one.get_fields(("f",))["f"]
     one.close()
-    for depth in (7, 6, 5, 4, 3):
+    # (ABI 10: lb_set_exchange_inline -- the exchange between the interior launches on the compute stream instead of beside them)
+    for depth, inline in ((7, False), (7, True), (6, False), (6, True), (5, True), (5, False), (4, False), (3, False)):
         s = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask, halo=True)
         s.set_obstacle_mask_halo(*_SlabSet._mask_halo_rows(mask, 0, ny, ny, True))
         s.set_variant(97 | 256 | 4096 | 16384 | 32768)        # every marching kernel allowed; the cycle's depth is the caller's
@@ -580,6 +581,7 @@ def test_slab_cycle_depth_set_by_the_caller_and_exchange_timing(lbhip, transport
             d = s.peer_export()
             s.peer_connect(0, 1, d, d, ny)
         s.set_slab_cycle(depth)
+        s.set_exchange_inline(inline)
         s.exchange_timing(True)
         s.set_f(f0)
         for n in (28, 28, 28, 9):
@@ -589,7 +591,7 @@ def test_slab_cycle_depth_set_by_the_caller_and_exchange_timing(lbhip, transport
         assert st["band_rows"] >= 2 * depth
         assert s.exchange_stats()["n"] == 0                    # (the query starts over)
         got = s.get_fields(("f",))["f"]
-        assert np.array_equal(got, want), (transport, depth)
+        assert np.array_equal(got, want), (transport, depth, inline)
         s.close()
 
 

@@ -127,6 +127,7 @@ def test_random_self_ring(lbhip, seed):
     ring = Simulation(nx, ny, 1.5, bc="periodic", obstacle_mask=mask, halo=True)
     ring.comm_init(comm_unique_id(), 0, 1)
     ring.set_variant(variant)
+    ring.set_exchange_inline(seed % 2 == 1)          # (odd seeds: the exchange between the interior launches, lb_set_exchange_inline)
     ring.set_f(f0)
     runs = [int(n) for n in rng.integers(1, 40, size=3)]
     for n in runs:

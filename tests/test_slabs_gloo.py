@@ -179,7 +179,22 @@ class _TimedStubEngine(object):
         return self.MS_PER_STEP[self.rank_of][self.depth] * self._n
 
 
-def _tune_worker(rank, world, port, out_dir):
+class _PlacedStubEngine(_TimedStubEngine):
+    """... and at each placement of the exchange (lb_set_exchange_inline): rank 1 is slow at depth 7 only while the exchange overlaps."""
+    MS_INLINE = {0: {7: 0.11, 6: 0.13, 5: 0.16}, 1: {7: 0.115, 6: 0.14, 5: 0.15}}
+
+    def __init__(self, **kw):
+        _TimedStubEngine.__init__(self, **kw)
+        self.inline = False
+
+    def set_exchange_inline(self, on):
+        self.inline = bool(on)
+
+    def timer_stop(self):
+        return (self.MS_INLINE if self.inline else self.MS_PER_STEP)[self.rank_of][self.depth] * self._n
+
+
+def _tune_worker(rank, world, port, out_dir, placed=False):
     for p in (os.path.join(ROOT, "2d-lb_amd"), ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -187,12 +202,15 @@ def _tune_worker(rank, world, port, out_dir):
     from LB_D2Q9.slabs import DistributedSlab
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
-        slab = DistributedSlab(64, 400, 1.4, bc="periodic", transport="torch", engine_factory=_TimedStubEngine)
+        slab = DistributedSlab(64, 400, 1.4, bc="periodic", transport="torch",
+                               engine_factory=_PlacedStubEngine if placed else _TimedStubEngine)
         slab.engine.rank_of = rank
         slab.transport = "peer"             # (what autotune asks: the schedule runs inside the engine)
         got = slab.autotune()
         np.savez(os.path.join(out_dir, "tune_%d.npz" % rank), depth=got["depth"], steps=got["steps"], engine_depth=slab.engine.depth,
-                 engine_steps=slab.engine.steps, t7=got["ms_per_step"][7], t6=got["ms_per_step"][6], t5=got["ms_per_step"][5])
+                 engine_steps=slab.engine.steps, t7=got["ms_per_step"][7], t6=got["ms_per_step"][6], t5=got["ms_per_step"][5],
+                 inline=got["exchange_inline"], engine_inline=getattr(slab.engine, "inline", False),
+                 i7=got.get("ms_per_step_inline", {}).get(7, -1.0))
     finally:
         dist.destroy_process_group()
 
@@ -207,3 +225,17 @@ def test_distributed_slab_autotune_agrees_on_the_slowest_ranks_best_depth(tmp_pa
         assert int(r[k]["depth"]) == 6 and int(r[k]["engine_depth"]) == 6
         assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["t6"]) - 0.13) < 1e-9 and abs(float(r[k]["t5"]) - 0.15) < 1e-9
         assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 3 * 3 * 2 * (7 + 6 + 5)
+        assert not bool(r[k]["inline"])                      # (an engine without lb_set_exchange_inline: nothing to place)
+
+
+def test_distributed_slab_autotune_places_the_exchange_where_the_slowest_rank_is_fastest(tmp_path):
+    """The same two ranks on an engine that can also run the exchange between the interior launches: there rank 1 is not slow at
+    depth 7 -- 0.115 ms per step is the best MAX over ranks of the six candidates; both ranks set depth 7 AND the inline exchange."""
+    import torch.multiprocessing as mp
+    mp.spawn(_tune_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "tune_%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        assert int(r[k]["depth"]) == 7 and int(r[k]["engine_depth"]) == 7
+        assert bool(r[k]["inline"]) and bool(r[k]["engine_inline"])
+        assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["i7"]) - 0.115) < 1e-9
+        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 2 * 3 * 3 * 2 * (7 + 6 + 5)

@@ -50,6 +50,7 @@ def child():
             kw = dict(inlet_rho=1.004, lid_u=0.05)
             slab = DistributedSlab(nx, ny, 1.5, bc=bc, obstacle_mask=m, transport="peer", device=dev, **kw)
             slab.engine.set_variant(variant)
+            slab.engine.set_exchange_inline("--inline" in sys.argv)       # (the exchange between the interior launches, every rank alike)
             spl = slab.engine.steps_per_launch()
             slab.set_f(f0)
             for n in runs:

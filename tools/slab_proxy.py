@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--variants", default="-1,9")
     ap.add_argument("--reps", type=int, default=3, help="timed runs per configuration; the best counts")
     ap.add_argument("--transports", default="rccl", help="comma list of rccl, peer (the slab path as a 1-rank ring over that transport)")
+    ap.add_argument("--inline", action="store_true", help="the exchange between the interior launches (lb_set_exchange_inline)")
     ap.add_argument("--torch-dist", action="store_true",
                     help="first join a one-rank torch.distributed group over RCCL, as bench.py does: torch's and RCCL's own streams then exist "
                          "before the handles' and compete for the process's hardware queues (GPU_MAX_HW_QUEUES)")
@@ -50,6 +51,8 @@ def main():
                 elif mode == "slab+peer-self":
                     d = sim.peer_export()
                     sim.peer_connect(0, 1, d, d, ny)
+                if mode != "plain" and args.inline:
+                    sim.set_exchange_inline(True)
                 sim.init_equilibrium(*shear_layer(args.nx, ny, 0, ny))
                 sim.run(10)
                 if mode != "plain":
