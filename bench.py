@@ -236,7 +236,7 @@ def measure_config(config, local_rank, steps, warmup, min_blocks, min_timed_s, s
             total += walls[-1]
         wall, ev_ms = statistics.median(walls), statistics.median(evs)
         health = sim.check()
-        mean_rho = health["sum_rho"] / (float(n) * ny_all)
+        mean_rho = health["sum_rho"] / (float(n) * n)
         if health["n_nonfinite"] or abs(mean_rho - 1.0) > 1e-3 or not health["max_mach"] < 0.3:
             raise SystemExit("bench: non-physical state after config %d (%r)" % (config, health))
         spl = sim.steps_per_launch()
