@@ -274,11 +274,15 @@ int effective_variant(const lb_sim *s)
     if (s->variant >= 0) return s->variant;
     const double pair_bytes = 2.0 * sizeof(float) * (double)s->lat_floats;
     const double cells = (double)s->p.nx * (s->min_h > 0 ? s->min_h : s->H);   // (ranks of one run agree on min_h)
-    // non-temporal stores from ~450 MB per lattice pair, i.e. once the pair no longer fits the 256 MB Infinity Cache with room
+    // non-temporal stores from ~450 MB per lattice pair (round 3), i.e. once the pair no longer fits the 256 MB Infinity Cache with room
     // to spare (round 3, k_step4, plain vs non-temporal: 311 MB 235.8 / 235.5 k MLUPS, 302 MB 232 / 227 k, 604 MB 241 / 265 k,
     // 613 MB 247 / 273 k -- the slab of one of eight GPUs at 8192^2 --, 680 MB 255 / 257 k, 1.2 GB 278 / 294 k:
     // profiles/r03_experiments.txt; the threshold was 1 GB)
-    int v = pair_bytes >= 4.5e8 ? ((s->p.flags & LB_FLAG_PLANAR) ? 9 : 1) : 16;
+    // (round 6, the deep kernels, plain | non-temporal, k MLUPS, profiles/r06l_nt_stores_midsize.txt, r06l_reference_case_bits.txt: pair of
+    //  170 MB (periodic 1536^2) 306 | 298, 302 MB (2048^2) 369 | 363, pipe 2048^2 291 | 295; 338 MB -- the reference's 3751 x 1251 case --
+    //  274-285 | 292-293 (two rounds, both depths), 415 MB: periodic 2400^2 385 | 388, pipe 337 against 308, cavity + mask 298 against 276:
+    //  the threshold is 320 MB now)
+    int v = pair_bytes >= 3.2e8 ? ((s->p.flags & LB_FLAG_PLANAR) ? 9 : 1) : 16;
     // from 1024^2 cells: three steps per pass (110 k MLUPS at 1024^2 against 87 k single-step); from 1280^2:
     // four (125 k at 1280^2, 158 k at 1536^2, 170 k at 2048^2, 220 k from 3072^2), whole grids and slabs alike,
     // in every boundary family, with and without obstacles (profiles/r01_sweep_variants.txt,
@@ -342,6 +346,12 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 // A marching launch of `depth` time steps per pass (k_step2 ... k_step5, k_deep), by the translation unit that instantiates that depth.
 // k_step4 gathers one row ahead where that fits in 256 registers without scratch (step4_prefetch, kernels_step4.h: every
 // instantiation without an obstacle mask but the D2Q9i fork's); variant bit 10 switches it off (A/B runs).
+bool deep2_chosen(const lb_sim *s)
+{
+    if (s->variant >= 0) return (s->variant & 65536) != 0;
+    return s->tuned_steps == 7 && s->tuned_wpc == 8 && !s->multi_slab();
+}
+
 bool launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs, int row_end,
                   bool macro, int depth)
 {
@@ -354,7 +364,8 @@ bool launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items,
     g.strips = strips; g.seg_rows = seg_rows; g.nsegs = nsegs; g.row_end = row_end;
     const int bc = kernel_bc(s);
     // (false: the unit has no instantiation for this boundary family -- k_deep / k_deep2 and the velocity-inlet family)
-    if (depth == 7 && (effective_variant(s) & 65536)) return lbk_launch_deep2_7(bc, s->has_mask, macro, g, a);    // k_deep2: four waves per workgroup
+    // k_deep2: four waves per workgroup -- asked for (variant bit 16) or found faster by lb_autotune (seven steps at "eight waves per CU")
+    if (depth == 7 && deep2_chosen(s)) return lbk_launch_deep2_7(bc, s->has_mask, macro, g, a);
     if (depth == 7) return lbk_launch_deep7(bc, s->has_mask, macro, g, a);
     if (depth == 6) return lbk_launch_deep6(bc, s->has_mask, macro, g, a);
     if (depth == 5) lbk_launch_march5(bc, s->has_mask, macro, g, a);
@@ -1260,7 +1271,10 @@ int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
     // (k_step4 at 8192^2 on one box: 4 waves per CU 189 k MLUPS, 6: 243 k, 8: 232 k, 12: 210 k -- profiles/r02_experiments.txt)
-    const Cand cands[] = {{7, 4}, {6, 4}, {5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
+    // ({7, 8}: k_deep2<7>, the same march by two waves per strip and direction, eight waves per CU -- in walled boxes and with an obstacle
+    //  mask only, where it has been seen ahead: the reference's 3751 x 1251 case 300 against 293 k MLUPS, pipe 4096^2 409-423 against
+    //  400-407 k; periodic 8192^2 without a mask it trails k_deep<7> by 4 %: profiles/r06l_reference_case_variants.txt, r06_deep2_check2.txt)
+    const Cand cands[] = {{7, 4}, {7, 8}, {6, 4}, {5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
     // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1 (the five-step candidates: 2 x 5; compared by time per step);
     // small grids: 36, so that the single-step candidate runs the way it would (hipGraph replay of 16 launches)
     const int per12 = small_grid(s) ? 36 : 12;
@@ -1296,6 +1310,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     for (int c = 0; c < NC; ++c) {
         ms_min[c] = 0.f;
         usable[c] = !(cands[c].steps >= 6 && !deep_applicable(s)) && !(cands[c].steps == 5 && !step5_applicable(s)) &&
+                    !(cands[c].steps == 7 && cands[c].wpc == 8 && s->p.bc_mode == LB_BC_PERIODIC && !s->has_mask) &&
                     !(cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) && !(cands[c].wpc < 0 && !tile_applicable(s)) &&
                     !(cands[c].steps == 3 && !step3_applicable(s)) && !(cands[c].steps == 2 && !step2_applicable(s));
     }
@@ -1325,7 +1340,8 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     if (best >= 0 && !small_grid(s)) {
         int second = -1;
         for (int c = 0; c < NC; ++c)
-            if (usable[c] && c != best && cands[c].steps != cands[best].steps && (second < 0 || ms_min[c] < ms_min[second])) second = c;
+            if (usable[c] && c != best && (cands[c].steps != cands[best].steps || cands[c].steps == 7) &&       // (7: k_deep<7> against k_deep2<7>)
+                (second < 0 || ms_min[c] < ms_min[second])) second = c;
         if (second >= 0 && ms_min[second] < 1.05f * best_ms) {
             float again[2] = {1e30f, 1e30f};
             const int pair[2] = {best, second};
@@ -1355,6 +1371,11 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     e0 = e1 = nullptr;
+    // (k_deep2<7> has to be ahead of k_deep<7> by more than the samples scatter: 1.5 %)
+    if (best >= 0 && cands[best].steps == 7 && cands[best].wpc == 8 && usable[0] && ms_min[0] <= 1.015f * ms_min[best]) {
+        best = 0;
+        best_ms = ms_min[0];
+    }
     if (best < 0) return bail(0);                       // nothing applicable
     s->tuned_steps = cands[best].steps;
     s->tuned_wpc = cands[best].wpc;
@@ -1364,7 +1385,7 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     for (int c = 0; c < NC; ++c) {
         if (!usable[c] || small_grid(s)) continue;      // (small grids replay single steps from a graph: the sample is not a launch)
         const Cand &k = cands[c];
-        const bool as_launched = (c == best) || (k.steps != cands[best].steps &&
+        const bool as_launched = (c == best) || (k.steps != cands[best].steps && !(k.steps == 7 && k.wpc == 8) &&
                                                  (k.steps >= 6 || k.steps == 1 || (k.steps == 4 && cands[best].wpc < 0 ? k.wpc < 0 : k.wpc == 8)));
         if (as_launched) s->depth_cost[k.steps] = ms_min[c] * (float)k.steps;
     }
@@ -1409,7 +1430,12 @@ int corners_patch(lb_sim *s, int which)
 }
 
 // steps a quick (one-round) tuning pass consumes at most: 11 candidates x 2 samples x 12 (36) steps, 2 x 2 x 10, + 1
-int autotune_quick_cost(const lb_sim *s) { return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 2 * 14 + 1; }
+// (an upper bound: every candidate usable; k_deep2<7> is one in walled boxes and with a mask only)
+int autotune_quick_cost(const lb_sim *s)
+{
+    const bool deep2 = s->p.bc_mode != LB_BC_PERIODIC || s->has_mask;
+    return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + (deep2 ? 2 : 1) * 2 * 14 + 1;
+}
 
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)
@@ -1514,7 +1540,7 @@ bool autotune_applies(const lb_sim *s)
 bool tune_entry_runs_here(const lb_sim *s, const TuneEntry &e)
 {
     if (!autotune_applies(s) || e.steps < 1 || e.steps > MAX_DEPTH) return false;
-    if (e.steps >= 6) return deep_applicable(s) && e.wpc == 4;
+    if (e.steps >= 6) return deep_applicable(s) && (e.wpc == 4 || (e.steps == 7 && e.wpc == 8 && (s->p.bc_mode != LB_BC_PERIODIC || s->has_mask)));
     if (e.steps == 5) return step5_applicable(s) && (e.wpc == 8 || e.wpc == 6);
     if (e.steps == 4) return e.wpc < 0 ? tile_applicable(s) : (step4_applicable(s) && (e.wpc == 8 || e.wpc == 6 || e.wpc == 4));
     if (e.steps == 3) return step3_applicable(s) && (e.wpc == 8 || e.wpc == 6 || e.wpc == 4);
@@ -3053,7 +3079,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen)
     else {
         const int spl = lb_steps_per_launch(s);
         if (!s->multi_slab() && use_tile_kernel(s) && spl == 4) kernel = "k_tile4 (LDS tiles)";
-        else if (spl == 7 && (effective_variant(s) & 65536)) kernel = "k_deep2<7> (marching strips, seven steps per pass, two waves per strip and direction -- stages 1-4 / 5-7 --, two waves per SIMD)";
+        else if (spl == 7 && deep2_chosen(s)) kernel = "k_deep2<7> (marching strips, seven steps per pass, two waves per strip and direction -- stages 1-4 / 5-7 --, two waves per SIMD)";
         else if (spl == 7) kernel = "k_deep<7> (marching strips, seven steps per pass, one wave per SIMD, stage windows in registers + LDS, gather one row ahead)";
         else if (spl == 6) kernel = "k_deep<6> (marching strips, six steps per pass, one wave per SIMD, stage windows in registers + LDS, gather one row ahead)";
         else if (spl == 5) kernel = "k_step5 (marching strips, five steps per pass: two stage windows in registers, two in wave-private LDS)";

@@ -302,7 +302,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 int lb_autotune(lb_sim *s);
 /* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
  * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
- * variant automatic and the pass (333 steps; 861 on grids <= 768^2) fits into max_steps; returns the number
+ * variant automatic and the pass (333 steps, 361 in walled boxes or with obstacles; 861 / 889 on grids <= 768^2) fits into max_steps; returns the number
  * of steps advanced, 0 when it did nothing.
  *
  * Environment: LB_TUNE_CACHE=<file> (or "mem": this process only) remembers every result of lb_autotune / lb_autotune_quick under
