@@ -318,10 +318,21 @@ int effective_variant(const lb_sim *s)
     // (slabs: ONE threshold per family, mask or not -- the halo cycle's depth follows from this choice (cycle_depth), every rank of a
     //  run must arrive at the same one, and the ranks agree on nx, min_h and the family but not on who holds obstacle cells: with
     //  round 5's 3800^2 / 4000^2 a rank with a mask and a rank without could pick different cycles between the two sizes)
-    const double deep_side = periodic_box ? (whole_grid ? 1500.0 : 2400.0)
-                                          : (whole_grid ? (s->has_mask ? 2150.0 : 2300.0) : 3800.0);
+    // Round 6, after the relaxation's fold, the non-temporal threshold above and k_deep2 (the seven steps by two waves per strip and
+    // direction, two per SIMD -- short segments and wall columns are where a second wave per SIMD pays): k_step5 | k_deep<7> | k_deep2<7>,
+    // k MLUPS, one box (profiles/r06o_walled_small_sweep.txt): pipe 1536^2 228 | 208 | 221, 1792^2 252 | 269 | 280, 2048^2 270 | 294 | 302,
+    // 2304^2 286 | 316 | 323, 2560^2 283 | 342 | 345; cavity 1792^2 264 | 266 | 290, 2048^2 284 | 292 | 315, 2560^2 288 | 341 | 354; pipe + mask
+    // 1792^2 233 | 236 | 249, 2048^2 255 | 255 | 270, 2560^2 273 | 300 | 310; the reference's case (2166^2 cells) 277 | 293 | 300; periodic with
+    // a mask 1280^2 220 | 239 | 225, 1536^2 268 | 287 | 273, 2048^2 280 | 341 | 336.  lb_autotune (profiles/r06n_tune_probe.txt): pipe from
+    // 3072^2 k_deep<7>, cavity k_deep2 up to 8192^2 within 1 % of k_deep.  Hence, whole grids: walled from 1700^2 cells, by k_deep2 below
+    // 2900^2; periodic with a mask from 1250^2.  (Slabs: as measured before.)
+    const double deep_side = periodic_box ? (whole_grid ? (s->has_mask ? 1250.0 : 1500.0) : 2400.0)
+                                          : (whole_grid ? 1700.0 : 3800.0);
     // (not the velocity-inlet family: its wall-row bands stop at five steps and k_deep has no instantiation for it)
-    if (cells >= deep_side * deep_side && s->p.bc_mode != LB_BC_VELOCITY_INLET) v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
+    if (cells >= deep_side * deep_side && s->p.bc_mode != LB_BC_VELOCITY_INLET) {
+        v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
+        if (whole_grid && !s->multi_slab() && !periodic_box && cells < 2900.0 * 2900.0) v |= 65536;
+    }
     return v;
 }
 
@@ -349,7 +360,9 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 bool deep2_chosen(const lb_sim *s)
 {
     if (s->variant >= 0) return (s->variant & 65536) != 0;
-    return s->tuned_steps == 7 && s->tuned_wpc == 8 && !s->multi_slab();
+    if (s->multi_slab()) return false;
+    if (s->tuned_steps) return s->tuned_steps == 7 && s->tuned_wpc == 8;       // lb_autotune's word
+    return (effective_variant(s) & 65536) != 0;                                // the size table's
 }
 
 bool launch_march(const lb_sim *s, hipStream_t st, const StepArgs &a, int items, int strips, int seg_rows, int nsegs, int row_end,
@@ -1180,7 +1193,10 @@ bool use_tile_kernel(const lb_sim *s)
     // (round 4: five steps per pass on overlapping strips, k_step5 / tiles: periodic 1024^2 166 / 198 k, 1280^2 233 / 218 k, 1536^2
     //  261 / 240 k, 1792^2 294 / 249 k, 2048^2 305 / 209 k; cavity 1280^2 173 / 202 k, 1536^2 200 / 220 k, 1792^2 225 / 231 k,
     //  2048^2 259 / 194 k: profiles/r04_step5_sweep.txt; until then the change-over to k_step4 was at 1950^2)
-    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1200.0 : 1850.0;
+    // (round 6, walled boxes, tiles | k_step5 | k_deep2<7>, k MLUPS, profiles/r06o_walled_tile_sweep.txt: pipe 1280^2 214 | 191 | 156, 1536^2
+    //  230 | 227 | 221, 1664^2 236 | 248 | 252, 1792^2 238 | 253 | 280, 2048^2 207 | 263 | 302; cavity 1536^2 227 | 240 | 231, 1792^2 233 | 266 | 290;
+    //  pipe + mask 1536^2 201 | 209 | 199, 1792^2 211 | 233 | 249: the walled change-over moves from 1850^2 to 1450^2)
+    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1200.0 : 1450.0;
     return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 
