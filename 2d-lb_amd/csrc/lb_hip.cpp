@@ -333,6 +333,15 @@ int effective_variant(const lb_sim *s)
         v |= 16384 | 32768;     // (slabs: inside the twelve- / fourteen-step halo cycle, cycle_depth)
         if (whole_grid && !s->multi_slab() && !periodic_box && cells < 2900.0 * 2900.0) v |= 65536;
     }
+    // Periodic whole grids without a mask, tiles | k_step5 | k_deep<6> | k_deep<7>, k MLUPS, 1680-step runs (profiles/r06q_periodic_small_sweep.txt):
+    // 1024^2 214 | 186 | 205 | 195, 1152^2 220 | 227 | 246 | 239, 1280^2 234 | 256 | 263 | 258, 1408^2 242 | 266 | 291 | 287, 1536^2 245 | 291 | 310 | 308,
+    // 1792^2 254 | 319 | 364 | 359, 2048^2 210 | 293 | 340 | 364: six steps per pass from 1100^2 cells, seven from 1900^2 (use_tile_kernel:
+    // the tiles below 1100^2).
+    if (periodic_box && whole_grid && !s->multi_slab() && !s->has_mask) {
+        v &= ~(16384 | 32768);
+        if (cells >= 1100.0 * 1100.0) v |= 256 | 4096 | 16384;
+        if (cells >= 1900.0 * 1900.0) v |= 32768;
+    }
     return v;
 }
 
@@ -1196,7 +1205,7 @@ bool use_tile_kernel(const lb_sim *s)
     // (round 6, walled boxes, tiles | k_step5 | k_deep2<7>, k MLUPS, profiles/r06o_walled_tile_sweep.txt: pipe 1280^2 214 | 191 | 156, 1536^2
     //  230 | 227 | 221, 1664^2 236 | 248 | 252, 1792^2 238 | 253 | 280, 2048^2 207 | 263 | 302; cavity 1536^2 227 | 240 | 231, 1792^2 233 | 266 | 290;
     //  pipe + mask 1536^2 201 | 209 | 199, 1792^2 211 | 233 | 249: the walled change-over moves from 1850^2 to 1450^2)
-    const double side = s->p.bc_mode == LB_BC_PERIODIC ? 1200.0 : 1450.0;
+    const double side = s->p.bc_mode == LB_BC_PERIODIC ? (s->has_mask ? 1200.0 : 1100.0) : 1450.0;
     return (double)s->p.nx * s->H < side * side || !step4_applicable(s);
 }
 

@@ -327,7 +327,7 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * rows -- the ten-step halo cycle; what the automatic choice takes from 1200^2 periodic / 1850^2 walled cells of a whole
  * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 14 six and bit 15 (with bit 14) seven time steps per pass
  * (k_deep, one wave per SIMD: whole-grid handles and slabs of >= 96 / 112 rows -- the twelve- / fourteen-step halo cycle --, not
- * the velocity-inlet family; automatic from 1500^2 periodic (1250^2 with obstacle-mask cells; slabs: 2400^2) / 1700^2 walled (slabs: 3800^2) cells), bit 16
+ * the velocity-inlet family; automatic from 1100^2 (six steps; seven from 1900^2) periodic (1250^2 with obstacle-mask cells; slabs: 2400^2) / 1700^2 walled (slabs: 3800^2) cells), bit 16
  * (with bits 14, 15) the seven-step launches by k_deep2 -- two waves per strip and direction, two waves per SIMD (round 6; automatic on walled whole grids of 1700^2 ... 2900^2 cells, one of lb_autotune's candidates in walled boxes and with obstacles), bit 13
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
