@@ -448,8 +448,8 @@ class Simulation(object):
         check(self._lib.lb_set_variant(self._h, int(variant)))
 
     def set_slab_cycle(self, depth):
-        """Slab handles: depth of the fused kernel the halo cycle runs on (0 = automatic, 3 ... 7); every rank of a run must set the
-        same value (lb_set_slab_cycle)."""
+        """Slab handles: depth of the fused kernel the halo cycle runs on (0 = automatic, 3 ... 7; 8 = seven steps by k_deep2, two waves
+        per SIMD); every rank of a run must set the same value (lb_set_slab_cycle)."""
         check(self._lib.lb_set_slab_cycle(self._h, int(depth)))
 
     def set_exchange_inline(self, on):

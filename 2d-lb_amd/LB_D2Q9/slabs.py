@@ -363,8 +363,9 @@ class DistributedSlab(_SlabSet):
         self.run(n, wait=False)
         return self.engine.timer_stop()
 
-    def autotune(self, depths=(7, 6, 5), cycles=3, rounds=2, placements=(False, True)):
-        """Collective: the ranks time the halo cycle on each candidate TOGETHER -- a depth of the fused kernel x where the exchange
+    def autotune(self, depths=(8, 7, 6, 5), cycles=3, rounds=2, placements=(False, True)):
+        """Collective: the ranks time the halo cycle on each candidate TOGETHER -- a depth of the fused kernel (8: seven steps per
+        launch by k_deep2, two waves per SIMD, which leaves RCCL's kernel the LDS it needs on every CU) x where the exchange
         runs (beside the interior launches on its own stream, or between them on the compute stream: lb_set_exchange_inline) --,
         `cycles` cycles of 2 x depth live time steps each (every candidate gives the same bits: tuning advances the simulation), the
         slowest rank's time counts, the best of `rounds`, and all set the candidate that is fastest per time step (lb_set_slab_cycle,
@@ -379,14 +380,14 @@ class DistributedSlab(_SlabSet):
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         hmin = min(h for _, h in self.parts)
         can_place = hasattr(self.engine, "set_exchange_inline")
-        cands = [(d, bool(pl)) for d in depths if hmin >= 16 * d for pl in (placements if can_place else (False,))]
+        cands = [(d, bool(pl)) for d in depths if hmin >= 16 * min(d, 7) for pl in (placements if can_place else (False,))]
         times, steps = {}, 0
         for r in range(rounds + 1):                      # (round 0 warms every candidate up)
             for d, pl in cands:
                 self.engine.set_slab_cycle(d)
                 if can_place:
                     self.engine.set_exchange_inline(pl)
-                n = 2 * d * cycles
+                n = 2 * min(d, 7) * cycles
                 self.engine.sync()
                 dist.barrier(self.group)
                 ms = self.timed_run(n)

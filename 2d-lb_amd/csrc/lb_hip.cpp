@@ -191,6 +191,7 @@ struct lb_sim {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int diag = 0;
     bool xchg_inline = false;   // slabs, split bands: the exchange on the COMPUTE stream, between the interior launches (lb_set_exchange_inline)
+    int slab_flavour = -1;      // slabs, seven-step cycle: 0 k_deep<7>, 1 k_deep2<7> (lb_set_slab_cycle(8)), -1 automatic (k_deep2 under RCCL)
     int forced_cycle = 0;       // slabs: depth of the fused kernel the halo cycle runs on, fixed by the caller (lb_set_slab_cycle); 0 = automatic
     // lb_exchange_timing: a pair of timing events around every halo exchange of lb_run, on the stream that carries it
     static constexpr int XT_RING = 256;
@@ -368,8 +369,14 @@ int launch_step(lb_sim *s, int row_begin, int row_step, int row_count, bool macr
 // instantiation without an obstacle mask but the D2Q9i fork's); variant bit 10 switches it off (A/B runs).
 bool deep2_chosen(const lb_sim *s)
 {
+    if (s->multi_slab() && s->slab_flavour >= 0) return s->slab_flavour == 1;      // lb_set_slab_cycle(7) / (8): the caller's word
     if (s->variant >= 0) return (s->variant & 65536) != 0;
-    if (s->multi_slab()) return false;
+    // Slabs without the caller's word (above: the ranks' collective tuner): by transport.  Beside k_deep<7> (2 x 80 KB of
+    // LDS per CU) RCCL's send / receive kernel waits for places and slows what it shares SIMDs with; beside k_deep2<7> (2 x 72 KB, eight
+    // waves per CU) it does not: one slab of 4 | 2 of an 8192^2 lattice over RCCL 381-392 | 402-450 k MLUPS by k_deep, 443-444 | 466 k by
+    // k_deep2 = the peer transport's rate; of 8: 374-381 | 383-392; the peer transport itself: equal within 1 %
+    // (profiles/r06s_slab_proxy_deep2.txt).  Every rank of a run shares the transport, so the ranks agree.
+    if (s->multi_slab()) return s->comm != nullptr && !s->peer_connected;
     if (s->tuned_steps) return s->tuned_steps == 7 && s->tuned_wpc == 8;       // lb_autotune's word
     return (effective_variant(s) & 65536) != 0;                                // the size table's
 }
@@ -1825,8 +1832,11 @@ int lb_set_slab_cycle(lb_sim *s, int depth)
 {
     if (s && s->cpu) return LB_OK;
     if (!s) return fail(LB_ERR_ARG, "null handle");
-    if (depth != 0 && (depth < 3 || depth > MAX_DEPTH)) return fail(LB_ERR_ARG, "halo cycle depth must be 0 (automatic) or 3..%d, got %d", MAX_DEPTH, depth);
-    s->forced_cycle = depth;
+    // (8: the seven-step cycle with k_deep2<7> for its launches, 7: with k_deep<7>; 0: automatic depth, kernel by transport)
+    if (depth != 0 && (depth < 3 || depth > MAX_DEPTH + 1))
+        return fail(LB_ERR_ARG, "halo cycle depth must be 0 (automatic), 3..%d, or %d (seven steps by k_deep2), got %d", MAX_DEPTH, MAX_DEPTH + 1, depth);
+    s->forced_cycle = depth > MAX_DEPTH ? MAX_DEPTH : depth;
+    s->slab_flavour = depth == 0 ? -1 : (depth > MAX_DEPTH ? 1 : 0);
     return LB_OK;
 }
 

@@ -277,6 +277,38 @@ def test_config4_eight_slabs_equal_one_gpu_run_bitwise(lbhip):
         assert np.array_equal(got[k], want[k]), k
 
 
+@pytest.mark.parametrize("transport,cycle,inline", [("rccl", 0, False), ("rccl", 7, True), ("peer", 0, False), ("peer", 8, False)])
+def test_one_slab_of_eight_as_a_ring_of_its_own_equals_the_plain_grid_bitwise(lbhip, transport, cycle, inline):
+    """The slab one of eight ranks holds (8192 x 1024, periodic in itself: a one-rank ring) through lb_run's halo cycle at the sizes
+    where the automatic choices apply -- fourteen-step cycle, thick split edge bands, under RCCL k_deep2<7> by default (under the peer
+    transport k_deep<7>; lb_set_slab_cycle(8) / (7) say so explicitly), the exchange beside or between the interior launches --
+    against the plain 8192 x 1024 grid, bit for bit."""
+    from LB_D2Q9.simulation import Simulation, comm_unique_id
+    import bench
+    nx, ny, steps = 8192, 1024, 14 * 3 + 7 + 3
+    one = Simulation(nx, ny, 1.7, bc="periodic")
+    one.init_equilibrium(*bench.shear_layer(nx, ny, 0, ny))
+    one.run(steps)
+    want = one.get_fields(("f",))["f"]
+    one.close()
+    s = Simulation(nx, ny, 1.7, bc="periodic", halo=True)
+    if transport == "rccl":
+        s.comm_init(comm_unique_id(), 0, 1)
+    else:
+        d = s.peer_export()
+        s.peer_connect(0, 1, d, d, ny)
+    s.set_slab_cycle(cycle)
+    s.set_exchange_inline(inline)
+    s.exchange_timing(True)
+    s.init_equilibrium(*bench.shear_layer(nx, ny, 0, ny))
+    s.run(steps)
+    st = s.exchange_stats()
+    assert st["cycle_depth"] == 7 and st["n"] >= 3
+    got = s.get_fields(("f",))["f"]
+    s.close()
+    assert np.array_equal(got, want)
+
+
 def test_config5_porous_obstacles_4096_vs_oracle(lbhip, oracle):
     """4096x4096 pipe flow through the reference's obstacle image (docs/CS205_obstacle_4.tif rescaled
     by nearest neighbour), bounce-back mask, two steps against the oracle + a longer sanity run."""

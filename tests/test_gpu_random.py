@@ -82,6 +82,8 @@ def _random_slab_partition_case(seed):
     nslabs = int(rng.integers(2, 6))
     ny = int(rng.integers(nslabs * 7, 700))                  # slab heights from 7 rows (no fused kernel) to 350
     variant = int(rng.choice((-1, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1)))
+    if seed % 4 == 3:                                # (the twelve- / fourteen-step cycle: k_deep<6>, k_deep<7>, k_deep2<7> -- from 96 / 112 rows)
+        variant = (97 | 256 | 4096 | 16384, 97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384 | 32768 | 65536)[(seed // 4) % 3]
     mask = None
     if rng.integers(0, 2):
         mask = rng.random((nx, ny)) < 0.03

@@ -154,7 +154,7 @@ def test_multirank_checkpoint_written_by_two_ranks_resumes_on_three(oracle, tmp_
 class _TimedStubEngine(object):
     """An engine that only knows how long a run 'takes' on this rank at each depth of the halo cycle: enough for the collective
     choice (the kernels' own equivalence at every depth is the GPU suite's: tests/test_gpu_parity.py)."""
-    MS_PER_STEP = {0: {7: 0.10, 6: 0.12, 5: 0.15}, 1: {7: 0.30, 6: 0.13, 5: 0.14}}       # rank 1 is slow at depth 7
+    MS_PER_STEP = {0: {8: 0.20, 7: 0.10, 6: 0.12, 5: 0.15}, 1: {8: 0.21, 7: 0.30, 6: 0.13, 5: 0.14}}       # rank 1 is slow at depth 7 (8: seven steps by k_deep2)
 
     def __init__(self, **kw):
         self.rank_of = None
@@ -181,7 +181,7 @@ class _TimedStubEngine(object):
 
 class _PlacedStubEngine(_TimedStubEngine):
     """... and at each placement of the exchange (lb_set_exchange_inline): rank 1 is slow at depth 7 only while the exchange overlaps."""
-    MS_INLINE = {0: {7: 0.11, 6: 0.13, 5: 0.16}, 1: {7: 0.115, 6: 0.14, 5: 0.15}}
+    MS_INLINE = {0: {8: 0.22, 7: 0.11, 6: 0.13, 5: 0.16}, 1: {8: 0.23, 7: 0.115, 6: 0.14, 5: 0.15}}
 
     def __init__(self, **kw):
         _TimedStubEngine.__init__(self, **kw)
@@ -224,7 +224,7 @@ def test_distributed_slab_autotune_agrees_on_the_slowest_ranks_best_depth(tmp_pa
     for k in range(2):
         assert int(r[k]["depth"]) == 6 and int(r[k]["engine_depth"]) == 6
         assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["t6"]) - 0.13) < 1e-9 and abs(float(r[k]["t5"]) - 0.15) < 1e-9
-        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 3 * 3 * 2 * (7 + 6 + 5)
+        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 3 * 3 * 2 * (7 + 7 + 6 + 5)
         assert not bool(r[k]["inline"])                      # (an engine without lb_set_exchange_inline: nothing to place)
 
 
@@ -238,4 +238,4 @@ def test_distributed_slab_autotune_places_the_exchange_where_the_slowest_rank_is
         assert int(r[k]["depth"]) == 7 and int(r[k]["engine_depth"]) == 7
         assert bool(r[k]["inline"]) and bool(r[k]["engine_inline"])
         assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["i7"]) - 0.115) < 1e-9
-        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 2 * 3 * 3 * 2 * (7 + 6 + 5)
+        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 2 * 3 * 3 * 2 * (7 + 7 + 6 + 5)

@@ -37,7 +37,7 @@ def child():
     # explicit schedules on small slabs: ten-step cycle, eight-step cycle, six-step cycle, three-step launches without the cycle,
     # two-step, single-step
     cases += [(1024, 128 * world + 5, v, (20, 7, 4), ("periodic", "pipe", "cavity"))
-              for v in ((97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1) if not quick else (97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096, 97 | 256, 1))]
+              for v in ((97 | 256 | 4096 | 16384 | 32768 | 65536, 97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096 | 16384, 97 | 256 | 4096, 97 | 256, 97, 97 | 128, 33, 1) if not quick else (97 | 256 | 4096 | 16384 | 32768 | 65536, 97 | 256 | 4096 | 16384 | 32768, 97 | 256 | 4096, 97 | 256, 1))]
     for nx, ny, variant, runs, families in cases:
         rng = np.random.default_rng(3)
         f0 = (w[None, None, :] * (1 + 0.02 * rng.standard_normal((nx, ny, 9)))).astype(np.float32)
