@@ -207,12 +207,12 @@ class Simulation(object):
     def run(self, num_iterations, wait=True):
         """num_iterations fused time steps.  The reference returns with the work complete (it waits after
         every kernel); pass wait=False to only enqueue (never blocks the host).  A blocking run of at least four
-        times the tuning pass (4 x 333 + 7 = 1339 steps; 4 x 361 + 7 in walled boxes or with obstacles; 4 x 861 + 7 on grids <= 768^2) first times the candidate kernel
+        times the tuning pass (4 x 361 + 7 = 1451 steps; 4 x 889 + 7 on grids <= 768^2) first times the candidate kernel
         configurations on its own first steps (lb_autotune_quick: they are bitwise equivalent, the trajectory is
         unchanged) and keeps the fastest for this grid; shorter runs use the size heuristic (or call autotune())."""
         n = int(num_iterations)
         if wait and n > 0:
-            # (the pass costs 333-361 steps, 861-889 on grids <= 768^2, some of them in configurations several times slower than
+            # (the pass costs 361 steps, 889 on grids <= 768^2, some of them in configurations several times slower than
             #  the best: it only pays for itself in a run several times that long)
             used = self._lib.lb_autotune_quick(self._h, (n - 7) // 4)
             if used < 0:

@@ -1303,9 +1303,10 @@ int autotune_whole_grid(lb_sim *s, int rounds)
 {
     struct Cand { int steps, wpc; };
     // (k_step4 at 8192^2 on one box: 4 waves per CU 189 k MLUPS, 6: 243 k, 8: 232 k, 12: 210 k -- profiles/r02_experiments.txt)
-    // ({7, 8}: k_deep2<7>, the same march by two waves per strip and direction, eight waves per CU -- in walled boxes and with an obstacle
-    //  mask only, where it has been seen ahead: the reference's 3751 x 1251 case 300 against 293 k MLUPS, pipe 4096^2 409-423 against
-    //  400-407 k; periodic 8192^2 without a mask it trails k_deep<7> by 4 %: profiles/r06l_reference_case_variants.txt, r06_deep2_check2.txt)
+    // ({7, 8}: k_deep2<7>, the same march by two waves per strip and direction, eight waves per CU: the reference's 3751 x 1251 case 300
+    //  against 293 k MLUPS, pipe 4096^2 409-423 against 400-407 k (profiles/r06l_reference_case_variants.txt, r06_deep2_check2.txt); periodic
+    //  without a mask it depends on the box -- 8192^2 482-486 against 475-477 k and 4096^2 454-457 against 444-447 k on a middling one
+    //  (profiles/r06u_deep2_headline.txt), 495-510 against 529 k on the fastest met -- which is what a tuner is for; it has to win by 1.5 %)
     const Cand cands[] = {{7, 4}, {7, 8}, {6, 4}, {5, 8}, {5, 6}, {4, 8}, {4, 6}, {4, 4}, {4, -1}, {3, 8}, {3, 6}, {3, 4}, {2, 8}, {2, 4}, {1, 0}};   // wpc -1: k_tile4
     // steps per timed sample: 3 x 4 = 4 x 3 = 6 x 2 = 12 x 1 (the five-step candidates: 2 x 5; compared by time per step);
     // small grids: 36, so that the single-step candidate runs the way it would (hipGraph replay of 16 launches)
@@ -1342,7 +1343,6 @@ int autotune_whole_grid(lb_sim *s, int rounds)
     for (int c = 0; c < NC; ++c) {
         ms_min[c] = 0.f;
         usable[c] = !(cands[c].steps >= 6 && !deep_applicable(s)) && !(cands[c].steps == 5 && !step5_applicable(s)) &&
-                    !(cands[c].steps == 7 && cands[c].wpc == 8 && s->p.bc_mode == LB_BC_PERIODIC && !s->has_mask) &&
                     !(cands[c].steps == 4 && cands[c].wpc >= 0 && !step4_applicable(s)) && !(cands[c].wpc < 0 && !tile_applicable(s)) &&
                     !(cands[c].steps == 3 && !step3_applicable(s)) && !(cands[c].steps == 2 && !step2_applicable(s));
     }
@@ -1462,12 +1462,8 @@ int corners_patch(lb_sim *s, int which)
 }
 
 // steps a quick (one-round) tuning pass consumes at most: 11 candidates x 2 samples x 12 (36) steps, 2 x 2 x 10, + 1
-// (an upper bound: every candidate usable; k_deep2<7> is one in walled boxes and with a mask only)
-int autotune_quick_cost(const lb_sim *s)
-{
-    const bool deep2 = s->p.bc_mode != LB_BC_PERIODIC || s->has_mask;
-    return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + (deep2 ? 2 : 1) * 2 * 14 + 1;
-}
+// (an upper bound: every candidate usable)
+int autotune_quick_cost(const lb_sim *s) { return 11 * 2 * (small_grid(s) ? 36 : 12) + 2 * 2 * 10 + 2 * 2 * 14 + 1; }
 
 // the Cython path runs four steps per launch through LDS tiles (k1_tile4) unless the grid is too small for them or an
 // explicit variant without bit 9 asks for single steps (k1_fstep)
@@ -1572,7 +1568,7 @@ bool autotune_applies(const lb_sim *s)
 bool tune_entry_runs_here(const lb_sim *s, const TuneEntry &e)
 {
     if (!autotune_applies(s) || e.steps < 1 || e.steps > MAX_DEPTH) return false;
-    if (e.steps >= 6) return deep_applicable(s) && (e.wpc == 4 || (e.steps == 7 && e.wpc == 8 && (s->p.bc_mode != LB_BC_PERIODIC || s->has_mask)));
+    if (e.steps >= 6) return deep_applicable(s) && (e.wpc == 4 || (e.steps == 7 && e.wpc == 8));
     if (e.steps == 5) return step5_applicable(s) && (e.wpc == 8 || e.wpc == 6);
     if (e.steps == 4) return e.wpc < 0 ? tile_applicable(s) : (step4_applicable(s) && (e.wpc == 8 || e.wpc == 6 || e.wpc == 4));
     if (e.steps == 3) return step3_applicable(s) && (e.wpc == 8 || e.wpc == 6 || e.wpc == 4);

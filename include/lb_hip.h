@@ -302,7 +302,7 @@ int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 int lb_autotune(lb_sim *s);
 /* The same with one sample per candidate, for callers that are about to run max_steps steps anyway and
  * will wait for them (the Python classes' blocking run()): tunes only when the handle is untuned, the
- * variant automatic and the pass (333 steps, 361 in walled boxes or with obstacles; 861 / 889 on grids <= 768^2) fits into max_steps; returns the number
+ * variant automatic and the pass (361 steps; 889 on grids <= 768^2) fits into max_steps; returns the number
  * of steps advanced, 0 when it did nothing.
  *
  * Environment: LB_TUNE_CACHE=<file> (or "mem": this process only) remembers every result of lb_autotune / lb_autotune_quick under
@@ -328,7 +328,7 @@ int lb_copy_calibration(lb_sim *s, int nontemporal, int64_t *bytes_moved);
  * grid, 1280^2 cells of a slab or of the velocity-inlet family), bit 14 six and bit 15 (with bit 14) seven time steps per pass
  * (k_deep, one wave per SIMD: whole-grid handles and slabs of >= 96 / 112 rows -- the twelve- / fourteen-step halo cycle --, not
  * the velocity-inlet family; automatic from 1100^2 (six steps; seven from 1900^2) periodic (1250^2 with obstacle-mask cells; slabs: 2400^2) / 1700^2 walled (slabs: 3800^2) cells), bit 16
- * (with bits 14, 15) the seven-step launches by k_deep2 -- two waves per strip and direction, two waves per SIMD (round 6; automatic on walled whole grids of 1700^2 ... 2900^2 cells, one of lb_autotune's candidates in walled boxes and with obstacles), bit 13
+ * (with bits 14, 15) the seven-step launches by k_deep2 -- two waves per strip and direction, two waves per SIMD (round 6; automatic on walled whole grids of 1700^2 ... 2900^2 cells, one of lb_autotune's candidates), bit 13
  * the LDS-tile kernel takes its tiles in launch order instead of one band of tile rows per XCD (bits 10, 11, 13: A/B
  * switches of things on by default).  Results never depend on it (bitwise); the ranks of one run must use the same value. */
 int lb_set_variant(lb_sim *s, int variant);

@@ -110,7 +110,7 @@ def main():
         macro = k.split(",")[2].strip() == "true"      # k_step<BC, MASK, MACRO, ...> / k_step2<BC, MASK, MACRO, NTS> / k_tile4<BC, MASK, MACRO, ...>
         masked = k.split(",")[1].strip() == "true"
         # time steps per launch: k_tile4: 4; k_deep<BC, MASK, MACRO, D, RW, PFD>: D; k_stepN: N
-        spl = 4 if k.startswith("k_tile4") else (int(k.split(",")[3]) if k.startswith("k_deep") else (int(k[6]) if k[6:7].isdigit() else 1))
+        spl = 4 if k.startswith("k_tile4") else (int(k.split(",")[3].strip(" >")) if k.startswith("k_deep") else (int(k[6]) if k[6:7].isdigit() else 1))
         alg = (73.0 if masked else 72.0) * side * side + (12.0 * side * side if macro else 0.0)      # compulsory bytes of one launch, whatever spl
         lines.append("| %s | %.4g | %.4g | %.4g | %.4g | %.4g | %.4g | %.3f |" % (k, f, w, rd, wr, rd + wr, alg, (rd + wr) / alg))
         key = ("%d/%d" % (side, spl)) if config == 4 else ("c%d/%d/%d" % (config, side, spl))
