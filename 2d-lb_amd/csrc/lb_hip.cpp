@@ -3077,6 +3077,9 @@ int lb_autotune(lb_sim *s)
     if (!s) return fail(LB_ERR_ARG, "null handle");
     if (s->stepping) return fail(LB_ERR_STATE, "lb_autotune inside a split step");
     if (!autotune_applies(s)) return 0;                // nothing to choose between
+    // (a forced variant fixes the kernels: every candidate would be timed as those, and the launch plan made from such costs is
+    //  nonsense -- bench.py --variant 119137 planned twenty steps as 1 + 1 + 4 + 7 + 7)
+    if (s->variant >= 0) return 0;
     // (LB_TUNE_CACHE holds a result for this shape: taken over, as lb_autotune_quick and lb_run do -- a profiled run then names the
     //  kernel the un-profiled run before it chose: tools/gpu_profile.sh)
     if (!s->tune_cache_checked && s->variant < 0 && !s->tuned_steps && tune_cache_apply(s)) return 0;

@@ -296,7 +296,8 @@ int lb_plan_launches(lb_sim *s, int n_steps, int *depths, int max_launches);
 int lb_hot_kernel(lb_sim *s, char *buf, int buflen);
 /* Pick the fastest configuration of the fused kernels for THIS grid by timing each candidate on a few
  * live time steps (all candidates give bitwise identical results, so this simply advances the
- * simulation): returns the number of steps advanced (0 when there is nothing to choose), <0 on error.
+ * simulation): returns the number of steps advanced (0 when there is nothing to choose -- also under a variant forced with
+ * lb_set_variant, which fixes the kernels), <0 on error.
  * Blocks the host (it reads HIP event times).  lb_run never tunes by itself.  A runner-up within 5 % of the winner is timed against it
  * once more over longer samples.  With LB_TUNE_CACHE set (below) a result remembered for this shape is taken over instead (returns 0). */
 int lb_autotune(lb_sim *s);
