@@ -372,8 +372,8 @@ bool deep2_chosen(const lb_sim *s)
     if (s->multi_slab() && s->slab_flavour >= 0) return s->slab_flavour == 1;      // lb_set_slab_cycle(7) / (8): the caller's word
     if (s->variant >= 0) return (s->variant & 65536) != 0;
     // Slabs without the caller's word (above: the ranks' collective tuner): by transport.  Beside k_deep<7> (2 x 80 KB of
-    // LDS per CU) RCCL's send / receive kernel waits for places and slows what it shares SIMDs with; beside k_deep2<7> (2 x 72 KB, eight
-    // waves per CU) it does not: one slab of 4 | 2 of an 8192^2 lattice over RCCL 381-392 | 402-450 k MLUPS by k_deep, 443-444 | 466 k by
+    // LDS per CU, lone waves) RCCL's send / receive kernel waits for places and slows what it shares SIMDs with; k_deep2<7>'s launches
+    // (2 x 72 KB, waves in pairs per SIMD) do not run longer for it, though it still takes most of a launch beside them: one slab of 4 | 2 of an 8192^2 lattice over RCCL 381-392 | 402-450 k MLUPS by k_deep, 443-444 | 466 k by
     // k_deep2 = the peer transport's rate; of 8: 374-381 | 383-392; the peer transport itself: equal within 1 %
     // (profiles/r06s_slab_proxy_deep2.txt).  Every rank of a run shares the transport, so the ranks agree.
     if (s->multi_slab()) return s->comm != nullptr && !s->peer_connected;

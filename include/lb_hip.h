@@ -336,8 +336,8 @@ int lb_set_variant(lb_sim *s, int variant);
 /* Slab handles (round 6; new work, the reference is single-device: opencl_dim.py:229-240).  Depth of the fused kernel the halo cycle
  * of lb_run runs on (the cycle is 2 x depth time steps between two exchanges): 0 = automatic (the size thresholds of
  * lb_set_variant's bits 12, 14, 15), 3 ... 7 = that depth wherever the smallest slab of the run has >= 16 x depth rows, 8 = seven
- * steps per launch by k_deep2<7> (two waves per strip and direction, 2 x 72 KB of LDS per CU) instead of k_deep<7> (2 x 80 KB: RCCL's
- * send / receive kernel, 20 KB of LDS per workgroup, then waits for places and slows what it shares SIMDs with).  With 0 the
+ * steps per launch by k_deep2<7> (two waves per strip and direction, in pairs per SIMD) instead of k_deep<7> (lone waves: RCCL's
+ * send / receive kernel slows the launches it runs beside by 5-30 %; k_deep2's do not run longer for it).  With 0 the
  * seven-step cycle runs on k_deep2 under the RCCL transport and on k_deep otherwise.  Results never depend on it (bitwise); EVERY
  * rank of a run must set the same value -- the ranks time the candidates together and agree (LB_D2Q9/slabs.py:
  * DistributedSlab.autotune). */
