@@ -363,11 +363,12 @@ class DistributedSlab(_SlabSet):
         self.run(n, wait=False)
         return self.engine.timer_stop()
 
-    def autotune(self, depths=(8, 7, 6, 5), cycles=3, rounds=2, placements=(False, True)):
+    def autotune(self, depths=(8, 7, 6, 5), cycles=20, rounds=2, placements=(False, True)):
         """Collective: the ranks time the halo cycle on each candidate TOGETHER -- a depth of the fused kernel (8: seven steps per
         launch by k_deep2, two waves per SIMD, which RCCL's kernel slows far less than it slows k_deep's lone waves) x where the exchange
         runs (beside the interior launches on its own stream, or between them on the compute stream: lb_set_exchange_inline) --,
-        `cycles` cycles of 2 x depth live time steps each (every candidate gives the same bits: tuning advances the simulation), the
+        `cycles` cycles of 2 x depth live time steps each (every candidate gives the same bits: tuning advances the simulation; twenty,
+        because what a transport's kernels cost the launches they run beside shows in a steady state only), the
         slowest rank's time counts, the best of `rounds`, and all set the candidate that is fastest per time step (lb_set_slab_cycle,
         lb_set_exchange_inline).  A whole-grid handle tunes itself (Simulation.autotune); slabs cannot: every rank must run the
         same schedule.  Returns {"depth": chosen, "exchange_inline": chosen, "ms_per_step": {depth: slowest rank's, the better

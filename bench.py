@@ -483,7 +483,7 @@ def main():
         # (depths 7, 6, 5 x the exchange beside / between the interior launches; twenty cycles per candidate: what RCCL's kernel costs
         #  the launches it runs beside shows in a steady state only -- six cycles had "beside" 7 % ahead where 140-step runs have it 3-6 %
         #  behind: profiles/r06i_bench_placement.txt, r06i_slab_proxy_placement.txt)
-        slab_tuning = sim.autotune(cycles=20, rounds=2)
+        slab_tuning = sim.autotune()               # (cycles=20, rounds=2: the defaults)
     if dist is not None and hasattr(eng, "exchange_timing") and args.transport in ("rccl", "peer"):
         eng.exchange_timing(True)
     copy_gbs = None

@@ -224,7 +224,7 @@ def test_distributed_slab_autotune_agrees_on_the_slowest_ranks_best_depth(tmp_pa
     for k in range(2):
         assert int(r[k]["depth"]) == 6 and int(r[k]["engine_depth"]) == 6
         assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["t6"]) - 0.13) < 1e-9 and abs(float(r[k]["t5"]) - 0.15) < 1e-9
-        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 3 * 3 * 2 * (7 + 7 + 6 + 5)
+        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 3 * 20 * 2 * (7 + 7 + 6 + 5)
         assert not bool(r[k]["inline"])                      # (an engine without lb_set_exchange_inline: nothing to place)
 
 
@@ -238,4 +238,4 @@ def test_distributed_slab_autotune_places_the_exchange_where_the_slowest_rank_is
         assert int(r[k]["depth"]) == 7 and int(r[k]["engine_depth"]) == 7
         assert bool(r[k]["inline"]) and bool(r[k]["engine_inline"])
         assert abs(float(r[k]["t7"]) - 0.30) < 1e-9 and abs(float(r[k]["i7"]) - 0.115) < 1e-9
-        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 2 * 3 * 3 * 2 * (7 + 7 + 6 + 5)
+        assert int(r[k]["steps"]) == int(r[k]["engine_steps"]) == 2 * 3 * 20 * 2 * (7 + 7 + 6 + 5)
