@@ -180,6 +180,9 @@ __global__ __launch_bounds__(64 * DEEP2_WAVES, 2) void k_deep2(const StepArgs a,
 #endif
     const int wy = (__builtin_amdgcn_readfirstlane(threadIdx.y) + (LB_DEEP2_SWAP ? ((blockIdx.x >> 8) & 1) * 2 : 0)) & 3;
     const int item = xcd_item(blockIdx.x, gridDim.x);
+#ifdef LB_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+#endif
     int sx, sy;
     if (item < strips * nsegs) {
         sx = item % strips;
@@ -202,6 +205,18 @@ __global__ __launch_bounds__(64 * DEEP2_WAVES, 2) void k_deep2(const StepArgs a,
     else if (wy == 1) deep2_front<BC, MASK, D, F, RWF, false>(a, x0, ym, yb - ym, trips, lds_front[1], lds_front[0], lds_ho[1], lds_dma[1]);
     else if (wy == 2) deep2_back<BC, MASK, MACRO, D, F, RWB, true>(a, x0, ym, ym - ya, trips, lds_back[0], lds_back[1], lds_ho[0]);
     else deep2_back<BC, MASK, MACRO, D, F, RWB, false>(a, x0, ym, yb - ym, trips, lds_back[1], lds_back[0], lds_ho[1]);
+#ifdef LB_DIAG
+    if ((a.diag & 4096) && threadIdx.x == 0) {
+        // per-wave timeline as k_deep's (tools/wave_timeline.py, LB_TIMELINE_DEEP2=1): four records per item; [6] = item * 4 + role
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned *o = reinterpret_cast<unsigned *>(a.rho) + 8 * (item * DEEP2_WAVES + wy);
+        o[0] = (unsigned)diag_t0; o[1] = (unsigned)(diag_t0 >> 32); o[2] = (unsigned)t1; o[3] = (unsigned)(t1 >> 32);
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+        o[6] = (unsigned)(item * DEEP2_WAVES + wy); o[7] = (unsigned)((wy & 1) ? yb - ym : ym - ya);
+    }
+#endif
 }
 
 }  // namespace

@@ -23,7 +23,8 @@ def main():
     #  from rebuilding them)
     sim = Simulation(n, ny, 1.7, bc=os.environ.get("LB_TIMELINE_BC", "periodic"), inlet_rho=1.0005)
     depth = int(os.environ.get("LB_TIMELINE_DEPTH", "4"))
-    sim.set_variant({4: 353, 6: 353 | 4096 | 16384, 7: 353 | 4096 | 16384 | 32768}[depth])
+    deep2 = os.environ.get("LB_TIMELINE_DEEP2") == "1"             # k_deep2<7>: four waves per item (front / back x down / up)
+    sim.set_variant({4: 353, 6: 353 | 4096 | 16384, 7: 353 | 4096 | 16384 | 32768}[depth] | (65536 if deep2 else 0))
     sim.init_equilibrium(*shear_layer(n, ny, 0, ny))
     sim.run(2 * depth)
     sim.run(depth)                                # the launch whose timeline is read
@@ -37,6 +38,8 @@ def main():
     seg_rows = max(-(-ny // segs), 8)
     segs = -(-ny // seg_rows)
     items = 2 * strips * segs
+    if deep2:
+        return deep2_report(u, strips, segs, n, ny)
     # (boxes with walls: the first / last strip march shorter segments, their extra items follow: read what is there)
     items = min(items + 8 * segs, u.size // 8)
     rec = u[:8 * items].reshape(items, 8).astype(np.int64)
@@ -80,6 +83,42 @@ def main():
     print("end by strip (max us):", " ".join("%.0f" % end[sx == i].max() for i in range(strips)))
     print("end by strip (median us):", " ".join("%.0f" % np.median(end[sx == i]) for i in range(strips)))
     print("end by segment (median us), first 16:", " ".join("%.0f" % np.median(end[sy == i]) for i in range(min(segs, 16))))
+
+
+def deep2_report(u, strips, segs, n, ny):
+    items = 4 * strips * segs
+    rec = u[:8 * items].reshape(items, 8).astype(np.int64)
+    t0 = rec[:, 0] | (rec[:, 1] << 32)
+    t1 = rec[:, 2] | (rec[:, 3] << 32)
+    ok = (rec[:, 6] == np.arange(items)) & (t1 > t0)
+    print("k_deep2, grid %d x %d: wave records %d, valid %d, pairs per strip %d" % (n, ny, items, int(ok.sum()), segs))
+    t0, t1, rec = t0[ok], t1[ok], rec[ok]
+    base = t0.min()
+    start, end = (t0 - base) / 100.0, (t1 - base) / 100.0
+    print("launch span %.1f us; wave start: median %.1f p90 %.1f max %.1f us; wave end: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f us"
+          % (end.max(), np.median(start), np.percentile(start, 90), start.max(), end.min(), np.percentile(end, 10), np.median(end),
+             np.percentile(end, 90), end.max()))
+    print("mean residency of a wave: %.1f %% of the launch" % (100 * (end - start).mean() / end.max()))
+    role = rec[:, 6] & 3
+    for r, name in enumerate(("front down", "front up", "back down", "back up")):
+        m = role == r
+        print("%-10s: %4d waves, start median %.1f, end median %.1f p90 %.1f max %.1f us, duration median %.1f us" % (
+            name, m.sum(), np.median(start[m]), np.median(end[m]), np.percentile(end[m], 90), end[m].max(), np.median((end - start)[m])))
+    hw = rec[:, 5]
+    simd, cu, se, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7, rec[:, 4] & 15
+    key = ((xcc * 8 + se) * 16 + cu) * 2 + ((hw >> 12) & 1)
+    per_cu = {}
+    for k, e in zip(key.tolist(), end.tolist()):
+        per_cu.setdefault(k, []).append(e)
+    counts = np.array([len(v) for v in per_cu.values()])
+    print("CUs holding waves: %d; waves per CU: %s" % (len(per_cu), dict(zip(*np.unique(counts, return_counts=True)))))
+    for c in sorted(set(counts.tolist())):
+        ends = np.array([max(v) for v in per_cu.values() if len(v) == c])
+        print("  CUs with %d waves: last wave ends median %.1f max %.1f us" % (c, np.median(ends), ends.max()))
+    hist, edges = np.histogram(end, bins=12)
+    print("wave ends, histogram:", " ".join("%.0f-%.0f:%d" % (edges[i], edges[i + 1], hist[i]) for i in range(len(hist))))
+    hist, edges = np.histogram(start, bins=8)
+    print("wave starts, histogram:", " ".join("%.0f-%.0f:%d" % (edges[i], edges[i + 1], hist[i]) for i in range(len(hist))))
 
 
 if __name__ == "__main__":
