@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: every GPU run of the round as one function each (run1 ... run59), in the order they were made; the header comment of a
+# Round 6: every GPU run of the round as one function each (run1 ... run60), in the order they were made; the header comment of a
 # function says what it measured, the outputs it names under gpurun_out/ were copied to profiles/ (profiles/r06_experiments.txt cites them).
 # Usage (through gpurun, from the repository root):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/r06/runs.sh 50'
 set -u
@@ -1152,7 +1152,20 @@ done
 sort $P
 }
 
+# round 6, GPU run 60: pinned profiles of configurations 2, 3, 5 on the final library (k_deep2 among the tuner's candidates)
+run60() {
+for c in 2 3 5; do
+  rm -rf gpurun_out/prof_r06zc$c
+  timeout 500 bash tools/gpu_profile.sh r06zc$c --config $c > gpurun_out/r06z_profile_c$c.log 2>&1
+  python3 - $c <<'PY'
+import json, sys
+d=json.loads(open("gpurun_out/prof_r06zc%s/unprofiled.json" % sys.argv[1]).read().strip().splitlines()[-1])
+print("config", sys.argv[1], d["value"], d["roofline"]["kernel"][:60], d["roofline"]["launch_ms"], d["roofline"]["frac"])
+PY
+done
+}
+
 if [ $# -ne 1 ] || ! declare -F "run$1" > /dev/null; then
-  echo "usage: bash tools/r06/runs.sh <1 ... 59>" >&2; exit 2
+  echo "usage: bash tools/r06/runs.sh <1 ... 60>" >&2; exit 2
 fi
 "run$1"
