@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: every GPU run of the round as one function each (run1 ... run60), in the order they were made; the header comment of a
+# Round 6: every GPU run of the round as one function each (run1 ... run61), in the order they were made; the header comment of a
 # function says what it measured, the outputs it names under gpurun_out/ were copied to profiles/ (profiles/r06_experiments.txt cites them).
 # Usage (through gpurun, from the repository root):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/r06/runs.sh 50'
 set -u
@@ -1165,7 +1165,19 @@ PY
 done
 }
 
+# round 6, GPU run 61: soak of the final library (the automatic choices after the size table's revision; k_deep2 forced): bitwise against the
+# single-step kernel over hundreds of steps, alone and beside a second process
+run61() {
+P=gpurun_out/r06z_soak.txt
+: > $P
+echo "== automatic choices, alone" >> $P
+timeout 600 python3 tools/soak_bitwise.py --more >> $P 2>&1
+echo "== k_deep2 forced (LB_SOAK_VARIANT=119137)" >> $P
+LB_SOAK_VARIANT=119137 timeout 600 python3 tools/soak_bitwise.py --more >> $P 2>&1
+grep -c "bitwise equal" $P; grep -v "bitwise equal" $P | head -20
+}
+
 if [ $# -ne 1 ] || ! declare -F "run$1" > /dev/null; then
-  echo "usage: bash tools/r06/runs.sh <1 ... 60>" >&2; exit 2
+  echo "usage: bash tools/r06/runs.sh <1 ... 61>" >&2; exit 2
 fi
 "run$1"

@@ -34,3 +34,10 @@ if "--more" in sys.argv:          # (round 5: the families of k_deep's hand-wait
     case("pipe", 8192, 8192, 150, False, inlet_rho=1.0005)
     case("cavity", 6144, 6144, 150, True, lid_u=0.05)
     case("periodic", 2048, 2048, 500, False)
+    # (round 6: the sizes the revised table gives to k_deep2<7> -- walled, 1700^2 ... 2900^2 cells --, k_deep<6> -- periodic from 1100^2 --
+    #  and the reference's own case)
+    case("pipe", 2048, 2048, 500, False, inlet_rho=1.0005)
+    case("cavity", 2304, 2304, 430, True, lid_u=0.05)
+    case("pipe", 3751, 1251, 500, True, inlet_rho=1.0005)
+    case("periodic", 1280, 1280, 700, False)
+    case("periodic", 1536, 1536, 600, True)
