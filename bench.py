@@ -152,7 +152,7 @@ def cpu_baseline(budgets=((256, 3.0), (1024, 4.0), (4096, 10.0)), all_cores_budg
     return out
 
 
-def load_pmc_traffic(key, plan):
+def load_pmc_traffic(key, plan, hot_kernel=""):
     """HBM bytes per launch, averaged over the launches of one timed block, from the committed rocprofv3 --pmc summaries of this
     workload (profiles/pmc_traffic.json, produced by tools/pmc_summary.py; key = grid side, or "c<config>/<side>" for the
     configurations other than the default; one entry per fused depth, "<key>/<steps per launch>").  `plan` = the depths of the
@@ -167,7 +167,9 @@ def load_pmc_traffic(key, plan):
         return None, "no traffic figure: %s unreadable (%s)" % (path, exc), None
     per_depth, srcs = {}, []
     for depth in sorted(set(plan)):
-        ent = d.get("%s/%d" % (key, depth))
+        # (seven steps per launch are k_deep<7>'s or k_deep2<7>'s: the profile of the kernel this line ran, if there is one)
+        family = "k_deep2" if (depth == 7 and "k_deep2" in hot_kernel) else ("k_deep" if depth >= 6 else None)
+        ent = (d.get("%s/%d:%s" % (key, depth, family)) if family else None) or d.get("%s/%d" % (key, depth))
         if not ent or not ent.get("hbm_bytes_per_launch"):
             return None, "no traffic figure: profiles/pmc_traffic.json holds no --pmc profile for %r (has: %s)" % (
                 "%s/%d" % (key, depth), ", ".join(sorted(d))), None
@@ -581,7 +583,7 @@ def main():
         bytes_per_launch = bytes_per_cell * n * h
         achieved = bytes_per_launch / launch_s / 1e9
         effective = B_ALG * n * h * args.steps / (ev_ms / 1e3) / 1e9
-        traffic, traffic_source, traffic_by_depth = load_pmc_traffic(n if args.config == 4 else "c%d/%d" % (args.config, n), plan or [spl]) \
+        traffic, traffic_source, traffic_by_depth = load_pmc_traffic(n if args.config == 4 else "c%d/%d" % (args.config, n), plan or [spl], eng.hot_kernel()) \
             if dist is None else (None, "no traffic figure: counters are collected on one GPU", None)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),

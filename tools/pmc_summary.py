@@ -121,6 +121,13 @@ def main():
         elif not macro and key in out:
             out[key + ":" + out[key]["kernel"].split("<")[0]] = out[key]
         if not macro:
+            # (also under "<key>:<kernel family>": k_deep<7> and k_deep2<7> both advance seven steps and either may be a line's kernel --
+            #  bench.py asks for its own first)
+            fam_key = ("%d/%d" % (side, spl) if config == 4 else "c%d/%d/%d" % (config, side, spl)) + ":" + k.split("<")[0]
+            out[fam_key] = {"calls_profiled": len(dur[k]), "kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr),
+                            "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "algorithmic_bytes": alg,
+                            "fetch_correction": round(fetch_corr, 4), "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1),
+                            "source": "profiles/%s_rocprof_summary.md" % tag}
             out[key] = {"calls_profiled": len(dur[k]),"kernel": k, "steps_per_launch": spl, "hbm_bytes_per_launch": round(rd + wr), "hbm_read_bytes": round(rd),
                    "hbm_write_bytes": round(wr), "algorithmic_bytes": alg, "fetch_correction": round(fetch_corr, 4),
                    "avg_launch_us_profiled": round(st.mean(dur[k]) / 1e3, 1), "source": "profiles/%s_rocprof_summary.md" % tag}
