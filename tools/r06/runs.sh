@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: every GPU run of the round as one function each (run1 ... run61), in the order they were made; the header comment of a
+# Round 6: every GPU run of the round as one function each (run1 ... run62), in the order they were made; the header comment of a
 # function says what it measured, the outputs it names under gpurun_out/ were copied to profiles/ (profiles/r06_experiments.txt cites them).
 # Usage (through gpurun, from the repository root):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/r06/runs.sh 50'
 set -u
@@ -1177,7 +1177,21 @@ LB_SOAK_VARIANT=119137 timeout 600 python3 tools/soak_bitwise.py --more >> $P 2>
 grep -c "bitwise equal" $P; grep -v "bitwise equal" $P | head -20
 }
 
+# round 6, GPU run 62: the driver's bench command on the last commit (traffic priced per kernel family), twice
+run62() {
+for rep in 1 2; do
+  timeout 600 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r06zz_bench_steps20_$rep.json 2> gpurun_out/r06zz_bench_steps20_$rep.err
+  python3 - $rep <<'PY'
+import json, sys
+d=json.loads(open("gpurun_out/r06zz_bench_steps20_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
+r=d["roofline"]
+print(d["value"], r["frac"], r.get("frac_plain_launch"), r["kernel"][:12], r["traffic"], r["traffic_frac"] if "traffic_frac" in r else None, r["traffic_source"][:120])
+print([(o["config"], o.get("value"), (o.get("kernel") or "")[:9], o.get("roofline_frac")) for o in d.get("other_configs", [])])
+PY
+done
+}
+
 if [ $# -ne 1 ] || ! declare -F "run$1" > /dev/null; then
-  echo "usage: bash tools/r06/runs.sh <1 ... 61>" >&2; exit 2
+  echo "usage: bash tools/r06/runs.sh <1 ... 62>" >&2; exit 2
 fi
 "run$1"
