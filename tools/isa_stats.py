@@ -26,6 +26,7 @@ TU = r"""
 #include "%(csrc)s/kernels_step4.h"
 #include "%(csrc)s/kernels_step5.h"
 #include "%(csrc)s/kernels_deep.h"
+#include "%(csrc)s/kernels_deep2.h"
 #include "%(csrc)s/kernels_tile.h"
 #include "%(csrc)s/kernels_phases.h"
 void isa_stats_force(hipStream_t st) { void *p = (void *)(&%(kernel)s); hipLaunchKernel(p, dim3(1), dim3(1), nullptr, 0, st); }
