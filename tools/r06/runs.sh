@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: every GPU run of the round as one function each (run1 ... run62), in the order they were made; the header comment of a
+# Round 6: every GPU run of the round as one function each (run1 ... run63), in the order they were made; the header comment of a
 # function says what it measured, the outputs it names under gpurun_out/ were copied to profiles/ (profiles/r06_experiments.txt cites them).
 # Usage (through gpurun, from the repository root):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/r06/runs.sh 50'
 set -u
@@ -1191,7 +1191,15 @@ PY
 done
 }
 
+# round 6, GPU run 63: the full GPU suite and smoke on the round's last commit
+run63() {
+timeout 1800 python3 -m pytest tests -m gpu -q > gpurun_out/r06_final_pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/r06_final_pytest_gpu.log
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/r06_final_pytest_gpu.log 2>&1
+grep -n "passed\|failed\|smoke ok\|pytest rc" gpurun_out/r06_final_pytest_gpu.log | tail -4
+}
+
 if [ $# -ne 1 ] || ! declare -F "run$1" > /dev/null; then
-  echo "usage: bash tools/r06/runs.sh <1 ... 62>" >&2; exit 2
+  echo "usage: bash tools/r06/runs.sh <1 ... 63>" >&2; exit 2
 fi
 "run$1"
